@@ -1,0 +1,172 @@
+// QKV self-attention forward / backward-to-input, shared by the UNet AttentionBlock (QKVAttentionLegacy /
+// QKVAttention of guided_diffusion) and the CLIP ViT nn.MultiheadAttention.
+//
+// Token-major qkv [nb*T][3C] comes straight out of the NHWC conv1x1 / in_proj GEMM.  Per (sequence, head):
+//   S = (q k^T) / sqrt(d)   (= (q*s)(k*s)^T with s = d^-1/4)   -> row softmax in fp32 -> P
+//   O = P v
+// The contractions run on the MFMA GEMM (batched over sequence x head through strides); the operand that
+// must be K-contiguous but is not (v for PV, P / dS for the transposed products) is produced by a tiled
+// transpose.  Rows of P are padded to a multiple of 4 floats with zeros.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// one wavefront per row, three passes over an L1/L2-resident row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, long rows, int T, int ld) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float* r = S + row * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < T; c += 64) mx = fmaxf(mx, r[c]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int c = lane; c < T; c += 64) {
+    const float e = __expf(r[c] - mx);
+    r[c] = e;
+    sum += e;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float inv = 1.f / sum;
+  for (int c = lane; c < ld; c += 64) r[c] = c < T ? r[c] * inv : 0.f;
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows, int T,
+                                                               int ld) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* p = P + row * ld;
+  float* d = dP + row * ld;
+  float s = 0.f;
+  for (int c = lane; c < T; c += 64) s += p[c] * d[c];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int c = lane; c < ld; c += 64) d[c] = c < T ? p[c] * (d[c] - s) : 0.f;
+}
+
+struct HeadOff {
+  long q, k, v, step;  // column offsets of head 0 and per-head step inside a 3C-wide row
+};
+HeadOff head_off(const AttnShape& sh) {
+  HeadOff h;
+  if (sh.legacy) {
+    h.q = 0;
+    h.k = sh.d;
+    h.v = 2 * sh.d;
+    h.step = 3 * sh.d;
+  } else {
+    h.q = 0;
+    h.k = sh.C;
+    h.v = 2 * sh.C;
+    h.step = sh.d;
+  }
+  return h;
+}
+
+}  // namespace
+
+int cgd_launch_softmax_rows(cgd_ctx* ctx, float* S, long rows, int T, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, S, rows, T, ld);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+int cgd_launch_softmax_bwd_rows(cgd_ctx* ctx, const float* P, float* dP, long rows, int T, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, P, dP, rows, T, ld);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, float* out, int ldo, const AttnBufs& bufs,
+                 hipStream_t s) {
+  const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
+  if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
+  const HeadOff ho = head_off(sh);
+  // qkvT[n][3C][Tp] <- qkv[n][T][3C]
+  CGD_TRY(cgd_launch_transpose(ctx, qkv, ldq, (long)T * ldq, bufs.qkvT, Tp, 3L * C * Tp, T, 3 * C, sh.nb, s));
+  // S = q k^T / sqrt(d)
+  GemmParams g;
+  g.A = qkv + ho.q;  g.lda = ldq;
+  g.B = qkv + ho.k;  g.ldb = ldq;
+  g.C = bufs.P;      g.ldc = Tp;
+  g.M = T; g.N = T; g.K = d;
+  g.alpha = 1.f / sqrtf((float)d);
+  g.nbatch = sh.nb * H; g.bdiv = H;
+  g.sA1 = (long)T * ldq; g.sA2 = ho.step;
+  g.sB1 = (long)T * ldq; g.sB2 = ho.step;
+  g.sC1 = (long)H * T * Tp; g.sC2 = (long)T * Tp;
+  CGD_TRY(cgd_launch_gemm(ctx, g, s));
+  CGD_TRY(cgd_launch_softmax_rows(ctx, bufs.P, (long)sh.nb * H * T, T, Tp, s));
+  // O = P v : B operand = v^T rows inside qkvT
+  GemmParams o;
+  o.A = bufs.P;  o.lda = Tp;
+  o.B = bufs.qkvT + ho.v * Tp;  o.ldb = Tp;
+  o.C = out;  o.ldc = ldo;
+  o.M = T; o.N = d; o.K = Tp;
+  o.nbatch = sh.nb * H; o.bdiv = H;
+  o.sA1 = (long)H * T * Tp; o.sA2 = (long)T * Tp;
+  o.sB1 = 3L * C * Tp; o.sB2 = ho.step * Tp;
+  o.sC1 = (long)T * ldo; o.sC2 = d;
+  CGD_TRY(cgd_launch_gemm(ctx, o, s));
+  return 0;
+}
+
+int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, const float* dout, int lddo, float* dqkv, int lddq,
+                 const AttnBufs& bufs, hipStream_t s) {
+  const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
+  const HeadOff ho = head_off(sh);
+  const float alpha = 1.f / sqrtf((float)d);
+  const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
+  // dP = dO v^T  (A = dO head slice, B = v token-major)
+  GemmParams g;
+  g.A = dout;  g.lda = lddo;
+  g.B = qkv + ho.v;  g.ldb = ldq;
+  g.C = bufs.dP;  g.ldc = Tp;
+  g.M = T; g.N = T; g.K = d;
+  g.nbatch = sh.nb * H; g.bdiv = H;
+  g.sA1 = (long)T * lddo; g.sA2 = d;
+  g.sB1 = (long)T * ldq; g.sB2 = ho.step;
+  g.sC1 = sP1; g.sC2 = sP2;
+  CGD_TRY(cgd_launch_gemm(ctx, g, s));
+  // dV[s][c] = sum_t P[t][s] dO[t][c] : A = P^T, B = dO^T
+  CGD_TRY(cgd_launch_transpose(ctx, bufs.P, Tp, sP2, bufs.Pt, Tp, sP2, T, T, sh.nb * H, s));
+  CGD_TRY(cgd_launch_transpose(ctx, dout, lddo, (long)T * lddo, bufs.dAt, Tp, (long)C * Tp, T, C, sh.nb, s));
+  GemmParams v;
+  v.A = bufs.Pt;  v.lda = Tp;
+  v.B = bufs.dAt;  v.ldb = Tp;
+  v.C = dqkv + ho.v;  v.ldc = lddq;
+  v.M = T; v.N = d; v.K = Tp;
+  v.nbatch = sh.nb * H; v.bdiv = H;
+  v.sA1 = sP1; v.sA2 = sP2;
+  v.sB1 = (long)C * Tp; v.sB2 = (long)d * Tp;
+  v.sC1 = (long)T * lddq; v.sC2 = ho.step;
+  CGD_TRY(cgd_launch_gemm(ctx, v, s));
+  // dS = P * (dP - rowsum(dP*P))   (in place in dP)
+  CGD_TRY(cgd_launch_softmax_bwd_rows(ctx, bufs.P, bufs.dP, (long)sh.nb * H * T, T, Tp, s));
+  // dQ[t][c] = alpha * sum_s dS[t][s] k[s][c] : B = k^T rows of qkvT
+  GemmParams q;
+  q.A = bufs.dP;  q.lda = Tp;
+  q.B = bufs.qkvT + ho.k * Tp;  q.ldb = Tp;
+  q.C = dqkv + ho.q;  q.ldc = lddq;
+  q.M = T; q.N = d; q.K = Tp;
+  q.alpha = alpha;
+  q.nbatch = sh.nb * H; q.bdiv = H;
+  q.sA1 = sP1; q.sA2 = sP2;
+  q.sB1 = 3L * C * Tp; q.sB2 = ho.step * Tp;
+  q.sC1 = (long)T * lddq; q.sC2 = ho.step;
+  CGD_TRY(cgd_launch_gemm(ctx, q, s));
+  // dK[s][c] = alpha * sum_t dS[t][s] q[t][c] : A = dS^T, B = q^T rows of qkvT
+  CGD_TRY(cgd_launch_transpose(ctx, bufs.dP, Tp, sP2, bufs.Pt, Tp, sP2, T, T, sh.nb * H, s));
+  GemmParams k;
+  k.A = bufs.Pt;  k.lda = Tp;
+  k.B = bufs.qkvT + ho.q * Tp;  k.ldb = Tp;
+  k.C = dqkv + ho.k;  k.ldc = lddq;
+  k.M = T; k.N = d; k.K = Tp;
+  k.alpha = alpha;
+  k.nbatch = sh.nb * H; k.bdiv = H;
+  k.sA1 = sP1; k.sA2 = sP2;
+  k.sB1 = 3L * C * Tp; k.sB2 = ho.step * Tp;
+  k.sC1 = (long)T * lddq; k.sC2 = ho.step;
+  CGD_TRY(cgd_launch_gemm(ctx, k, s));
+  return 0;
+}

@@ -1,0 +1,24 @@
+#!/usr/bin/env bash
+# Builds libcgd_mi355x.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libcgd_mi355x.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result"
+mkdir -p build
+objs=()
+pids=()
+for src in gemm norm elem attn guidance unet vit capi; do
+  obj=build/$src.o
+  objs+=("$obj")
+  if [[ ! -f $obj || $src.hip -nt $obj || common.h -nt $obj || kernels.h -nt $obj || net.h -nt $obj || guidance.h -nt $obj \
+        || ../../include/cgd_mi355x.h -nt $obj ]]; then
+    $HIPCC $FLAGS -c $src.hip -o $obj &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do
+  [[ -n "$p" ]] && wait "$p"
+done
+$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $OUT
+echo "built $(realpath $OUT)"

@@ -1,0 +1,77 @@
+// Shared declarations of libcgd_mi355x (gfx950 only).  Internal header: the public C ABI is
+// include/cgd_mi355x.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+// ---- precision modes of the MFMA contractions ------------------------------------------------
+// 0: fp32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products, 157 TF peak
+// 1: bf16x3 split (a = hi + lo, hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-17 per product
+// 2: single bf16 product (fp32 accumulate)
+enum { CGD_PREC_F32 = 0, CGD_PREC_BF16X3 = 1, CGD_PREC_BF16 = 2 };
+
+struct cgd_ctx {
+  int device = 0;
+  int precision = CGD_PREC_BF16X3;
+  std::string err;
+  float* ws = nullptr;       // split-K partial slabs
+  size_t ws_bytes = 0;
+  int num_cu = 256;
+};
+
+#define CGD_HIP(ctx, expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__) + " @" + __FILE__ + ":" + \
+                   std::to_string(__LINE__);                                                 \
+      return -1;                                                                             \
+    }                                                                                        \
+  } while (0)
+
+#define CGD_FAIL(ctx, msg)        \
+  do {                            \
+    (ctx)->err = (msg);           \
+    return -2;                    \
+  } while (0)
+
+#define CGD_TRY(expr)             \
+  do {                            \
+    int r__ = (expr);             \
+    if (r__ != 0) return r__;     \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- GEMM / implicit-GEMM conv ---------------------------------------------------------------
+// C[M][N] = alpha * sum_k A[m][k] * B[n][k] (+ bias[n]) (+ R[m][n]);  A and B are K-contiguous fp32.
+// conv=1: A is an NHWC activation [Bn*H*W][lda] (Cin used channels) and the contraction runs over
+// k = tap*Cin + ci, tap = ky*3+kx, with zero padding 1; `ups`=1 reads a (H/2,W/2) source through a
+// nearest-2x upsample view.  B is the packed weight [N][9*Cin].
+struct GemmParams {
+  const float* A = nullptr;
+  const float* B = nullptr;
+  float* C = nullptr;
+  const float* bias = nullptr;
+  const float* R = nullptr;
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldb = 0, ldc = 0, ldr = 0;
+  int nbatch = 1, bdiv = 1;  // z -> (z / bdiv, z % bdiv)
+  long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sC1 = 0, sC2 = 0, sR1 = 0, sR2 = 0;
+  float alpha = 1.f;
+  int conv = 0, H = 0, W = 0, Cin = 0, ups = 0;
+  int splitk = 1;
+  float* ws = nullptr;
+  int force_tile = 0;  // 0 auto, 64, 128
+};
+
+int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s);
+
+// thin direct convs for the 3-channel ends of the UNet
+int cgd_launch_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w /*[Cout][3][3][Cin] (co,ky,kx,ci)*/, const float* bias,
+                       float* y_nhwc, int Bn, int H, int W, int Cin, int Cout, hipStream_t s);
+int cgd_launch_conv_thin_out(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w /*[Cout][9*Cin]*/, const float* bias,
+                             float* y_nchw, int Bn, int H, int W, int Cin, int Cout, hipStream_t s);

@@ -1,0 +1,449 @@
+// GroupNorm(32)+FiLM+SiLU and LayerNorm, forward and backward-to-input, NHWC fp32.  HBM-bound kernels:
+// every tensor pass is a coalesced float4 stream; statistics are shifted per-channel sums merged with
+// Chan's formula (robust when |mean| >> std), reductions are deterministic (no atomics).
+//
+// Replaces guided_diffusion's GroupNorm32 -> SiLU (ResBlock.in_layers), out_norm(h)*(1+scale)+shift -> SiLU
+// (ResBlock.out_layers with use_scale_shift_norm) and clip's fp32 LayerNorm.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXJ = 4;  // float4 column iterations per thread: C <= 4096
+
+struct ColMap {
+  int cq, TQ, rows, r, q0;
+  bool active;
+};
+__device__ __forceinline__ ColMap col_map(int C) {
+  ColMap m;
+  m.cq = C >> 2;
+  m.TQ = m.cq < 256 ? m.cq : 256;
+  m.rows = 256 / m.TQ;
+  m.r = threadIdx.x / m.TQ;
+  m.q0 = threadIdx.x % m.TQ;
+  m.active = m.r < m.rows;
+  return m;
+}
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.f + __expf(-u)); }
+__device__ __forceinline__ float dsilu_f(float u) {
+  const float s = 1.f / (1.f + __expf(-u));
+  return s * (1.f + u * (1.f - s));
+}
+
+// ---- forward statistics: per (b, chunk, group) -> (mean, M2) ------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __restrict__ x, int ldx, int HW, int C, int chunk,
+                                                               float* __restrict__ part /*[B][nchunk][32][2]*/) {
+  __shared__ float lds_s[1024 * 4], lds_ss[1024 * 4], lds_k[1024 * 4];  // up to 4096 channels
+  __shared__ float red_s[256 * 4], red_ss[256 * 4];
+  const ColMap m = col_map(C);
+  const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x;
+  const int p0 = ck * chunk, p1 = min(HW, p0 + chunk);
+  const float* xb = x + ((long)b * HW) * ldx;
+  const int cpg = C / 32;
+  // rows>1 and a column loop never coexist (rows>1 <=> cq<256 <=> one column iteration)
+  for (int j = 0; j < MAXJ; ++j) {
+    const int q = m.q0 + j * m.TQ;
+    if (q >= m.cq) break;
+    float4 k4 = *(const float4*)(xb + (long)p0 * ldx + q * 4);
+    float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
+    if (m.active) {
+      for (int p = p0 + m.r; p < p1; p += m.rows) {
+        const float4 v = *(const float4*)(xb + (long)p * ldx + q * 4);
+        const float dx = v.x - k4.x, dy = v.y - k4.y, dz = v.z - k4.z, dw = v.w - k4.w;
+        s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+        ss.x += dx * dx; ss.y += dy * dy; ss.z += dz * dz; ss.w += dw * dw;
+      }
+    }
+    if (m.rows > 1) {
+      // cross-row reduction through LDS (rows*cq float4 <= 256 float4)
+      if (m.active) {
+        *(float4*)&red_s[(m.r * m.cq + q) * 4] = s;
+        *(float4*)&red_ss[(m.r * m.cq + q) * 4] = ss;
+      }
+      __syncthreads();
+      if (m.r == 0) {
+        for (int rr = 1; rr < m.rows; ++rr) {
+          const float4 a = *(const float4*)&red_s[(rr * m.cq + q) * 4];
+          const float4 c = *(const float4*)&red_ss[(rr * m.cq + q) * 4];
+          s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+          ss.x += c.x; ss.y += c.y; ss.z += c.z; ss.w += c.w;
+        }
+      }
+    }
+    if (m.r == 0) {
+      *(float4*)&lds_s[q * 4] = s;
+      *(float4*)&lds_ss[q * 4] = ss;
+      *(float4*)&lds_k[q * 4] = k4;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int g = threadIdx.x;
+    const float n = (float)(p1 - p0);
+    float msum = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) msum += lds_k[c] + lds_s[c] / n;
+    const float mg = msum / cpg;
+    float m2 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const float mc = lds_k[c] + lds_s[c] / n;
+      m2 += (lds_ss[c] - lds_s[c] * lds_s[c] / n) + n * (mc - mg) * (mc - mg);
+    }
+    float* o = part + (((long)b * nchunk + ck) * 32 + g) * 2;
+    o[0] = mg;
+    o[1] = m2;
+  }
+}
+
+// merge chunks -> stats[b][g] = (mean, rstd); one wavefront per (b, g)
+__global__ __launch_bounds__(64) void gn_stats_final_kernel(const float* __restrict__ part, int nchunk, int HW, int chunk, int cpg,
+                                                            float eps, float* __restrict__ stats /*[B][32][2]*/) {
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  double wsum = 0.0;
+  for (int ck = lane; ck < nchunk; ck += 64) {
+    const int n = min(HW, (ck + 1) * chunk) - ck * chunk;
+    wsum += (double)n * part[(((long)b * nchunk + ck) * 32 + g) * 2];
+  }
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+  const double mean = wsum / (double)HW;
+  double m2 = 0.0;
+  for (int ck = lane; ck < nchunk; ck += 64) {
+    const int n = min(HW, (ck + 1) * chunk) - ck * chunk;
+    const float* pp = part + (((long)b * nchunk + ck) * 32 + g) * 2;
+    const double d = (double)pp[0] - mean;
+    m2 += (double)pp[1] + (double)n * cpg * d * d;
+  }
+  for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+  if (lane == 0) {
+    const double var = m2 / ((double)HW * cpg);
+    stats[((long)b * 32 + g) * 2 + 0] = (float)mean;
+    stats[((long)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// fold (mean, rstd, gamma, beta, film) into per-channel y = x*a + b; coef[b][c] = {a, b, gcoef = gamma*(1+scale), mean}
+__global__ void gn_coef_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ film /*[B][ldfilm] scale|shift or null*/, int ldfilm, int C, float* __restrict__ coef) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int g = c / (C / 32);
+  const float mean = stats[((long)b * 32 + g) * 2], rstd = stats[((long)b * 32 + g) * 2 + 1];
+  float gm = gamma[c], bt = beta[c];
+  if (film) {
+    const float sc = 1.f + film[(long)b * ldfilm + c], sh = film[(long)b * ldfilm + C + c];
+    gm *= sc;
+    bt = bt * sc + sh;
+  }
+  float* o = coef + ((long)b * C + c) * 4;
+  o[0] = gm * rstd;
+  o[1] = bt - mean * gm * rstd;
+  o[2] = gm;
+  o[3] = mean;
+}
+
+// y = act(x*a + b)
+template <int ACT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int HW,
+                                                       int C, int chunk, const float* __restrict__ coef) {
+  const ColMap m = col_map(C);
+  if (!m.active) return;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * chunk, p1 = min(HW, p0 + chunk);
+  const float* xb = x + ((long)b * HW) * ldx;
+  float* yb = y + ((long)b * HW) * ldy;
+  for (int j = 0; j < MAXJ; ++j) {
+    const int q = m.q0 + j * m.TQ;
+    if (q >= m.cq) break;
+    const float4* cf = (const float4*)(coef + ((long)b * C + q * 4) * 4);
+    const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+    for (int p = p0 + m.r; p < p1; p += m.rows) {
+      const float4 v = *(const float4*)(xb + (long)p * ldx + q * 4);
+      float4 o;
+      o.x = v.x * c0.x + c0.y;
+      o.y = v.y * c1.x + c1.y;
+      o.z = v.z * c2.x + c2.y;
+      o.w = v.w * c3.x + c3.y;
+      if (ACT == 1) {
+        o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w);
+      }
+      *(float4*)(yb + (long)p * ldy + q * 4) = o;
+    }
+  }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------
+// du = dz * act'(u), u = x*a+b.  per (b, chunk, group): P1 = sum_c gcoef_c * sum du ; P2 = sum_c gcoef_c * sum du*(x-mean)
+template <int ACT>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz,
+                                                             int lddz, int HW, int C, int chunk, const float* __restrict__ coef,
+                                                             float* __restrict__ part /*[B][nchunk][32][2]*/) {
+  __shared__ float lds_1[1024 * 4], lds_2[1024 * 4];
+  __shared__ float red_1[256 * 4], red_2[256 * 4];
+  const ColMap m = col_map(C);
+  const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x;
+  const int p0 = ck * chunk, p1 = min(HW, p0 + chunk);
+  const float* xb = x + ((long)b * HW) * ldx;
+  const float* db = dz + ((long)b * HW) * lddz;
+  const int cpg = C / 32;
+  for (int j = 0; j < MAXJ; ++j) {
+    const int q = m.q0 + j * m.TQ;
+    if (q >= m.cq) break;
+    const float4* cf = (const float4*)(coef + ((long)b * C + q * 4) * 4);
+    const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    if (m.active) {
+      for (int p = p0 + m.r; p < p1; p += m.rows) {
+        const float4 v = *(const float4*)(xb + (long)p * ldx + q * 4);
+        float4 d = *(const float4*)(db + (long)p * lddz + q * 4);
+        if (ACT == 1) {
+          d.x *= dsilu_f(v.x * c0.x + c0.y);
+          d.y *= dsilu_f(v.y * c1.x + c1.y);
+          d.z *= dsilu_f(v.z * c2.x + c2.y);
+          d.w *= dsilu_f(v.w * c3.x + c3.y);
+        }
+        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        s2.x += d.x * (v.x - c0.w); s2.y += d.y * (v.y - c1.w); s2.z += d.z * (v.z - c2.w); s2.w += d.w * (v.w - c3.w);
+      }
+    }
+    if (m.rows > 1) {
+      if (m.active) {
+        *(float4*)&red_1[(m.r * m.cq + q) * 4] = s1;
+        *(float4*)&red_2[(m.r * m.cq + q) * 4] = s2;
+      }
+      __syncthreads();
+      if (m.r == 0) {
+        for (int rr = 1; rr < m.rows; ++rr) {
+          const float4 a = *(const float4*)&red_1[(rr * m.cq + q) * 4];
+          const float4 c = *(const float4*)&red_2[(rr * m.cq + q) * 4];
+          s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+          s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+        }
+      }
+    }
+    if (m.r == 0) {
+      s1.x *= c0.z; s1.y *= c1.z; s1.z *= c2.z; s1.w *= c3.z;
+      s2.x *= c0.z; s2.y *= c1.z; s2.z *= c2.z; s2.w *= c3.z;
+      *(float4*)&lds_1[q * 4] = s1;
+      *(float4*)&lds_2[q * 4] = s2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int g = threadIdx.x;
+    float a = 0.f, c2 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      a += lds_1[c];
+      c2 += lds_2[c];
+    }
+    float* o = part + (((long)b * nchunk + ck) * 32 + g) * 2;
+    o[0] = a;
+    o[1] = c2;
+  }
+}
+
+// bcoef[b][c] = {A1 = rstd*gcoef, A2 = rstd^3 * mean_g(dxhat*(x-mean)) , A3 = rstd * mean_g(dxhat), unused}
+// dx = du*A1 - (x-mean)*A2 - A3
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ stats,
+                                   const float* __restrict__ coef, int C, int HW, float* __restrict__ bcoef) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int cpg = C / 32, g = c / cpg;
+  double p1 = 0.0, p2 = 0.0;
+  for (int ck = 0; ck < nchunk; ++ck) {
+    const float* pp = part + (((long)b * nchunk + ck) * 32 + g) * 2;
+    p1 += pp[0];
+    p2 += pp[1];
+  }
+  const double N = (double)HW * cpg;
+  const float rstd = stats[((long)b * 32 + g) * 2 + 1];
+  float* o = bcoef + ((long)b * C + c) * 4;
+  o[0] = rstd * coef[((long)b * C + c) * 4 + 2];
+  o[1] = (float)((double)rstd * rstd * rstd * p2 / N);
+  o[2] = (float)((double)rstd * p1 / N);
+  o[3] = 0.f;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz,
+                                                           int lddz, float* __restrict__ dx, int lddx, const float* __restrict__ add,
+                                                           int ldadd, int HW, int C, int chunk, const float* __restrict__ coef,
+                                                           const float* __restrict__ bcoef) {
+  const ColMap m = col_map(C);
+  if (!m.active) return;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * chunk, p1 = min(HW, p0 + chunk);
+  const float* xb = x + ((long)b * HW) * ldx;
+  const float* db = dz + ((long)b * HW) * lddz;
+  float* ob = dx + ((long)b * HW) * lddx;
+  const float* ab = add ? add + ((long)b * HW) * ldadd : nullptr;
+  for (int j = 0; j < MAXJ; ++j) {
+    const int q = m.q0 + j * m.TQ;
+    if (q >= m.cq) break;
+    const float4* cf = (const float4*)(coef + ((long)b * C + q * 4) * 4);
+    const float4* bf = (const float4*)(bcoef + ((long)b * C + q * 4) * 4);
+    const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+    const float4 b0 = bf[0], b1 = bf[1], b2 = bf[2], b3 = bf[3];
+    for (int p = p0 + m.r; p < p1; p += m.rows) {
+      const float4 v = *(const float4*)(xb + (long)p * ldx + q * 4);
+      float4 d = *(const float4*)(db + (long)p * lddz + q * 4);
+      if (ACT == 1) {
+        d.x *= dsilu_f(v.x * c0.x + c0.y);
+        d.y *= dsilu_f(v.y * c1.x + c1.y);
+        d.z *= dsilu_f(v.z * c2.x + c2.y);
+        d.w *= dsilu_f(v.w * c3.x + c3.y);
+      }
+      float4 o;
+      o.x = d.x * b0.x - (v.x - c0.w) * b0.y - b0.z;
+      o.y = d.y * b1.x - (v.y - c1.w) * b1.y - b1.z;
+      o.z = d.z * b2.x - (v.z - c2.w) * b2.y - b2.z;
+      o.w = d.w * b3.x - (v.w - c3.w) * b3.y - b3.z;
+      if (ab) {
+        const float4 a = *(const float4*)(ab + (long)p * ldadd + q * 4);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      }
+      *(float4*)(ob + (long)p * lddx + q * 4) = o;
+    }
+  }
+}
+
+// ---- LayerNorm: one wavefront per row -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int rows,
+                                                     int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float* __restrict__ stats /*[rows][2]*/) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = xr[c] - mean;
+    v += d * d;
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const float rstd = rsqrtf(v / C + eps);
+  float* yr = y + (long)row * ldy;
+  for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+  if (lane == 0 && stats) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+}
+
+// dx = rstd*(dy*g - mean(dy*g) - xhat*mean(dy*g*xhat)) (+ add)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                     float* __restrict__ dx, int lddx, const float* __restrict__ add, int ldadd,
+                                                     int rows, int C, const float* __restrict__ gamma,
+                                                     const float* __restrict__ stats) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  const float* dr = dy + (long)row * lddy;
+  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float g = dr[c] * gamma[c];
+    s1 += g;
+    s2 += g * (xr[c] - mean) * rstd;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  s1 /= C;
+  s2 /= C;
+  float* orow = dx + (long)row * lddx;
+  const float* ar = add ? add + (long)row * ldadd : nullptr;
+  for (int c = lane; c < C; c += 64) {
+    const float xh = (xr[c] - mean) * rstd;
+    float o = rstd * (dr[c] * gamma[c] - s1 - xh * s2);
+    if (ar) o += ar[c];
+    orow[c] = o;
+  }
+}
+
+int pick_chunk(int HW, int B) {
+  // aim at >= ~1024 workgroups for big tensors, >= 8 pixels per chunk
+  int chunk = HW * B / 1024;
+  if (chunk < 8) chunk = 8;
+  if (chunk > 256) chunk = 256;
+  if (chunk > HW) chunk = HW;
+  return chunk;
+}
+
+}  // namespace
+
+size_t cgd_gn_scratch_floats(int B, int HW, int C) {
+  const int chunk = pick_chunk(HW, B);
+  const int nchunk = cdiv(HW, chunk);
+  return (size_t)B * nchunk * 64 + (size_t)B * 64 + (size_t)B * C * 4 * 2;
+}
+
+// scratch layout: part | stats (B*64) | coef (B*C*4) | bcoef (B*C*4)
+static void gn_layout(float* scratch, int B, int HW, int C, int* chunk, int* nchunk, float** part, float** stats, float** coef,
+                      float** bcoef) {
+  *chunk = pick_chunk(HW, B);
+  *nchunk = cdiv(HW, *chunk);
+  *part = scratch;
+  *stats = *part + (size_t)B * *nchunk * 64;
+  *coef = *stats + (size_t)B * 64;
+  *bcoef = *coef + (size_t)B * C * 4;
+}
+
+int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma,
+                      const float* beta, const float* film, int ldfilm, int act, float eps, float* scratch, hipStream_t s) {
+  if (C % 32 || C > 4096) CGD_FAIL(ctx, "groupnorm: C must be a multiple of 32 and <= 4096");
+  if ((ldx & 3) || (ldy & 3)) CGD_FAIL(ctx, "groupnorm: row strides must be multiples of 4");
+  int chunk, nchunk;
+  float *part, *stats, *coef, *bcoef;
+  gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ldx, HW, C, chunk, part);
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(64), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats);
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, stats, gamma, beta, film, ldfilm, C, coef);
+  if (act)
+    hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add,
+                      int ldadd, int B, int HW, int C, int act, float* scratch, hipStream_t s) {
+  int chunk, nchunk;
+  float *part, *stats, *coef, *bcoef;
+  gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  if (act) {
+    hipLaunchKernelGGL((gn_bwd_partial_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, HW, C, chunk, coef, part);
+  } else {
+    hipLaunchKernelGGL((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, HW, C, chunk, coef, part);
+  }
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
+  if (act) {
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C,
+                       chunk, coef, bcoef);
+  } else {
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C,
+                       chunk, coef, bcoef);
+  }
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int cgd_launch_ln_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int rows, int C, const float* gamma,
+                      const float* beta, float eps, float* stats, hipStream_t s) {
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps, stats);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int cgd_launch_ln_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, const float* add,
+                      int ldadd, int rows, int C, const float* gamma, const float* stats, hipStream_t s) {
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, C, gamma,
+                     stats);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,597 @@
+// ADM UNet (guided_diffusion.unet.UNetModel) forward and backward-to-input on MI355X.
+//
+// Replaces the `model(x, timesteps, y)` callable the reference hands to the sampler
+// (/root/reference/cgd/cgd.py:251, built at /root/reference/cgd/script_util.py:316 from
+// /root/reference/data/diffusion_model_flags.py) and the UNet leg of th.autograd.grad(loss, x) (cgd.py:228).
+// Only d/dx is ever taken, so no weight gradient exists here: the backward of every conv / linear is the same
+// MFMA kernel on a second, pre-rotated / pre-transposed copy of the weights packed once at load.
+//
+// Layout: activations NHWC fp32 (pixel-major rows, channels contiguous) so that conv1x1 / qkv / proj are plain
+// GEMMs and conv3x3 is an implicit GEMM whose K-slices are contiguous channel runs; the public tensors stay NCHW
+// (3- and 6-channel ends are handled by thin direct kernels that convert on the fly).
+// Every buffer is allocated on the first call for a given (B,H,W) and reused afterwards: the hot loop does not
+// allocate.  288 GB of HBM makes aliasing unnecessary: each intermediate owns its buffer.
+#include <cmath>
+#include <memory>
+
+#include "../../include/cgd_mi355x.h"
+#include "net.h"
+
+namespace {
+
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd, int Co, int Ci) {
+  const long total = (long)Co * Ci * 9;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kx = (int)(i % 3);
+    long t = i / 3;
+    const int ky = (int)(t % 3);
+    t /= 3;
+    const int ci = (int)(t % Ci), co = (int)(t / Ci);
+    const float v = w[i];
+    if (wf) wf[((long)co * 9 + ky * 3 + kx) * Ci + ci] = v;
+    if (wd) wd[((long)ci * 9 + (2 - ky) * 3 + (2 - kx)) * Co + co] = v;
+  }
+}
+
+}  // namespace
+
+int cgd_pack_conv3x3(cgd_ctx* ctx, const float* w, float* wf, float* wd, int Co, int Ci, hipStream_t s) {
+  const long total = (long)Co * Ci * 9;
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wf, wd, Co, Ci);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+namespace {
+
+struct UNet;
+
+struct Module {
+  virtual ~Module() {}
+  virtual int fwd(UNet& u, TV x, int B, int& H, int& W, TV* out, hipStream_t s) = 0;
+  virtual int bwd(UNet& u, TV dout, TV* din, hipStream_t s) = 0;
+};
+
+struct ResBlock : Module {
+  std::string pre;
+  int cin = 0, cout = 0;
+  bool up = false, down = false, skip_conv = false;
+  long emb_off = 0;
+  // params / packed
+  float *g1 = 0, *b1 = 0, *cw1f = 0, *cw1d = 0, *cb1 = 0, *g2 = 0, *b2 = 0, *cw2f = 0, *cw2d = 0, *cb2 = 0, *skw = 0, *skwT = 0,
+        *skb = 0;
+  // runtime
+  int B = 0, H = 0, W = 0, Ho = 0, Wo = 0;
+  TV x;
+  DevBuf h1, h1p, xr, h2, h3, out, s1, s2;
+  DevBuf d3, d2, d1, d1f, dx;
+  int fwd(UNet& u, TV x, int B, int& H, int& W, TV* out, hipStream_t s) override;
+  int bwd(UNet& u, TV dout, TV* din, hipStream_t s) override;
+};
+
+struct AttnBlock : Module {
+  std::string pre;
+  int C = 0, heads = 0, d = 0, legacy = 1;
+  float *g = 0, *b = 0, *qkvw = 0, *qkvwT = 0, *qkvb = 0, *pw = 0, *pwT = 0, *pb = 0;
+  int B = 0, T = 0;
+  TV x;
+  DevBuf n, qkv, a, out, sc, qkvT, P, Pt, dP, dAt, da, dqkv, dn, dx;
+  int fwd(UNet& u, TV x, int B, int& H, int& W, TV* out, hipStream_t s) override;
+  int bwd(UNet& u, TV dout, TV* din, hipStream_t s) override;
+};
+
+struct UNet : NetBase {
+  cgd_unet_config cfg;
+  int ted = 0, ch0 = 0, ch_last = 0;
+  long emb_total = 0;
+  std::vector<std::vector<std::unique_ptr<Module>>> in_blocks;  // in_blocks[0] is the stem conv (empty vector)
+  std::vector<std::unique_ptr<Module>> mid;
+  std::vector<std::vector<std::unique_ptr<Module>>> out_blocks;
+  std::vector<int> in_chans;  // channels of every hs entry
+  std::vector<ResBlock*> resblocks;
+  // packed stem / head weights
+  float *stem_wf = 0, *stem_wd = 0, *head_wf = 0, *head_wd = 0;
+  float *emb_w_all = 0, *emb_b_all = 0, *freqs = 0;
+  // runtime
+  int B = 0, H = 0, W = 0;
+  bool have_fwd = false;
+  DevBuf temb, e1, e1s, e2, e2s, emb_all, h0, headn, head_s, dheadn, dhead;
+  std::vector<DevBuf> cats;
+  std::vector<TV> hs;
+  std::vector<std::pair<int, int>> hs_hw;
+  std::vector<TV> cat_in;       // [h | skip] view fed to each output block
+  std::vector<int> cat_c1;      // channels of the h part
+  std::vector<std::pair<int, int>> cat_hw;
+  TV head_in;
+
+  int build();
+  int finalize(hipStream_t s);
+  int forward(const float* x, const float* t, const int64_t* y, float* out, int B, int H, int W, hipStream_t s);
+  int dgrad(const float* gout, float* gx, hipStream_t s);
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t s) {
+  cgd_ctx* ctx = u.ctx;
+  B = Bn; H = Hh; W = Ww;
+  Ho = up ? 2 * H : (down ? H / 2 : H);
+  Wo = up ? 2 * W : (down ? W / 2 : W);
+  x = xin;
+  const long npi = (long)B * H * W, npo = (long)B * Ho * Wo;
+  CGD_TRY(u.ensure(s1, cgd_gn_scratch_floats(B, H * W, cin)));
+  CGD_TRY(u.ensure(s2, cgd_gn_scratch_floats(B, Ho * Wo, cout)));
+  CGD_TRY(u.ensure(h1, npi * cin));
+  CGD_TRY(u.ensure(h2, npo * cout));
+  CGD_TRY(u.ensure(h3, npo * cout));
+  CGD_TRY(u.ensure(out, npo * cout));
+  // in_layers: GN -> SiLU
+  CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, h1.p, cin, B, H * W, cin, g1, b1, nullptr, 0, 1, 1e-5f, s1.p, s));
+  const float* conv_in = h1.p;
+  const float* skip_src = x.p;
+  int skip_ld = x.ld;
+  if (down) {
+    CGD_TRY(u.ensure(h1p, npo * cin));
+    CGD_TRY(u.ensure(xr, npo * cin));
+    CGD_TRY(cgd_launch_pool2x2(ctx, h1.p, cin, h1p.p, cin, nullptr, 0, B, Ho, Wo, cin, 0.25f, s));
+    CGD_TRY(cgd_launch_pool2x2(ctx, x.p, x.ld, xr.p, cin, nullptr, 0, B, Ho, Wo, cin, 0.25f, s));
+    conv_in = h1p.p;
+    skip_src = xr.p;
+    skip_ld = cin;
+  } else if (up) {
+    CGD_TRY(u.ensure(xr, npo * cin));
+    CGD_TRY(cgd_launch_upsample2x(ctx, x.p, x.ld, xr.p, cin, nullptr, 0, B, Ho, Wo, cin, 1.f, s));
+    skip_src = xr.p;
+    skip_ld = cin;
+  }
+  // conv1 (the nearest-2x upsample of an `up` block is folded into the conv's gather)
+  GemmParams c1;
+  c1.A = conv_in; c1.lda = cin; c1.B = cw1f; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
+  c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
+  CGD_TRY(cgd_launch_gemm(ctx, c1, s));
+  // out_layers: GN * (1+scale) + shift -> SiLU -> conv2 (+ skip)
+  CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, h3.p, cout, B, Ho * Wo, cout, g2, b2, u.emb_all.p + emb_off, (int)u.emb_total, 1, 1e-5f,
+                            s2.p, s));
+  const float* R = skip_src;
+  int ldr = skip_ld;
+  if (skip_conv) {
+    GemmParams sk;
+    sk.A = skip_src; sk.lda = skip_ld; sk.B = skw; sk.ldb = cin; sk.C = out.p; sk.ldc = cout; sk.bias = skb;
+    sk.M = (int)npo; sk.N = cout; sk.K = cin;
+    CGD_TRY(cgd_launch_gemm(ctx, sk, s));
+    R = out.p;
+    ldr = cout;
+  }
+  GemmParams c2;
+  c2.A = h3.p; c2.lda = cout; c2.B = cw2f; c2.ldb = 9 * cout; c2.C = out.p; c2.ldc = cout; c2.bias = cb2; c2.R = R; c2.ldr = ldr;
+  c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
+  CGD_TRY(cgd_launch_gemm(ctx, c2, s));
+  Hh = Ho; Ww = Wo;
+  *o = TV{out.p, cout, cout};
+  return 0;
+}
+
+int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
+  cgd_ctx* ctx = u.ctx;
+  const long npi = (long)B * H * W, npo = (long)B * Ho * Wo;
+  CGD_TRY(u.ensure(d3, npo * cout));
+  CGD_TRY(u.ensure(d2, npo * cout));
+  CGD_TRY(u.ensure(d1, npo * cin));
+  CGD_TRY(u.ensure(dx, npi * cin));
+  // conv2 dgrad
+  GemmParams c2;
+  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
+  c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
+  CGD_TRY(cgd_launch_gemm(ctx, c2, s));
+  // GN2 + FiLM + SiLU backward
+  CGD_TRY(cgd_launch_gn_bwd(ctx, h2.p, cout, d3.p, cout, d2.p, cout, nullptr, 0, B, Ho * Wo, cout, 1, s2.p, s));
+  // conv1 dgrad (at the conv's own resolution)
+  GemmParams c1;
+  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
+  c1.M = (int)npo; c1.N = cin; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cout;
+  CGD_TRY(cgd_launch_gemm(ctx, c1, s));
+  // skip path first into dx, then GN1 backward accumulates on top
+  const float* dh1 = d1.p;
+  const float* add = nullptr;
+  int ldadd = 0;
+  if (down) {
+    // h_upd = x_upd = AvgPool2d(2): adjoint = nearest upsample * 0.25
+    CGD_TRY(u.ensure(d1f, npi * cin));
+    CGD_TRY(cgd_launch_upsample2x(ctx, d1.p, cin, d1f.p, cin, nullptr, 0, B, H, W, cin, 0.25f, s));
+    dh1 = d1f.p;
+    CGD_TRY(cgd_launch_upsample2x(ctx, dout.p, dout.ld, dx.p, cin, nullptr, 0, B, H, W, cin, 0.25f, s));  // identity skip
+    add = dx.p; ldadd = cin;
+  } else if (up) {
+    // nearest upsample adjoint = 2x2 sum
+    CGD_TRY(u.ensure(d1f, npi * cin));
+    CGD_TRY(cgd_launch_pool2x2(ctx, d1.p, cin, d1f.p, cin, nullptr, 0, B, H, W, cin, 1.f, s));
+    dh1 = d1f.p;
+    CGD_TRY(cgd_launch_pool2x2(ctx, dout.p, dout.ld, dx.p, cin, nullptr, 0, B, H, W, cin, 1.f, s));
+    add = dx.p; ldadd = cin;
+  } else if (skip_conv) {
+    GemmParams sk;
+    sk.A = dout.p; sk.lda = dout.ld; sk.B = skwT; sk.ldb = cout; sk.C = dx.p; sk.ldc = cin;
+    sk.M = (int)npo; sk.N = cin; sk.K = cout;
+    CGD_TRY(cgd_launch_gemm(ctx, sk, s));
+    add = dx.p; ldadd = cin;
+  } else {
+    add = dout.p; ldadd = dout.ld;
+  }
+  CGD_TRY(cgd_launch_gn_bwd(ctx, x.p, x.ld, dh1, cin, dx.p, cin, add, ldadd, B, H * W, cin, 1, s1.p, s));
+  *din = TV{dx.p, cin, cin};
+  return 0;
+}
+
+int AttnBlock::fwd(UNet& u, TV xin, int Bn, int& H, int& W, TV* o, hipStream_t s) {
+  cgd_ctx* ctx = u.ctx;
+  B = Bn; T = H * W;
+  x = xin;
+  const long rows = (long)B * T;
+  const int Tp = attn_tp(T);
+  CGD_TRY(u.ensure(sc, cgd_gn_scratch_floats(B, T, C)));
+  CGD_TRY(u.ensure(n, rows * C));
+  CGD_TRY(u.ensure(qkv, rows * 3 * C));
+  CGD_TRY(u.ensure(a, rows * C));
+  CGD_TRY(u.ensure(out, rows * C));
+  CGD_TRY(u.ensure(qkvT, (size_t)B * 3 * C * Tp));
+  CGD_TRY(u.ensure(P, (size_t)B * heads * T * Tp));
+  CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, n.p, C, B, T, C, g, b, nullptr, 0, 0, 1e-5f, sc.p, s));
+  GemmParams q;
+  q.A = n.p; q.lda = C; q.B = qkvw; q.ldb = C; q.C = qkv.p; q.ldc = 3 * C; q.bias = qkvb; q.M = (int)rows; q.N = 3 * C; q.K = C;
+  CGD_TRY(cgd_launch_gemm(ctx, q, s));
+  AttnShape sh{B, heads, T, d, C, legacy};
+  AttnBufs bf{qkvT.p, P.p, nullptr, nullptr, nullptr};
+  CGD_TRY(cgd_attn_fwd(ctx, sh, qkv.p, 3 * C, a.p, C, bf, s));
+  GemmParams p;
+  p.A = a.p; p.lda = C; p.B = pw; p.ldb = C; p.C = out.p; p.ldc = C; p.bias = pb; p.R = x.p; p.ldr = x.ld; p.M = (int)rows; p.N = C;
+  p.K = C;
+  CGD_TRY(cgd_launch_gemm(ctx, p, s));
+  *o = TV{out.p, C, C};
+  return 0;
+}
+
+int AttnBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
+  cgd_ctx* ctx = u.ctx;
+  const long rows = (long)B * T;
+  const int Tp = attn_tp(T);
+  CGD_TRY(u.ensure(da, rows * C));
+  CGD_TRY(u.ensure(dqkv, rows * 3 * C));
+  CGD_TRY(u.ensure(dn, rows * C));
+  CGD_TRY(u.ensure(dx, rows * C));
+  CGD_TRY(u.ensure(Pt, (size_t)B * heads * T * Tp));
+  CGD_TRY(u.ensure(dP, (size_t)B * heads * T * Tp));
+  CGD_TRY(u.ensure(dAt, (size_t)B * C * Tp));
+  GemmParams p;
+  p.A = dout.p; p.lda = dout.ld; p.B = pwT; p.ldb = C; p.C = da.p; p.ldc = C; p.M = (int)rows; p.N = C; p.K = C;
+  CGD_TRY(cgd_launch_gemm(ctx, p, s));
+  AttnShape sh{B, heads, T, d, C, legacy};
+  AttnBufs bf{qkvT.p, P.p, Pt.p, dP.p, dAt.p};
+  CGD_TRY(cgd_attn_bwd(ctx, sh, qkv.p, 3 * C, da.p, C, dqkv.p, 3 * C, bf, s));
+  GemmParams q;
+  q.A = dqkv.p; q.lda = 3 * C; q.B = qkvwT; q.ldb = 3 * C; q.C = dn.p; q.ldc = C; q.M = (int)rows; q.N = C; q.K = 3 * C;
+  CGD_TRY(cgd_launch_gemm(ctx, q, s));
+  CGD_TRY(cgd_launch_gn_bwd(ctx, x.p, x.ld, dn.p, C, dx.p, C, dout.p, dout.ld, B, T, C, 0, sc.p, s));
+  *din = TV{dx.p, C, C};
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+int UNet::build() {
+  const int mc = cfg.model_channels;
+  ted = mc * 4;
+  add_param("time_embed.0.weight", (int64_t)ted * mc);
+  add_param("time_embed.0.bias", ted);
+  add_param("time_embed.2.weight", (int64_t)ted * ted);
+  add_param("time_embed.2.bias", ted);
+  if (cfg.num_classes > 0) add_param("label_emb.weight", (int64_t)cfg.num_classes * ted);
+
+  auto is_att = [&](int ds) {
+    for (int i = 0; i < cfg.n_att; ++i)
+      if (cfg.attention_ds[i] == ds) return true;
+    return false;
+  };
+  auto make_rb = [&](const std::string& pre, int cin, int cout, bool up, bool down) {
+    auto rb = std::make_unique<ResBlock>();
+    rb->pre = pre; rb->cin = cin; rb->cout = cout; rb->up = up; rb->down = down; rb->skip_conv = cin != cout;
+    add_param(pre + ".in_layers.0.weight", cin);
+    add_param(pre + ".in_layers.0.bias", cin);
+    add_param(pre + ".in_layers.2.weight", (int64_t)cout * cin * 9);
+    add_param(pre + ".in_layers.2.bias", cout);
+    add_param(pre + ".emb_layers.1.weight", (int64_t)2 * cout * ted);
+    add_param(pre + ".emb_layers.1.bias", 2 * cout);
+    add_param(pre + ".out_layers.0.weight", cout);
+    add_param(pre + ".out_layers.0.bias", cout);
+    add_param(pre + ".out_layers.3.weight", (int64_t)cout * cout * 9);
+    add_param(pre + ".out_layers.3.bias", cout);
+    if (rb->skip_conv) {
+      add_param(pre + ".skip_connection.weight", (int64_t)cout * cin);
+      add_param(pre + ".skip_connection.bias", cout);
+    }
+    rb->emb_off = emb_total;
+    emb_total += 2 * cout;
+    resblocks.push_back(rb.get());
+    return rb;
+  };
+  auto make_att = [&](const std::string& pre, int C) {
+    auto ab = std::make_unique<AttnBlock>();
+    ab->pre = pre; ab->C = C;
+    ab->heads = cfg.num_head_channels == -1 ? cfg.num_heads : C / cfg.num_head_channels;
+    ab->d = C / ab->heads;
+    ab->legacy = cfg.use_new_attention_order ? 0 : 1;
+    add_param(pre + ".norm.weight", C);
+    add_param(pre + ".norm.bias", C);
+    add_param(pre + ".qkv.weight", (int64_t)3 * C * C);
+    add_param(pre + ".qkv.bias", 3 * C);
+    add_param(pre + ".proj_out.weight", (int64_t)C * C);
+    add_param(pre + ".proj_out.bias", C);
+    return ab;
+  };
+
+  int ch = ch0 = (int)(cfg.channel_mult[0] * mc);
+  add_param("input_blocks.0.0.weight", (int64_t)ch * cfg.in_channels * 9);
+  add_param("input_blocks.0.0.bias", ch);
+  in_blocks.emplace_back();
+  in_chans.push_back(ch);
+  int ds = 1, idx = 1;
+  for (int level = 0; level < cfg.n_mult; ++level) {
+    const int co = (int)(cfg.channel_mult[level] * mc);
+    for (int r = 0; r < cfg.num_res_blocks; ++r) {
+      std::vector<std::unique_ptr<Module>> blk;
+      const std::string pre = "input_blocks." + std::to_string(idx);
+      blk.push_back(make_rb(pre + ".0", ch, co, false, false));
+      ch = co;
+      if (is_att(ds)) blk.push_back(make_att(pre + ".1", ch));
+      in_blocks.push_back(std::move(blk));
+      in_chans.push_back(ch);
+      ++idx;
+    }
+    if (level != cfg.n_mult - 1) {
+      std::vector<std::unique_ptr<Module>> blk;
+      blk.push_back(make_rb("input_blocks." + std::to_string(idx) + ".0", ch, ch, false, true));
+      in_blocks.push_back(std::move(blk));
+      in_chans.push_back(ch);
+      ++idx;
+      ds *= 2;
+    }
+  }
+  mid.push_back(make_rb("middle_block.0", ch, ch, false, false));
+  mid.push_back(make_att("middle_block.1", ch));
+  mid.push_back(make_rb("middle_block.2", ch, ch, false, false));
+  std::vector<int> chans = in_chans;
+  int oidx = 0;
+  for (int level = cfg.n_mult - 1; level >= 0; --level) {
+    const int co = (int)(cfg.channel_mult[level] * mc);
+    for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+      const int ich = chans.back();
+      chans.pop_back();
+      std::vector<std::unique_ptr<Module>> blk;
+      const std::string pre = "output_blocks." + std::to_string(oidx);
+      int sub = 0;
+      blk.push_back(make_rb(pre + "." + std::to_string(sub++), ch + ich, co, false, false));
+      ch = co;
+      if (is_att(ds)) blk.push_back(make_att(pre + "." + std::to_string(sub++), ch));
+      if (level && i == cfg.num_res_blocks) {
+        blk.push_back(make_rb(pre + "." + std::to_string(sub++), ch, ch, true, false));
+        ds /= 2;
+      }
+      out_blocks.push_back(std::move(blk));
+      ++oidx;
+    }
+  }
+  ch_last = ch;
+  add_param("out.0.weight", ch);
+  add_param("out.0.bias", ch);
+  add_param("out.2.weight", (int64_t)cfg.out_channels * ch0 * 9);
+  add_param("out.2.bias", cfg.out_channels);
+  if (ch_last != ch0) CGD_FAIL(ctx, "unet: channel bookkeeping mismatch");
+  cats.resize(out_blocks.size());
+  return 0;
+}
+
+int UNet::finalize(hipStream_t s) {
+  CGD_TRY(check_all_set());
+  auto tr = [&](const float* w, float** wt, int rows, int cols) -> int {  // [rows][cols] -> [cols][rows]
+    if (!*wt) CGD_TRY(alloc(wt, (size_t)rows * cols));
+    return cgd_launch_transpose(ctx, w, cols, 0, *wt, rows, 0, rows, cols, 1, s);
+  };
+  if (!emb_w_all) {
+    CGD_TRY(alloc(&emb_w_all, (size_t)emb_total * ted));
+    CGD_TRY(alloc(&emb_b_all, (size_t)emb_total));
+  }
+  for (ResBlock* rb : resblocks) {
+    const std::string& p = rb->pre;
+    rb->g1 = P(p + ".in_layers.0.weight"); rb->b1 = P(p + ".in_layers.0.bias");
+    rb->cb1 = P(p + ".in_layers.2.bias");
+    rb->g2 = P(p + ".out_layers.0.weight"); rb->b2 = P(p + ".out_layers.0.bias");
+    rb->cb2 = P(p + ".out_layers.3.bias");
+    if (!rb->cw1f) {
+      CGD_TRY(alloc(&rb->cw1f, (size_t)rb->cout * rb->cin * 9));
+      CGD_TRY(alloc(&rb->cw1d, (size_t)rb->cout * rb->cin * 9));
+      CGD_TRY(alloc(&rb->cw2f, (size_t)rb->cout * rb->cout * 9));
+      CGD_TRY(alloc(&rb->cw2d, (size_t)rb->cout * rb->cout * 9));
+    }
+    CGD_TRY(cgd_pack_conv3x3(ctx, P(p + ".in_layers.2.weight"), rb->cw1f, rb->cw1d, rb->cout, rb->cin, s));
+    CGD_TRY(cgd_pack_conv3x3(ctx, P(p + ".out_layers.3.weight"), rb->cw2f, rb->cw2d, rb->cout, rb->cout, s));
+    if (rb->skip_conv) {
+      rb->skw = P(p + ".skip_connection.weight");
+      rb->skb = P(p + ".skip_connection.bias");
+      CGD_TRY(tr(rb->skw, &rb->skwT, rb->cout, rb->cin));
+    }
+    CGD_HIP(ctx, hipMemcpyAsync(emb_w_all + rb->emb_off * ted, P(p + ".emb_layers.1.weight"), (size_t)2 * rb->cout * ted * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
+    CGD_HIP(ctx, hipMemcpyAsync(emb_b_all + rb->emb_off, P(p + ".emb_layers.1.bias"), (size_t)2 * rb->cout * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
+  }
+  auto fin_att = [&](Module* m) -> int {
+    AttnBlock* ab = dynamic_cast<AttnBlock*>(m);
+    if (!ab) return 0;
+    const std::string& p = ab->pre;
+    ab->g = P(p + ".norm.weight"); ab->b = P(p + ".norm.bias");
+    ab->qkvw = P(p + ".qkv.weight"); ab->qkvb = P(p + ".qkv.bias");
+    ab->pw = P(p + ".proj_out.weight"); ab->pb = P(p + ".proj_out.bias");
+    CGD_TRY(tr(ab->qkvw, &ab->qkvwT, 3 * ab->C, ab->C));
+    CGD_TRY(tr(ab->pw, &ab->pwT, ab->C, ab->C));
+    return 0;
+  };
+  for (auto& blk : in_blocks)
+    for (auto& m : blk) CGD_TRY(fin_att(m.get()));
+  for (auto& m : mid) CGD_TRY(fin_att(m.get()));
+  for (auto& blk : out_blocks)
+    for (auto& m : blk) CGD_TRY(fin_att(m.get()));
+  // stem (in_channels -> ch0) and head (ch0 -> out_channels)
+  if (!stem_wf) {
+    CGD_TRY(alloc(&stem_wf, (size_t)ch0 * cfg.in_channels * 9));
+    CGD_TRY(alloc(&stem_wd, (size_t)ch0 * cfg.in_channels * 9));
+    CGD_TRY(alloc(&head_wf, (size_t)ch0 * cfg.out_channels * 9));
+    CGD_TRY(alloc(&head_wd, (size_t)ch0 * cfg.out_channels * 9));
+  }
+  CGD_TRY(cgd_pack_conv3x3(ctx, P("input_blocks.0.0.weight"), stem_wf, stem_wd, ch0, cfg.in_channels, s));
+  CGD_TRY(cgd_pack_conv3x3(ctx, P("out.2.weight"), head_wf, head_wd, cfg.out_channels, ch0, s));
+  if (!freqs) {
+    const int half = cfg.model_channels / 2;
+    std::vector<float> f(half);
+    for (int i = 0; i < half; ++i) f[i] = (float)std::exp(-std::log(10000.0) * (double)i / (double)half);
+    CGD_TRY(alloc(&freqs, half));
+    CGD_HIP(ctx, hipMemcpy(freqs, f.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  }
+  CGD_HIP(ctx, hipStreamSynchronize(s));
+  finalized = true;
+  return 0;
+}
+
+int UNet::forward(const float* x, const float* t, const int64_t* y, float* out, int Bn, int Hh, int Ww, hipStream_t s) {
+  if (!finalized) CGD_FAIL(ctx, "unet: finalize() has not been called after the last set_param");
+  const int levels = cfg.n_mult - 1;
+  if ((Hh % (1 << levels)) || (Ww % (1 << levels))) CGD_FAIL(ctx, "unet: H and W must be divisible by 2^(levels-1)");
+  if (cfg.num_classes > 0 && !y) CGD_FAIL(ctx, "unet: class-conditional model needs y");
+  B = Bn; H = Hh; W = Ww;
+  have_fwd = false;
+  const int mc = cfg.model_channels;
+  // ---- embeddings (independent of x: no backward) ----
+  CGD_TRY(ensure(temb, (size_t)B * mc));
+  CGD_TRY(ensure(e1, (size_t)B * ted));
+  CGD_TRY(ensure(e1s, (size_t)B * ted));
+  CGD_TRY(ensure(e2, (size_t)B * ted));
+  CGD_TRY(ensure(e2s, (size_t)B * ted));
+  CGD_TRY(ensure(emb_all, (size_t)B * emb_total));
+  CGD_TRY(cgd_launch_timestep_embedding(ctx, t, freqs, temb.p, B, mc, s));
+  GemmParams g1;
+  g1.A = temb.p; g1.lda = mc; g1.B = P("time_embed.0.weight"); g1.ldb = mc; g1.C = e1.p; g1.ldc = ted; g1.bias = P("time_embed.0.bias");
+  g1.M = B; g1.N = ted; g1.K = mc;
+  CGD_TRY(cgd_launch_gemm(ctx, g1, s));
+  CGD_TRY(cgd_launch_act_fwd(ctx, e1.p, e1s.p, (long)B * ted, 1, s));
+  GemmParams g2;
+  g2.A = e1s.p; g2.lda = ted; g2.B = P("time_embed.2.weight"); g2.ldb = ted; g2.C = e2.p; g2.ldc = ted; g2.bias = P("time_embed.2.bias");
+  g2.M = B; g2.N = ted; g2.K = ted;
+  CGD_TRY(cgd_launch_gemm(ctx, g2, s));
+  if (cfg.num_classes > 0) CGD_TRY(cgd_launch_embedding_add(ctx, P("label_emb.weight"), y, e2.p, B, ted, s));
+  CGD_TRY(cgd_launch_act_fwd(ctx, e2.p, e2s.p, (long)B * ted, 1, s));
+  GemmParams g3;
+  g3.A = e2s.p; g3.lda = ted; g3.B = emb_w_all; g3.ldb = ted; g3.C = emb_all.p; g3.ldc = (int)emb_total; g3.bias = emb_b_all;
+  g3.M = B; g3.N = (int)emb_total; g3.K = ted;
+  CGD_TRY(cgd_launch_gemm(ctx, g3, s));
+  // ---- stem ----
+  CGD_TRY(ensure(h0, (size_t)B * H * W * ch0));
+  CGD_TRY(cgd_launch_conv_in(ctx, x, stem_wf, P("input_blocks.0.0.bias"), h0.p, B, H, W, cfg.in_channels, ch0, s));
+  hs.clear(); hs_hw.clear();
+  TV h{h0.p, ch0, ch0};
+  int ch = H, cw = W;
+  hs.push_back(h); hs_hw.push_back({ch, cw});
+  for (size_t i = 1; i < in_blocks.size(); ++i) {
+    for (auto& m : in_blocks[i]) CGD_TRY(m->fwd(*this, h, B, ch, cw, &h, s));
+    hs.push_back(h); hs_hw.push_back({ch, cw});
+  }
+  for (auto& m : mid) CGD_TRY(m->fwd(*this, h, B, ch, cw, &h, s));
+  cat_in.clear(); cat_c1.clear(); cat_hw.clear();
+  size_t top = hs.size();
+  for (size_t k = 0; k < out_blocks.size(); ++k) {
+    const TV sk = hs[--top];
+    const int ct = h.C + sk.C;
+    const long np = (long)B * ch * cw;
+    CGD_TRY(ensure(cats[k], (size_t)np * ct));
+    CGD_TRY(cgd_launch_copy2d(ctx, h.p, h.ld, nullptr, 0, cats[k].p, ct, np, h.C, s));
+    CGD_TRY(cgd_launch_copy2d(ctx, sk.p, sk.ld, nullptr, 0, cats[k].p + h.C, ct, np, sk.C, s));
+    cat_c1.push_back(h.C);
+    cat_hw.push_back({ch, cw});
+    h = TV{cats[k].p, ct, ct};
+    cat_in.push_back(h);
+    for (auto& m : out_blocks[k]) CGD_TRY(m->fwd(*this, h, B, ch, cw, &h, s));
+  }
+  // ---- head: GN -> SiLU -> conv3x3 (ch0 -> out_channels), NCHW out ----
+  head_in = h;
+  CGD_TRY(ensure(head_s, cgd_gn_scratch_floats(B, H * W, ch0)));
+  CGD_TRY(ensure(headn, (size_t)B * H * W * ch0));
+  CGD_TRY(cgd_launch_gn_fwd(ctx, h.p, h.ld, headn.p, ch0, B, H * W, ch0, P("out.0.weight"), P("out.0.bias"), nullptr, 0, 1, 1e-5f,
+                            head_s.p, s));
+  CGD_TRY(cgd_launch_conv_thin_out(ctx, headn.p, ch0, head_wf, P("out.2.bias"), out, B, H, W, ch0, cfg.out_channels, s));
+  have_fwd = true;
+  return 0;
+}
+
+int UNet::dgrad(const float* gout, float* gx, hipStream_t s) {
+  if (!have_fwd) CGD_FAIL(ctx, "unet: dgrad() needs a preceding forward()");
+  // head
+  CGD_TRY(ensure(dheadn, (size_t)B * H * W * ch0));
+  CGD_TRY(ensure(dhead, (size_t)B * H * W * ch0));
+  CGD_TRY(cgd_launch_conv_in(ctx, gout, head_wd, nullptr, dheadn.p, B, H, W, cfg.out_channels, ch0, s));
+  CGD_TRY(cgd_launch_gn_bwd(ctx, head_in.p, head_in.ld, dheadn.p, ch0, dhead.p, ch0, nullptr, 0, B, H * W, ch0, 1, head_s.p, s));
+  TV d{dhead.p, ch0, ch0};
+  // output blocks in reverse; remember the skip halves of the concat gradients
+  std::vector<TV> dskip(out_blocks.size());
+  for (int k = (int)out_blocks.size() - 1; k >= 0; --k) {
+    for (int j = (int)out_blocks[k].size() - 1; j >= 0; --j) CGD_TRY(out_blocks[k][j]->bwd(*this, d, &d, s));
+    const int c1 = cat_c1[k];
+    dskip[k] = TV{d.p + c1, d.ld, d.C - c1};
+    d = TV{d.p, d.ld, c1};
+  }
+  for (int j = (int)mid.size() - 1; j >= 0; --j) CGD_TRY(mid[j]->bwd(*this, d, &d, s));
+  // input blocks in reverse: hs[i] was consumed by output block k = n-1-i
+  const int n = (int)in_blocks.size();
+  for (int i = n - 1; i >= 0; --i) {
+    const TV& sk = dskip[n - 1 - i];
+    const long np = (long)B * hs_hw[i].first * hs_hw[i].second;
+    CGD_TRY(cgd_launch_copy2d(ctx, d.p, d.ld, sk.p, sk.ld, d.p, d.ld, np, d.C, s));  // d += skip-half (in place)
+    if (i == 0) break;
+    for (int j = (int)in_blocks[i].size() - 1; j >= 0; --j) CGD_TRY(in_blocks[i][j]->bwd(*this, d, &d, s));
+  }
+  // stem dgrad: NHWC (ch0) -> NCHW (in_channels)
+  CGD_TRY(cgd_launch_conv_thin_out(ctx, d.p, d.ld, stem_wd, nullptr, gx, B, H, W, ch0, cfg.in_channels, s));
+  return 0;
+}
+
+}  // namespace
+
+struct cgd_unet {
+  UNet net;
+};
+
+extern "C" {
+
+int cgd_unet_create(cgd_ctx* ctx, const cgd_unet_config* cfg, cgd_unet** out) {
+  if (!ctx || !cfg || !out) return -3;
+  if (cfg->in_channels != 3 || (cfg->out_channels != 6 && cfg->out_channels != 3)) CGD_FAIL(ctx, "unet: in_channels must be 3, out_channels 3 or 6");
+  if (cfg->n_mult < 1 || cfg->n_mult > 8) CGD_FAIL(ctx, "unet: bad channel_mult");
+  cgd_unet* u = new cgd_unet();
+  u->net.ctx = ctx;
+  u->net.cfg = *cfg;
+  if (u->net.build() != 0) {
+    delete u;
+    return -2;
+  }
+  *out = u;
+  return 0;
+}
+void cgd_unet_destroy(cgd_unet* u) { delete u; }
+int cgd_unet_num_params(cgd_unet* u) { return (int)u->net.params.size(); }
+int cgd_unet_param_info(cgd_unet* u, int i, char* buf, int len, int64_t* numel) {
+  if (i < 0 || i >= (int)u->net.params.size()) return -1;
+  snprintf(buf, len, "%s", u->net.params[i].name.c_str());
+  if (numel) *numel = u->net.params[i].numel;
+  return 0;
+}
+int cgd_unet_set_param(cgd_unet* u, const char* name, const float* data, int64_t numel) { return u->net.set_param(name, data, numel); }
+int cgd_unet_finalize(cgd_unet* u) { return u->net.finalize(nullptr); }
+int cgd_unet_forward(cgd_unet* u, const float* x, const float* t, const int64_t* y, float* out, int B, int H, int W, void* stream) {
+  return u->net.forward(x, t, y, out, B, H, W, (hipStream_t)stream);
+}
+int cgd_unet_dgrad(cgd_unet* u, const float* g_out, float* g_x, void* stream) { return u->net.dgrad(g_out, g_x, (hipStream_t)stream); }
+}

@@ -1,0 +1,159 @@
+"""Handles of the two device networks behind the C ABI.
+
+`UNet` mirrors the callable the reference hands to the sampler, `model(x, timesteps, y)`
+(/root/reference/cgd/cgd.py:251, built by /root/reference/cgd/script_util.py:281-324); `ClipImageTower`
+mirrors `clip_model.encode_image` + `.visual.input_resolution` (/root/reference/cgd/clip_util.py:59-66,
+/root/reference/cgd/cgd.py:194).  Both add `dgrad`, the hand-derived backward-to-input that replaces
+`th.autograd.grad(loss, x)` (cgd.py:228).
+"""
+import ctypes as C
+
+import torch as th
+
+from . import lib as L
+
+DEFAULT_CHANNEL_MULT = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
+
+VIT_CONFIGS = {
+    # name: (resolution, patch, width, layers, heads, out_dim)   (clip/model.py)
+    "ViT-B/32": (224, 32, 768, 12, 12, 512),
+    "ViT-B/16": (224, 16, 768, 12, 12, 512),
+    "ViT-L/14": (224, 14, 1024, 24, 16, 768),
+}
+
+
+class _Net:
+    _prefix = None
+
+    def _fn(self, name):
+        return getattr(self.ctx.lib, f"cgd_{self._prefix}_{name}")
+
+    def param_specs(self):
+        n = self._fn("num_params")(self.h)
+        buf = C.create_string_buffer(256)
+        numel = C.c_int64()
+        out = []
+        for i in range(n):
+            self.ctx.check(self._fn("param_info")(self.h, i, buf, 256, C.byref(numel)))
+            out.append((buf.value.decode(), numel.value))
+        return out
+
+    def load_state_dict(self, sd, prefix=""):
+        """Upload every parameter (fp32) and pack the forward / dgrad weight layouts."""
+        for name, numel in self.param_specs():
+            key = prefix + name
+            if key not in sd:
+                raise KeyError(f"missing parameter {key}")
+            t = sd[key].detach().to(dtype=th.float32).contiguous()
+            if t.numel() != numel:
+                raise ValueError(f"{key}: expected {numel} elements, got {t.numel()}")
+            self.ctx.check(self._fn("set_param")(self.h, name.encode(), t.data_ptr(), numel))
+        self.ctx.check(self._fn("finalize")(self.h))
+        return self
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._fn("destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class UNet(_Net):
+    _prefix = "unet"
+
+    def __init__(self, ctx, image_size, model_channels, num_res_blocks, attention_resolutions="32,16,8", channel_mult=None,
+                 num_classes=None, num_heads=4, num_head_channels=-1, use_new_attention_order=False, in_channels=3,
+                 out_channels=6):
+        self.ctx = ctx
+        if channel_mult is None:
+            channel_mult = DEFAULT_CHANNEL_MULT[image_size]
+        att = [image_size // int(r) for r in str(attention_resolutions).split(",")]
+        cfg = L.UNetConfig()
+        cfg.image_size, cfg.model_channels, cfg.num_res_blocks = image_size, model_channels, num_res_blocks
+        cfg.n_mult = len(channel_mult)
+        for i, m in enumerate(channel_mult):
+            cfg.channel_mult[i] = float(m)
+        cfg.n_att = len(att)
+        for i, a in enumerate(att):
+            cfg.attention_ds[i] = a
+        cfg.num_classes = int(num_classes or 0)
+        cfg.num_heads, cfg.num_head_channels = num_heads, num_head_channels
+        cfg.use_new_attention_order = int(bool(use_new_attention_order))
+        cfg.in_channels, cfg.out_channels = in_channels, out_channels
+        self.cfg = cfg
+        self.num_classes = num_classes
+        self.out_channels = out_channels
+        h = C.c_void_p()
+        ctx.check(ctx.lib.cgd_unet_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def forward(self, x, timesteps, y=None, out=None):
+        """x (B,3,H,W) fp32 NCHW on the GPU; timesteps (B,) (any dtype; converted to fp32); y (B,) int64."""
+        B, _, H, W = x.shape
+        x = x.contiguous().float()
+        t = timesteps.to(device=x.device, dtype=th.float32).contiguous()
+        if y is not None:
+            y = y.to(device=x.device, dtype=th.int64).contiguous()
+        if out is None:
+            out = th.empty((B, self.out_channels, H, W), device=x.device, dtype=th.float32)
+        self.ctx.check(self.ctx.lib.cgd_unet_forward(self.h, x.data_ptr(), t.data_ptr(), L.ptr(y), out.data_ptr(), B, H, W,
+                                                     L.stream_ptr()))
+        self._keep = (x, t, y)  # inputs must outlive the enqueued work
+        return out
+
+    __call__ = forward
+
+    def dgrad(self, g_out, g_x=None):
+        """d(sum(out*g_out))/dx for the last forward."""
+        g_out = g_out.contiguous().float()
+        B, _, H, W = g_out.shape
+        if g_x is None:
+            g_x = th.empty((B, 3, H, W), device=g_out.device, dtype=th.float32)
+        self.ctx.check(self.ctx.lib.cgd_unet_dgrad(self.h, g_out.data_ptr(), g_x.data_ptr(), L.stream_ptr()))
+        self._keep_g = g_out
+        return g_x
+
+
+class ClipImageTower(_Net):
+    _prefix = "vit"
+
+    def __init__(self, ctx, name="ViT-B/32", config=None):
+        self.ctx = ctx
+        res, patch, width, layers, heads, out = config or VIT_CONFIGS[name]
+        cfg = L.ViTConfig(res, patch, width, layers, heads, out)
+        self.cfg = cfg
+        self.input_resolution = res
+        self.patch, self.out_dim = patch, out
+        h = C.c_void_p()
+        ctx.check(ctx.lib.cgd_vit_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._layout = 0
+        self._n = 0
+
+    def load_clip_state_dict(self, sd):
+        """Accepts an OpenAI CLIP state dict (keys `visual.*`) or a bare visual-tower dict."""
+        prefix = "visual." if any(k.startswith("visual.") for k in sd) else ""
+        return self.load_state_dict(sd, prefix)
+
+    def encode_image(self, img, layout=0, n=None, out=None):
+        """layout 0: (N,3,res,res) NCHW already CLIP-normalised; layout 1: patch rows from cutouts_fwd."""
+        img = img.contiguous().float()
+        N = img.shape[0] if layout == 0 else int(n)
+        if out is None:
+            out = th.empty((N, self.out_dim), device=img.device, dtype=th.float32)
+        self.ctx.check(self.ctx.lib.cgd_vit_forward(self.h, img.data_ptr(), layout, N, out.data_ptr(), L.stream_ptr()))
+        self._layout, self._n, self._keep = layout, N, img
+        return out
+
+    def dgrad(self, d_emb, d_img=None):
+        d_emb = d_emb.contiguous().float()
+        if d_img is None:
+            d_img = th.empty_like(self._keep)
+        self.ctx.check(self.ctx.lib.cgd_vit_dgrad(self.h, d_emb.data_ptr(), d_img.data_ptr(), L.stream_ptr()))
+        self._keep_g = d_emb
+        return d_img

@@ -1,0 +1,168 @@
+/* libcgd_mi355x — C ABI of the MI355X-native CLIP-guided diffusion sampling step.
+ *
+ * The reference (afiaka87/clip-guided-diffusion) is pure Python and has NO native boundary; the per-timestep
+ * hot path is reached through two Python callables handed to the sampler:
+ *     model(x, timesteps, y)            /root/reference/cgd/cgd.py:251  (guided_diffusion UNetModel)
+ *     cond_fn(x, t, out, y=None)        /root/reference/cgd/cgd.py:151-239, :255
+ * and the sampler update of guided_diffusion's p_sample_with_grad / ddim_sample_with_grad selected at
+ * /root/reference/cgd/cgd.py:242-245.  This header is the boundary a maintainer binds with ctypes
+ * (INTEGRATION.md shows the stub); each entry point cites the reference code it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer to fp32 unless stated; the caller (PyTorch-ROCm) owns all
+ * I/O buffers; the library owns packed weights, saved activations and workspaces inside its handles; all work
+ * is enqueued on the caller's stream (`stream` = hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
+ * no hidden synchronisation; functions return 0 on success, non-zero on error and never throw —
+ * cgd_last_error() returns the message.  Handles are single-threaded, one per GPU.
+ */
+#ifndef CGD_MI355X_H
+#define CGD_MI355X_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cgd_ctx cgd_ctx;
+typedef struct cgd_unet cgd_unet;
+typedef struct cgd_vit cgd_vit;
+
+/* MFMA contraction precision (fp32 storage everywhere): 0 = fp32-input MFMA (exact), 1 = bf16x3 split
+ * (~fp32 accuracy, default), 2 = single bf16 product (the reference's CUDA path runs the nets in fp16). */
+enum { CGD_F32 = 0, CGD_BF16X3 = 1, CGD_BF16 = 2 };
+
+int cgd_ctx_create(cgd_ctx** out, int device);
+void cgd_ctx_destroy(cgd_ctx* ctx);
+const char* cgd_last_error(cgd_ctx* ctx);
+int cgd_set_precision(cgd_ctx* ctx, int mode);
+int cgd_get_precision(cgd_ctx* ctx);
+const char* cgd_version(void);
+
+/* ---- UNet epsilon/sigma predictor: replaces guided_diffusion.unet.UNetModel built at
+ *      /root/reference/cgd/script_util.py:316 from /root/reference/data/diffusion_model_flags.py ---- */
+typedef struct cgd_unet_config {
+  int image_size;
+  int model_channels;
+  int num_res_blocks;
+  int n_mult;
+  float channel_mult[8];
+  int n_att;
+  int attention_ds[8];     /* downsample rates that carry attention (image_size // attention_resolution) */
+  int num_classes;         /* 0 = unconditional */
+  int num_heads;
+  int num_head_channels;   /* -1: use num_heads */
+  int use_new_attention_order;
+  int in_channels;         /* 3 */
+  int out_channels;        /* 6 (learn_sigma) */
+} cgd_unet_config;
+
+int cgd_unet_create(cgd_ctx* ctx, const cgd_unet_config* cfg, cgd_unet** out);
+void cgd_unet_destroy(cgd_unet* u);
+/* parameter ingestion, names = upstream state-dict keys (model.load_state_dict at script_util.py:317);
+ * `data` may be a host or device pointer */
+int cgd_unet_num_params(cgd_unet* u);
+int cgd_unet_param_info(cgd_unet* u, int index, char* name_buf, int buf_len, int64_t* numel);
+int cgd_unet_set_param(cgd_unet* u, const char* name, const float* data, int64_t numel);
+int cgd_unet_finalize(cgd_unet* u); /* pack fwd + dgrad (rotated/transposed) weight layouts */
+/* model(x, timesteps, y): x (B,3,H,W) NCHW, timesteps (B) fp32 (already mapped/rescaled), y (B) int64 or NULL
+ * -> out (B,6,H,W) NCHW.  Keeps the activations the backward pass needs. */
+int cgd_unet_forward(cgd_unet* u, const float* x, const float* timesteps, const int64_t* y, float* out, int B, int H, int W,
+                     void* stream);
+/* d(sum(out * g_out))/dx of the LAST forward: replaces the UNet leg of th.autograd.grad(loss, x), cgd.py:228 */
+int cgd_unet_dgrad(cgd_unet* u, const float* g_out, float* g_x, void* stream);
+
+/* ---- CLIP image tower (VisionTransformer): replaces clip_model.encode_image, cgd/cgd.py:194 ---- */
+typedef struct cgd_vit_config {
+  int resolution, patch, width, layers, heads, out_dim;
+} cgd_vit_config;
+int cgd_vit_create(cgd_ctx* ctx, const cgd_vit_config* cfg, cgd_vit** out);
+void cgd_vit_destroy(cgd_vit* v);
+int cgd_vit_num_params(cgd_vit* v);
+int cgd_vit_param_info(cgd_vit* v, int index, char* name_buf, int buf_len, int64_t* numel);
+int cgd_vit_set_param(cgd_vit* v, const char* name, const float* data, int64_t numel);
+int cgd_vit_finalize(cgd_vit* v);
+/* layout 0: img (N,3,res,res) NCHW; layout 1: patch rows [N*g*g][3*patch*patch] (what cgd_cutouts_fwd layout 1 writes) */
+int cgd_vit_forward(cgd_vit* v, const float* img, int layout, int N, float* emb /* (N,out_dim) */, void* stream);
+int cgd_vit_dgrad(cgd_vit* v, const float* d_emb, float* d_img /* same layout as the forward input */, void* stream);
+
+/* ---- cutouts: replaces MakeCutouts.forward (cgd/modules.py:50-66) + x.add(1).div(2) (cgd.py:190) + CLIP_NORMALIZE
+ *      (clip_util.py:45).  coords: device int32 [cutn][4] = (oy, ox, h, w) of each (possibly truncated) crop. ---- */
+int cgd_cutouts_fwd(cgd_ctx* ctx, const float* x_in, const int32_t* coords, float* out, int B, int H, int W, int cutn, int cut_size,
+                    int layout, int patch, void* stream);
+int cgd_cutouts_bwd(cgd_ctx* ctx, const float* d_out, const int32_t* coords, float* g_in, int B, int H, int W, int cutn,
+                    int cut_size, int layout, int patch, int accumulate, void* stream);
+
+/* ---- losses.spherical_dist_loss (cgd/losses.py:10-14) weighted as at cgd.py:196-204, with its gradient.
+ *      emb (cutn*B, D) row = cut*B+b; targets_n (P, D) L2-normalised; weights (B, P) dense per-sample prompt
+ *      weights; d_emb (cutn*B, D); loss_part (cutn*B) partial losses (sum = 'CLIP Loss'). ---- */
+int cgd_spherical_loss(cgd_ctx* ctx, const float* emb, const float* targets_n, const float* weights, float* d_emb, float* loss_part,
+                       int cutn, int B, int P, int D, float clip_guidance_scale, void* stream);
+
+/* per-timestep scalars of the (respaced) diffusion process, float64 tables evaluated on the host */
+typedef struct cgd_step_coef {
+  float sqrt_recip;             /* sqrt(1/abar_t)                                  */
+  float sqrt_recipm1;           /* sqrt(1/abar_t - 1)                              */
+  float coef1, coef2;           /* posterior_mean_coef1/2                          */
+  float min_log, max_log;       /* posterior_log_variance_clipped[t], log(beta_t)  */
+  float fac;                    /* sqrt(1-abar)[current_timestep] (cgd.py:177)     */
+  float sqrt_one_minus_ab;      /* sqrt(1-abar_t)            (DDIM)                */
+  float sqrt_ab_prev;           /* sqrt(abar_{t-1})          (DDIM)                */
+  float sqrt_one_minus_ab_prev; /* sqrt(1-abar_{t-1})        (DDIM, eta=0)         */
+  int nonzero;                  /* t != 0                                          */
+} cgd_step_coef;
+
+/* p_mean_variance tail (epsilon-pred, LEARNED_RANGE, clip_denoised=False) + blend x_in (cgd.py:177-179) */
+int cgd_pmv_blend(cgd_ctx* ctx, const float* x, const float* model_out6, float* pred_xstart, float* mean, float* log_variance,
+                  float* x_in, int B, int H, int W, const cgd_step_coef* k, void* stream);
+/* number of per-block partial entries the two kernels below write */
+int cgd_guidance_part_blocks(int B, int H, int W);
+/* tv_loss / range_loss / saturation gradients (losses.py:5-7,17-22; cgd.py:201-218) chained through the blend and
+ * x0 = a*x - b*eps:  g_direct (B,3,H,W) = dL/dx not through the UNet; seed6 (B,6,H,W) = dL/d(model_out);
+ * loss_part [blocks][3] = partial (tv, range, sat) losses.  g_clip_in = dL_clip/dx_in from cgd_cutouts_bwd or NULL. */
+int cgd_guidance_combine(cgd_ctx* ctx, const float* g_clip_in, const float* x_in, const float* pred_xstart, float* g_direct,
+                         float* seed6, float* loss_part, int B, int H, int W, const cgd_step_coef* k, float tv_scale,
+                         float range_scale, float sat_scale, void* stream);
+/* g = -(g_direct + g_unet) (cgd.py:228); g_part [blocks][2] = partial (sum g, sum g^2) */
+int cgd_grad_finish(cgd_ctx* ctx, const float* g_direct, const float* g_unet, float* g, float* g_part, int B, int H, int W,
+                    void* stream);
+/* scalars[8] = {CLIP, TV, Range, Sat, Total loss, Magnitude, Grad mean, magnitude clamp factor} (log keys of cgd.py:208-233) */
+int cgd_scalars(cgd_ctx* ctx, const float* clip_part, int n_clip, const float* loss_part, const float* g_part, int B, int H, int W,
+                int use_magnitude, float* scalars, void* stream);
+/* mode 0: p_sample_with_grad + condition_mean_with_grad; mode 1: ddim_sample_with_grad + condition_score_with_grad (eta 0).
+ * g may be NULL (no guidance); scalars (from cgd_scalars) carries the magnitude clamp factor, or NULL. */
+int cgd_sample_update(cgd_ctx* ctx, const float* x, const float* pred_xstart, const float* mean, const float* log_variance,
+                      const float* g, const float* noise, const float* scalars, float* sample, float* pred_xstart_out, int B, int H,
+                      int W, const cgd_step_coef* k, int mode, void* stream);
+
+/* ---- single ops, exported for parity tests and for user-supplied cond_fn plumbing ---- */
+/* C[M][N] = alpha * A[M][K] B[N][K]^T (+bias[N]) (+R[M][N]); conv3x3: A is NHWC (Bn,H,W,Cin), B = [N][9*Cin] */
+int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, const float* R,
+                int ldr, int M, int N, int K, float alpha, int force_tile, int splitk, void* stream);
+int cgd_op_conv3x3(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_packed, float* y_nhwc, int ldy, const float* bias,
+                   const float* R, int ldr, int Bn, int H, int W, int Cin, int Cout, int upsample_input, int force_tile, int splitk,
+                   void* stream);
+int cgd_op_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w, const float* bias, float* y_nhwc, int Bn, int H, int W, int Cin,
+                   int Cout, void* stream);
+int cgd_op_conv_thin_out(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w, const float* bias, float* y_nchw, int Bn, int H,
+                         int W, int Cin, int Cout, void* stream);
+int64_t cgd_op_gn_scratch_floats(int B, int HW, int C);
+int cgd_op_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma,
+                  const float* beta, const float* film, int act, float eps, float* scratch, void* stream);
+int cgd_op_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add, int ldadd,
+                  int B, int HW, int C, int act, float* scratch, void* stream);
+int cgd_op_ln_fwd(cgd_ctx* ctx, const float* x, float* y, int rows, int C, const float* gamma, const float* beta, float eps,
+                  float* stats, void* stream);
+int cgd_op_ln_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx, int rows, int C, const float* gamma, const float* stats,
+                  void* stream);
+int cgd_op_pool2x2(cgd_ctx* ctx, const float* in, float* out, int B, int Ho, int Wo, int C, float scale, void* stream);
+int cgd_op_upsample2x(cgd_ctx* ctx, const float* in, float* out, int B, int Ho, int Wo, int C, float scale, void* stream);
+int cgd_op_act(cgd_ctx* ctx, const float* x, const float* dy, float* out, int64_t n, int act, void* stream);
+int64_t cgd_op_attn_buf_floats(int nb, int heads, int T, int d, int which);
+int cgd_op_attn_fwd(cgd_ctx* ctx, const float* qkv, float* out, int nb, int heads, int T, int d, int legacy, float* bufs[5],
+                    void* stream);
+int cgd_op_attn_bwd(cgd_ctx* ctx, const float* qkv, const float* dout, float* dqkv, int nb, int heads, int T, int d, int legacy,
+                    float* bufs[5], void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,334 @@
+"""Parity checks of the HIP path (through the C ABI) against the CPU oracle / plain PyTorch fp32(64).
+
+Each check returns a list of records {name, err_abs, err_rel, ref_max, ok}.  Used by tests/test_gpu_*.py
+(pytest -m gpu) and by tests/gpu_diag.py (one-shot report written to gpurun_out/).
+Tolerance: north_star's rtol 1e-3 / atol 1e-4 (fp32), applied as |a-b| <= atol*max(1,|ref|max) + rtol*|b|.
+"""
+import math
+import os
+import sys
+
+import torch as th
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+RTOL, ATOL = 1e-3, 1e-4
+DEV = "cuda"
+
+
+def rec(name, got, ref, rtol=RTOL, atol=ATOL):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    refmax = ref.abs().max().item() if ref.numel() else 0.0
+    diff = (got - ref).abs()
+    err = diff.max().item() if ref.numel() else 0.0
+    tol = atol * max(1.0, refmax) + rtol * ref.abs()
+    ok = bool((diff <= tol).all().item()) and bool(th.isfinite(got).all().item())
+    return {"name": name, "err_abs": err, "err_rel": err / (refmax + 1e-30), "ref_max": refmax, "ok": ok}
+
+
+def _ctx(precision):
+    import cgd_amd  # noqa: F401
+    from cgd_amd import lib
+    return lib.Context(0, precision)
+
+
+def g(seed=0):
+    return th.Generator().manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def check_gemm(precision):
+    from cgd_amd import ops
+    ctx = _ctx(precision)
+    out = []
+    cases = [(300, 200, 128, 0, 1), (1, 1024, 256, 0, 1), (64, 1024, 4608, 0, 1), (800, 2304, 768, 0, 1), (130, 70, 52, 64, 1),
+             (256, 256, 512, 128, 1), (256, 192, 1024, 64, 4), (4096, 256, 288, 0, 1)]
+    for (M, N, K, tile, sk) in cases:
+        A = th.randn(M, K, generator=g(1))
+        B = th.randn(N, K, generator=g(2))
+        bias = th.randn(N, generator=g(3))
+        R = th.randn(M, N, generator=g(4))
+        ref = 0.5 * (A.double() @ B.double().T) + bias.double() + R.double()
+        got = ops.gemm(ctx, A.to(DEV), B.to(DEV), bias.to(DEV), R.to(DEV), alpha=0.5, force_tile=tile, splitk=sk)
+        out.append(rec(f"gemm[p{precision}] {M}x{N}x{K} tile{tile} sk{sk}", got, ref.float(), atol=ATOL * math.sqrt(K)))
+    return out
+
+
+def check_conv(precision):
+    from cgd_amd import ops
+    ctx = _ctx(precision)
+    out = []
+    for (Bn, H, W, Ci, Co, ups, tile) in [(2, 12, 20, 64, 96, 0, 0), (1, 32, 32, 128, 256, 0, 128), (1, 16, 16, 64, 64, 1, 0),
+                                          (1, 8, 8, 256, 128, 0, 64)]:
+        Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+        x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
+        w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)
+        b = th.randn(Co, generator=g(7))
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+        ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).float()
+        wf, wd = ops.pack_conv3x3(w)
+        got = ops.conv3x3(ctx, x.permute(0, 2, 3, 1).contiguous().to(DEV), wf.to(DEV), b.to(DEV), upsample_input=bool(ups), force_tile=tile)
+        out.append(rec(f"conv3x3[p{precision}] B{Bn} {H}x{W} {Ci}->{Co} ups{ups}", got.permute(0, 3, 1, 2), ref))
+        if not ups:
+            # dgrad = same kernel on the rotated/transposed packing
+            dy = th.randn(Bn, Co, H, W, generator=g(8))
+            xr = x.double().requires_grad_()
+            (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
+            got = ops.conv3x3(ctx, dy.permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None)
+            out.append(rec(f"conv3x3 dgrad[p{precision}] {Ci}<-{Co}", got.permute(0, 3, 1, 2), xr.grad.float()))
+    # thin ends
+    x = th.randn(2, 3, 16, 24, generator=g(9))
+    w = th.randn(64, 3, 3, 3, generator=g(10)) / math.sqrt(27)
+    b = th.randn(64, generator=g(11))
+    wf, wd = ops.pack_conv3x3(w)
+    got = ops.conv_in(ctx, x.to(DEV), wf.to(DEV), b.to(DEV), 64)
+    out.append(rec("conv_in 3->64", got.permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1)))
+    dy = th.randn(2, 64, 16, 24, generator=g(12))
+    xr = x.clone().requires_grad_()
+    (F.conv2d(xr, w, None, padding=1) * dy).sum().backward()
+    got = ops.conv_thin_out(ctx, dy.permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None, 3)
+    out.append(rec("conv_thin_out dgrad 64->3", got, xr.grad))
+    w6 = th.randn(6, 64, 3, 3, generator=g(13)) / math.sqrt(9 * 64)
+    b6 = th.randn(6, generator=g(14))
+    wf6, wd6 = ops.pack_conv3x3(w6)
+    h = th.randn(2, 64, 16, 24, generator=g(15))
+    got = ops.conv_thin_out(ctx, h.permute(0, 2, 3, 1).contiguous().to(DEV), wf6.to(DEV), b6.to(DEV), 6)
+    out.append(rec("conv_thin_out 64->6", got, F.conv2d(h, w6, b6, padding=1)))
+    d6 = th.randn(2, 6, 16, 24, generator=g(16))
+    hr = h.clone().requires_grad_()
+    (F.conv2d(hr, w6, None, padding=1) * d6).sum().backward()
+    got = ops.conv_in(ctx, d6.to(DEV), wd6.to(DEV), None, 64)
+    out.append(rec("conv_in dgrad 6->64", got.permute(0, 3, 1, 2), hr.grad))
+    return out
+
+
+def check_norm():
+    from cgd_amd import ops
+    ctx = _ctx(1)
+    out = []
+    for (B, HW, Cc, film, act) in [(2, 96, 64, False, 1), (1, 1024, 192, True, 1), (2, 64, 1344, True, 1), (1, 4096, 256, False, 0),
+                                   (3, 16, 2048, True, 1), (1, 300, 96, False, 1)]:
+        x = th.randn(B, HW, Cc, generator=g(20)) * 2 + 0.7
+        gamma = 1 + 0.1 * th.randn(Cc, generator=g(21))
+        beta = 0.1 * th.randn(Cc, generator=g(22))
+        fl = 0.3 * th.randn(B, 2 * Cc, generator=g(23)) if film else None
+        dz = th.randn(B, HW, Cc, generator=g(24))
+        xr = x.double().requires_grad_()
+        y = F.group_norm(xr.permute(0, 2, 1), 32, gamma.double(), beta.double(), 1e-5)  # (B,C,HW)
+        if film:
+            sc, sh = fl.double()[:, :Cc, None], fl.double()[:, Cc:, None]
+            y = y * (1 + sc) + sh
+        if act:
+            y = F.silu(y)
+        y = y.permute(0, 2, 1)
+        (y * dz.double()).sum().backward()
+        yd, scr = ops.groupnorm_fwd(ctx, x.to(DEV), gamma.to(DEV), beta.to(DEV), None if fl is None else fl.to(DEV), act=act)
+        out.append(rec(f"groupnorm fwd B{B} HW{HW} C{Cc} film{int(film)} act{act}", yd, y.float()))
+        dx = ops.groupnorm_bwd(ctx, x.to(DEV), dz.to(DEV), scr, act=act)
+        out.append(rec(f"groupnorm bwd B{B} HW{HW} C{Cc} film{int(film)} act{act}", dx, xr.grad.float()))
+    for (rows, Cc) in [(50, 768), (7, 1024), (800, 768)]:
+        x = th.randn(rows, Cc, generator=g(25)) * 1.5 + 0.3
+        gamma = 1 + 0.1 * th.randn(Cc, generator=g(26))
+        beta = 0.1 * th.randn(Cc, generator=g(27))
+        dy = th.randn(rows, Cc, generator=g(28))
+        xr = x.double().requires_grad_()
+        y = F.layer_norm(xr, (Cc,), gamma.double(), beta.double(), 1e-5)
+        (y * dy.double()).sum().backward()
+        yd, st = ops.layernorm_fwd(ctx, x.to(DEV), gamma.to(DEV), beta.to(DEV))
+        out.append(rec(f"layernorm fwd {rows}x{Cc}", yd, y.float()))
+        out.append(rec(f"layernorm bwd {rows}x{Cc}", ops.layernorm_bwd(ctx, x.to(DEV), dy.to(DEV), gamma.to(DEV), st), xr.grad.float()))
+    return out
+
+
+def check_elem():
+    from cgd_amd import ops
+    ctx = _ctx(1)
+    out = []
+    x = th.randn(2, 8, 12, 64, generator=g(30))
+    out.append(rec("pool2x2", ops.pool2x2(ctx, x.to(DEV)), F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)))
+    out.append(rec("upsample2x", ops.upsample2x(ctx, x.to(DEV)),
+                   F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)))
+    v = th.randn(1000, generator=g(31)) * 3
+    dy = th.randn(1000, generator=g(32))
+    for kind, fn in [(1, F.silu), (2, lambda t: t * th.sigmoid(1.702 * t))]:
+        vr = v.double().requires_grad_()
+        yy = fn(vr)
+        (yy * dy.double()).sum().backward()
+        out.append(rec(f"act{kind} fwd", ops.act(ctx, v.to(DEV), kind), yy.float()))
+        out.append(rec(f"act{kind} bwd", ops.act(ctx, v.to(DEV), kind, dy.to(DEV)), vr.grad.float()))
+    return out
+
+
+def _attn_ref(qkv, nb, heads, T, d, legacy):
+    Cc = heads * d
+    x = qkv.reshape(nb, T, 3 * Cc).permute(0, 2, 1)  # (nb, 3C, T) channel-major like the reference
+    if legacy:
+        q, k, v = x.reshape(nb * heads, 3 * d, T).split(d, dim=1)
+    else:
+        q, k, v = x.chunk(3, dim=1)
+        q, k, v = (z.reshape(nb * heads, d, T) for z in (q, k, v))
+    s = 1 / math.sqrt(math.sqrt(d))
+    w = th.softmax(th.einsum("bct,bcs->bts", q * s, k * s), dim=-1)
+    a = th.einsum("bts,bcs->bct", w, v).reshape(nb, Cc, T)
+    return a.permute(0, 2, 1).reshape(nb * T, Cc)
+
+
+def check_attn(precision):
+    from cgd_amd import ops
+    ctx = _ctx(precision)
+    out = []
+    for (nb, heads, T, d, legacy) in [(2, 2, 64, 64, 1), (1, 4, 256, 64, 1), (3, 12, 50, 64, 0), (1, 3, 100, 64, 0), (1, 4, 64, 128, 1)]:
+        Cc = heads * d
+        qkv = th.randn(nb * T, 3 * Cc, generator=g(40))
+        dout = th.randn(nb * T, Cc, generator=g(41))
+        qr = qkv.double().requires_grad_()
+        ref = _attn_ref(qr, nb, heads, T, d, legacy)
+        (ref * dout.double()).sum().backward()
+        at = ops.Attention(ctx, nb, heads, T, d, legacy, DEV)
+        got = at.forward(qkv.to(DEV))
+        out.append(rec(f"attn fwd[p{precision}] nb{nb} h{heads} T{T} d{d} legacy{legacy}", got, ref.float()))
+        dq = at.backward(qkv.to(DEV), dout.to(DEV))
+        out.append(rec(f"attn bwd[p{precision}] nb{nb} h{heads} T{T} d{d} legacy{legacy}", dq, qr.grad.float()))
+    return out
+
+
+def check_cutouts_loss():
+    import ctypes as C
+    from cgd_amd import lib as L
+    from oracle import guidance as og
+    ctx = _ctx(1)
+    out = []
+    for (B, H, W, cutn, cs, patch, coords) in [
+        (1, 64, 64, 3, 224, 32, [(0, 0, 64), (0, 0, 64), (0, 0, 64)]),
+        (2, 256, 256, 4, 224, 32, [(3, 7, 224), (0, 0, 256), (20, 30, 233), (32, 0, 224)]),
+        (1, 256, 288, 3, 224, 32, [(10, 5, 250), (60, 0, 228), (0, 31, 256)]),  # truncated crops (H/W naming quirk)
+        (1, 96, 96, 2, 64, 16, [(5, 9, 80), (0, 0, 96)]),
+    ]:
+        x = th.rand(B, 3, H, W, generator=g(50)) * 2.4 - 1.2
+        xr = x.double().requires_grad_()
+        mk = og.MakeCutouts(cs, cutn)
+        cut = og.clip_normalize(mk((xr + 1) / 2, coords=coords))
+        dy = th.randn(cut.shape, generator=g(51)).double()
+        (cut * dy).sum().backward()
+        geo = []
+        for (ox, oy, s) in coords:
+            geo.append((oy, ox, min(s, H - oy), min(s, W - ox)))
+        cd = th.tensor(geo, dtype=th.int32, device=DEV)
+        xd = x.to(DEV)
+        o = th.empty((cutn * B, 3, cs, cs), device=DEV)
+        ctx.check(ctx.lib.cgd_cutouts_fwd(ctx.h, xd.data_ptr(), cd.data_ptr(), o.data_ptr(), B, H, W, cutn, cs, 0, 0, L.stream_ptr()))
+        out.append(rec(f"cutouts fwd B{B} {H}x{W} cutn{cutn} cs{cs}", o, cut.float()))
+        gx = th.empty((B, 3, H, W), device=DEV)
+        dyd = dy.float().to(DEV)
+        ctx.check(ctx.lib.cgd_cutouts_bwd(ctx.h, dyd.data_ptr(), cd.data_ptr(), gx.data_ptr(), B, H, W, cutn, cs, 0, 0, 0, L.stream_ptr()))
+        out.append(rec(f"cutouts bwd B{B} {H}x{W} cutn{cutn} cs{cs}", gx, xr.grad.float()))
+        # patch-row layout = patchify(NCHW)
+        gsz = cs // patch
+        o1 = th.empty((cutn * B * gsz * gsz, 3 * patch * patch), device=DEV)
+        ctx.check(ctx.lib.cgd_cutouts_fwd(ctx.h, xd.data_ptr(), cd.data_ptr(), o1.data_ptr(), B, H, W, cutn, cs, 1, patch, L.stream_ptr()))
+        refp = cut.float().reshape(cutn * B, 3, gsz, patch, gsz, patch).permute(0, 2, 4, 1, 3, 5).reshape(cutn * B * gsz * gsz, -1)
+        out.append(rec(f"cutouts fwd patch-layout B{B} {H}x{W}", o1, refp))
+        dyp = dy.float().reshape(cutn * B, 3, gsz, patch, gsz, patch).permute(0, 2, 4, 1, 3, 5).reshape(cutn * B * gsz * gsz, -1).contiguous().to(DEV)
+        gx1 = th.empty((B, 3, H, W), device=DEV)
+        ctx.check(ctx.lib.cgd_cutouts_bwd(ctx.h, dyp.data_ptr(), cd.data_ptr(), gx1.data_ptr(), B, H, W, cutn, cs, 1, patch, 0, L.stream_ptr()))
+        out.append(rec(f"cutouts bwd patch-layout B{B} {H}x{W}", gx1, xr.grad.float()))
+    # spherical loss (+ broadcast rules of cgd.py:196-200)
+    for (cutn, B, P, D) in [(4, 1, 3, 512), (5, 2, 1, 512), (3, 2, 2, 768)]:
+        emb = th.randn(cutn * B, D, generator=g(52))
+        tg = th.randn(P, D, generator=g(53))
+        wts = th.tensor([1.0, 0.5, -0.3][:P])
+        wts = wts / wts.sum().abs()
+        er = emb.double().requires_grad_()
+        d = og.spherical_dist_loss(er.view(cutn, B, D).unsqueeze(0), tg.double().unsqueeze(0)).view(cutn, B, -1)
+        loss = d.mul(wts.double()).sum(2).mean(0).sum() * 1000.0
+        loss.backward()
+        if B == 1 or P == 1:
+            wm = wts.view(1, P).expand(B, P).contiguous()
+        else:
+            wm = th.eye(B) * wts.sum()
+        demb = th.empty_like(emb, device=DEV)
+        part = th.empty(cutn * B, device=DEV)
+        ed, tn, wd_ = emb.to(DEV), F.normalize(tg, dim=-1).to(DEV), wm.float().contiguous().to(DEV)
+        ctx.check(ctx.lib.cgd_spherical_loss(ctx.h, ed.data_ptr(), tn.data_ptr(), wd_.data_ptr(), demb.data_ptr(), part.data_ptr(), cutn, B, P,
+                                             D, 1000.0, L.stream_ptr()))
+        out.append(rec(f"spherical loss value cutn{cutn} B{B} P{P}", part.sum().reshape(1), loss.detach().float().reshape(1)))
+        out.append(rec(f"spherical loss grad cutn{cutn} B{B} P{P}", demb, er.grad.float()))
+    return out
+
+
+# ---- networks --------------------------------------------------------------------------------------------
+UNET_CASES = {
+    "mini": dict(image_size=32, model_channels=64, num_res_blocks=1, attention_resolutions="16,8", channel_mult=(1, 2, 2), num_classes=10,
+                 num_head_channels=64),
+    "mini128": dict(image_size=32, model_channels=32, num_res_blocks=1, attention_resolutions="8", channel_mult=(1, 2, 4), num_classes=None,
+                    num_heads=2, num_head_channels=-1),
+    "mini64": dict(image_size=32, model_channels=96, num_res_blocks=2, attention_resolutions="32,16,8", channel_mult=(1, 2, 3), num_classes=7,
+                   num_head_channels=32, use_new_attention_order=True),
+    "cfg64": dict(image_size=64, model_channels=192, num_res_blocks=3, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64,
+                  use_new_attention_order=True),
+    "cfg256": dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000,
+                   num_head_channels=64),
+}
+
+
+def build_unet_pair(ctx, case, seed=1234):
+    from cgd_amd import nets
+    from oracle.unet import UNetModel, synthetic_init_
+    kw = UNET_CASES[case]
+    ref = synthetic_init_(UNetModel(**kw), seed=seed).eval()
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    dev = nets.UNet(ctx, **kw)
+    dev.load_state_dict({k: v.to(DEV) for k, v in ref.state_dict().items()})
+    return ref, dev
+
+
+def check_unet(case, precision, B=1, hw=None):
+    ctx = _ctx(precision)
+    ref, dev = build_unet_pair(ctx, case)
+    kw = UNET_CASES[case]
+    H, W = hw or (kw["image_size"], kw["image_size"])
+    x = th.randn(B, 3, H, W, generator=g(60))
+    t = th.tensor([417.0] * B)
+    y = th.randint(0, kw["num_classes"], (B,), generator=g(61)) if kw.get("num_classes") else None
+    gout = th.randn(B, 6, H, W, generator=g(62))
+    gout[:, 3:] = 0  # the guidance only seeds the epsilon channels
+    xr = x.clone().requires_grad_()
+    o = ref(xr, t, y)
+    (o * gout).sum().backward()
+    od = dev.forward(x.to(DEV), t.to(DEV), None if y is None else y.to(DEV))
+    gx = dev.dgrad(gout.to(DEV))
+    th.cuda.synchronize()
+    tag = f"unet[{case} p{precision} B{B} {H}x{W}]"
+    return [rec(f"{tag} forward", od, o.detach()), rec(f"{tag} dgrad", gx, xr.grad)]
+
+
+def build_vit_pair(ctx, name="ViT-B/32", seed=4321):
+    from cgd_amd import nets
+    from oracle.clip_vit import ClipImageModel, synthetic_init_
+    ref = synthetic_init_(ClipImageModel(name), seed=seed).eval().float()
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    dev = nets.ClipImageTower(ctx, name)
+    dev.load_clip_state_dict({k: v.to(DEV) for k, v in ref.state_dict().items()})
+    return ref, dev
+
+
+def check_vit(name, precision, N=3):
+    ctx = _ctx(precision)
+    ref, dev = build_vit_pair(ctx, name)
+    img = th.randn(N, 3, 224, 224, generator=g(70))
+    de = th.randn(N, ref.visual.output_dim, generator=g(71))
+    ir = img.clone().requires_grad_()
+    e = ref.encode_image(ir)
+    (e * de).sum().backward()
+    ed = dev.encode_image(img.to(DEV))
+    di = dev.dgrad(de.to(DEV))
+    th.cuda.synchronize()
+    tag = f"vit[{name} p{precision} N{N}]"
+    return [rec(f"{tag} forward", ed, e.detach()), rec(f"{tag} dgrad", di, ir.grad)]
