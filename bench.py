@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Headline benchmark: diffusion steps/sec (UNet fwd + CLIP fwd + losses + backward to x_t + sampler update).
+
+Workload (BASELINE.json configs[1]): 256x256 class-conditional ADM UNet (554 M params), respace 250, cutn 16,
+batch 1, CLIP ViT-B/32, clip_guidance_scale 1000 / tv 150 / range 50, randomize_class, synthetic seeded weights
+(no checkpoints / network on the bench box).  One "step" = one guided p_sample step of one sample.
+N GPUs run N independent samples (1 per GPU, no per-step collective; one RCCL broadcast of the packed weights at init).
+
+Prints ONE JSON line (see the driver contract) with two extra objects:
+  roofline     : dominant kernel = MFMA implicit-GEMM conv/GEMM (`igemm_kernel`): algorithmic FLOP of all its launches
+                 in the timed region / their summed HIP-event duration, against the dense bf16 MFMA peak (2.5 PF/s).
+  cpu_baseline : the CPU oracle (plain PyTorch fp32 port of the reference path) timed on the host cores (rank 0, N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch as th  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+UNET_256 = dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64)
+FLOP_PER_STEP = 4.775e12  # UNet 2*(1119.8+1125.9) GMAC + CLIP 16*2*(4.409+4.455) GMAC
+
+
+def build_device(ctx, rank, world, precision, clip_name="ViT-B/32"):
+    from cgd_amd import diffusion as dd
+    from cgd_amd import guidance as dg
+    from cgd_amd import nets, sampler, synthetic
+    dev = f"cuda:{ctx.device}"
+    unet = nets.UNet(ctx, **UNET_256)
+    clip = nets.ClipImageTower(ctx, clip_name)
+    for net, seed in ((unet, 1234), (clip, 4321)):
+        specs = net.param_specs()
+        total = sum(n for _, n in specs)
+        if rank == 0:
+            sd = synthetic.synthetic_state_dict(net, seed=seed, device=dev)
+            flat = synthetic.flat_pack(sd, [n for n, _ in specs])
+        else:
+            flat = th.empty(total, device=dev)
+        if world > 1:
+            dist.broadcast(flat, src=0)  # the single collective of the whole job: weights over xGMI (RCCL)
+        net.load_state_dict(synthetic.flat_unpack(flat, specs))
+        del flat
+    tables = dd.create_gaussian_diffusion(1000, "linear", "250", False)
+    smp = sampler.GuidedSampler(ctx, tables)
+    gt = th.Generator().manual_seed(99)
+    targets = th.randn(1, clip.out_dim, generator=gt).to(dev)
+    guid = dg.ClipGuidance(ctx, unet, clip, smp, targets, [1.0], 16, clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0)
+    return unet, clip, smp, guid
+
+
+def run_steps(smp, guid, unet, nsteps, dev, seed):
+    th.manual_seed(seed)
+    y0 = th.zeros(1, dtype=th.long, device=dev)
+    gen = smp.p_sample_loop_progressive(unet, (1, 3, 256, 256), clip_denoised=False, model_kwargs={"y": y0}, cond_fn=guid, device=dev,
+                                        progress=False, skip_timesteps=0, randomize_class=True, cond_fn_with_grad=True)
+    guid.current_timestep = smp.num_timesteps - 1
+    last = None
+    for k, out in enumerate(gen):
+        guid.current_timestep -= 1
+        last = out
+        if k + 1 >= nsteps:
+            break
+    return last
+
+
+def cpu_baseline(steps=2, warmup=1):
+    """CPU oracle = plain-PyTorch fp32 restatement of the reference's --device cpu path, same workload."""
+    from oracle import clip_vit as ocv
+    from oracle import diffusion as od
+    from oracle import guidance as og
+    from oracle import unet as ou
+    cores = os.cpu_count() or 1
+    th.set_num_threads(cores)
+    unet = ou.synthetic_init_(ou.UNetModel(**UNET_256)).eval()
+    clip = ocv.synthetic_init_(ocv.ClipImageModel("ViT-B/32")).eval().float()
+    for p in list(unet.parameters()) + list(clip.parameters()):
+        p.requires_grad_(False)
+    diff = od.create_gaussian_diffusion(1000, "linear", "250", False)
+    targets = th.randn(1, 512, generator=th.Generator().manual_seed(99))
+    mk = og.MakeCutouts(224, 16)
+    cond, state = og.make_cond_fn(diffusion=diff, clip_model=clip, make_cutouts=mk, target_embeds=targets, weights=th.tensor([1.0]),
+                                  num_cutouts=16)
+    th.manual_seed(0)
+    gen = diff.p_sample_loop_progressive(unet, (1, 3, 256, 256), clip_denoised=False, cond_fn=cond, model_kwargs={"y": th.zeros(1, dtype=th.long)},
+                                         device="cpu", randomize_class=True, cond_fn_with_grad=True)
+    state["current_timestep"] = diff.num_timesteps - 1
+    t0 = None
+    for k, _ in enumerate(gen):
+        state["current_timestep"] -= 1
+        if k + 1 == warmup:
+            t0 = time.perf_counter()
+        if k + 1 >= warmup + steps:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "diffusion steps/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} full guided steps of the same 256x256/cutn16/ViT-B/32 workload after {warmup} warm-up, torch fp32, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    th.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=th.device(dev))
+
+    import cgd_amd  # noqa: F401
+    from cgd_amd import lib
+    ctx = lib.Context(local, args.precision)
+    unet, clip, smp, guid = build_device(ctx, rank, world, args.precision)
+
+    total = args.warmup + args.steps
+    assert total <= smp.num_timesteps
+    th.manual_seed(1000 + rank)
+    y0 = th.zeros(1, dtype=th.long, device=dev)
+    gen = smp.p_sample_loop_progressive(unet, (1, 3, 256, 256), clip_denoised=False, model_kwargs={"y": y0}, cond_fn=guid, device=dev,
+                                        progress=False, skip_timesteps=0, randomize_class=True, cond_fn_with_grad=True)
+    guid.current_timestep = smp.num_timesteps - 1
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        th.cuda.synchronize()
+
+    it = iter(gen)
+    for _ in range(args.warmup):
+        next(it)
+        guid.current_timestep -= 1
+    prof = not args.no_profile
+    if prof:
+        ctx.check(ctx.lib.cgd_profile(ctx.h, 1))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = next(it)
+        guid.current_timestep -= 1
+    sync()
+    dt = time.perf_counter() - t0
+    roof = None
+    if prof:
+        buf = (C.c_double * 3)()
+        ctx.check(ctx.lib.cgd_profile_read(ctx.h, buf))
+        ctx.check(ctx.lib.cgd_profile(ctx.h, 0))
+        gemm_ms, gemm_flop, launches = buf[0], buf[1], buf[2]
+        ach = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": f"igemm_kernel<{args.precision}> (implicit-GEMM conv3x3 / GEMM)", "achieved": round(ach, 2),
+                "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
+                "launches_per_step": launches / args.steps, "avg_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
+                "flop_per_launch": gemm_flop / max(launches, 1), "kernel_time_share": round(gemm_ms * 1e-3 / dt, 4),
+                "mfma_products_per_flop": {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]}
+    assert th.isfinite(out["sample"]).all().item(), "non-finite sample"
+    tmax = th.tensor([dt], device=dev, dtype=th.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = tmax.item()
+
+    if rank == 0:
+        res = {
+            "metric": "diffusion steps/sec (UNet+CLIP+grad) at 256x256 cutn=16",
+            "value": round(world * args.steps / tmax, 4),
+            "unit": "diffusion steps/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(tmax / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate, fp32 storage)", "bf16": "bf16"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 256x256 class-cond UNet (554M), respace 250, cutn 16, batch 1/GPU, CLIP ViT-B/32, "
+                                   "cgs 1000 tv 150 range 50, randomize_class, p_sample",
+                       "global_batch": world, "parallelism": f"{world} independent samples (1/GPU), weights broadcast once over RCCL",
+                       "tflop_per_step": FLOP_PER_STEP / 1e12,
+                       "achieved_tflops_whole_step": round(FLOP_PER_STEP * args.steps / tmax / 1e12, 2)},
+        }
+        if roof:
+            res["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # never lose the GPU number to a host-side problem
+                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,30 @@ int cgd_set_precision(cgd_ctx* ctx, int mode) {
 }
 int cgd_get_precision(cgd_ctx* ctx) { return ctx->precision; }
 
+int cgd_profile(cgd_ctx* ctx, int enable) {
+  ctx->prof_on = enable != 0;
+  return 0;
+}
+
+// out[0] = summed MFMA GEMM/conv time (ms), out[1] = summed algorithmic FLOP, out[2] = launches; resets the records
+int cgd_profile_read(cgd_ctx* ctx, double* out) {
+  CGD_HIP(ctx, hipDeviceSynchronize());
+  double ms = 0.0, fl = 0.0;
+  for (ProfRec& r : ctx->prof_recs) {
+    float t = 0.f;
+    CGD_HIP(ctx, hipEventElapsedTime(&t, r.a, r.b));
+    ms += t;
+    fl += r.flops;
+    ctx->prof_pool.push_back(r.a);
+    ctx->prof_pool.push_back(r.b);
+  }
+  out[0] = ms;
+  out[1] = fl;
+  out[2] = (double)ctx->prof_recs.size();
+  ctx->prof_recs.clear();
+  return 0;
+}
+
 int cgd_cutouts_fwd(cgd_ctx* ctx, const float* x_in, const int32_t* coords, float* out, int B, int H, int W, int cutn, int cut_size,
                     int layout, int patch, void* stream) {
   return cgd_launch_cutouts_fwd(ctx, x_in, coords, out, B, H, W, cutn, cut_size, layout, patch, S(stream));

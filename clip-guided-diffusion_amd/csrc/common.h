@@ -13,6 +13,11 @@
 // 2: single bf16 product (fp32 accumulate)
 enum { CGD_PREC_F32 = 0, CGD_PREC_BF16X3 = 1, CGD_PREC_BF16 = 2 };
 
+struct ProfRec {
+  hipEvent_t a, b;
+  double flops;
+};
+
 struct cgd_ctx {
   int device = 0;
   int precision = CGD_PREC_BF16X3;
@@ -20,6 +25,10 @@ struct cgd_ctx {
   float* ws = nullptr;       // split-K partial slabs
   size_t ws_bytes = 0;
   int num_cu = 256;
+  // optional HIP-event timing of every MFMA GEMM/conv launch (bench.py roofline leg)
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
 };
 
 #define CGD_HIP(ctx, expr)                                                                   \

@@ -416,7 +416,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (p.conv && (p.Cin % BK)) CGD_FAIL(ctx, "cgd_launch_gemm: conv Cin must be a multiple of 32");
   if (p.conv) p.K = 9 * p.Cin;
   int tile = p.force_tile;
-  if (!tile) tile = ((long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.nbatch >= ctx->num_cu) ? 128 : 64;
+  if (!tile) tile = (p.M > 64 && p.N > 64 && (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.nbatch >= ctx->num_cu) ? 128 : 64;
   const long ntiles = (long)cdiv(p.M, tile) * cdiv(p.N, tile);
   const int nkt = cdiv(p.K, BK);
   if (p.splitk <= 0) p.splitk = 1;
@@ -431,6 +431,22 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     if ((size_t)p.splitk * p.M * p.N * sizeof(float) > ctx->ws_bytes) CGD_FAIL(ctx, "cgd_launch_gemm: split-K workspace too small");
     p.ws = ctx->ws;
   }
+  ProfRec pr;
+  if (ctx->prof_on) {
+    auto get = [&](hipEvent_t* e) -> int {
+      if (!ctx->prof_pool.empty()) {
+        *e = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+        return 0;
+      }
+      CGD_HIP(ctx, hipEventCreate(e));
+      return 0;
+    };
+    CGD_TRY(get(&pr.a));
+    CGD_TRY(get(&pr.b));
+    pr.flops = 2.0 * p.M * p.N * p.K * p.nbatch;
+    CGD_HIP(ctx, hipEventRecord(pr.a, s));
+  }
   switch (ctx->precision) {
     case CGD_PREC_F32: launch_mode<0>(p, tile, s); break;
     case CGD_PREC_BF16X3: launch_mode<1>(p, tile, s); break;
@@ -441,6 +457,10 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.ws, p.splitk, p.M, p.N, p.C, p.ldc, p.bias, p.R,
                        p.ldr, p.alpha);
+  }
+  if (ctx->prof_on) {
+    CGD_HIP(ctx, hipEventRecord(pr.b, s));
+    ctx->prof_recs.push_back(pr);
   }
   CGD_HIP(ctx, hipGetLastError());
   return 0;

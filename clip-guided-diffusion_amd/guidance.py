@@ -1,0 +1,215 @@
+"""CLIP guidance (`cond_fn`) without autograd: the MI355X replacement of the closure defined at
+/root/reference/cgd/cgd.py:151-239.
+
+`ClipGuidance` keeps the reference's plugin signature `cond_fn(x, t, out, y=None) -> Tensor[B,3,H,W]` and its
+closure-variable semantics (`current_timestep`, set by the generator at cgd.py:265-267), but evaluates the
+gradient in closed form through the C ABI:
+    cutouts -> CLIP ViT forward -> spherical loss (+grad) -> ViT dgrad -> cutout scatter -> tv/range/sat grads
+    -> chain through the blend and x0 = a*x - b*eps -> UNet dgrad -> negative gradient (-> magnitude clamp).
+Cutout coordinates are drawn exactly like the reference does (three CPU-generator draws per cutout,
+/root/reference/cgd/modules.py:44-46).
+"""
+import torch as th
+import torch.nn.functional as F
+
+from . import lib as L
+
+
+def generate_coords(side_x, side_y, cutn, cut_size, cut_pow, generator=None):
+    """(offsetx, offsety, size) per cutout; same draw order as MakeCutouts._generate_coords."""
+    max_size = min(side_y, side_x)
+    min_size = min(side_y, side_x, cut_size)
+    coords = []
+    for _ in range(cutn):
+        size = int(th.rand([], generator=generator) ** cut_pow * (max_size - min_size) + min_size)
+        ox = th.randint(0, side_x - size + 1, (), generator=generator).item()
+        oy = th.randint(0, side_y - size + 1, (), generator=generator).item()
+        coords.append((ox, oy, size))
+    return coords
+
+
+def crop_geometry(coords, H, W):
+    """(ox, oy, size) -> (oy, ox, h, w) of the slice input[:, :, oy:oy+size, ox:ox+size] (truncated at the border)."""
+    return [(oy, ox, max(0, min(size, H - oy)), max(0, min(size, W - ox))) for (ox, oy, size) in coords]
+
+
+class MakeCutouts(th.nn.Module):
+    """Drop-in for cgd.modules.MakeCutouts (modules.py:5-66): same constructor, forward(input, use_cache,
+    num_cutouts_override) and cache_coordinates(side_x, side_y); the crop+pool runs in one HIP kernel.
+    `use_augs` is accepted for signature parity; the reference CLI hard-codes it to False (cgd.py:402)."""
+
+    def __init__(self, cut_size, num_cutouts, cutout_size_power=1.0, use_augs=False, ctx=None):
+        super().__init__()
+        if use_augs:
+            raise NotImplementedError("torchvision augmentations are outside the MI355X hot path (cgd.py:402 disables them)")
+        self.cut_size, self.cutn, self.cut_pow = cut_size, num_cutouts, cutout_size_power
+        self.cached_coords = None
+        self.ctx = ctx
+        self.last_coords = None
+
+    def cache_coordinates(self, side_x, side_y):
+        self.cached_coords = generate_coords(side_x, side_y, self.cutn, self.cut_size, self.cut_pow)
+
+    def draw(self, side_x, side_y, use_cache=False, num_cutouts_override=None):
+        cutn = num_cutouts_override if num_cutouts_override is not None else self.cutn
+        if use_cache and self.cached_coords is not None:
+            return self.cached_coords[:cutn]
+        return generate_coords(side_x, side_y, cutn, self.cut_size, self.cut_pow)
+
+    def forward(self, input, use_cache=False, num_cutouts_override=None):
+        """input (B,3,H,W) in [0,1] -> (cutn*B,3,cut,cut) NCHW, *not* normalised (as in the reference)."""
+        if self.ctx is None:
+            self.ctx = L.Context(input.device.index or 0)
+        B, _, H, W = input.shape
+        coords = self.draw(H, W, use_cache, num_cutouts_override)  # (side_x, side_y) = (H, W): reference naming
+        self.last_coords = coords
+        geo = th.tensor(crop_geometry(coords, H, W), dtype=th.int32, device=input.device)
+        # the kernel pools (x+1)/2 and applies the CLIP normalisation; undo both to return the raw pooled crop
+        x_pm1 = (input.float() * 2 - 1).contiguous()
+        out = th.empty((len(coords) * B, 3, self.cut_size, self.cut_size), device=input.device, dtype=th.float32)
+        self.ctx.check(self.ctx.lib.cgd_cutouts_fwd(self.ctx.h, x_pm1.data_ptr(), geo.data_ptr(), out.data_ptr(), B, H, W, len(coords),
+                                                    self.cut_size, 0, 0, L.stream_ptr()))
+        mean = th.tensor(CLIP_MEAN, device=input.device).view(1, 3, 1, 1)
+        std = th.tensor(CLIP_STD, device=input.device).view(1, 3, 1, 1)
+        return out * std + mean
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def prompt_weight_matrix(weights, batch, device):
+    """The reference broadcasts (1,cutn,B,D) against (1,P,D) (cgd.py:196-200): valid for B==1, P==1 or B==P.
+    Returns the dense (B,P) weights the loss kernel consumes; B==P>1 scores sample b against prompt b only and
+    scales by sum(w)."""
+    w = th.as_tensor(weights, dtype=th.float32).flatten()
+    P = w.numel()
+    if batch == 1 or P == 1:
+        m = w.view(1, P).expand(batch, P)
+    elif batch == P:
+        m = th.eye(batch) * w.sum()
+    else:
+        raise RuntimeError(f"The size of tensor a ({batch}) must match the size of tensor b ({P}) at non-singleton dimension 2")
+    return m.contiguous().to(device)
+
+
+class ClipGuidance:
+    def __init__(self, ctx, unet, clip_tower, diffusion, target_embeds, weights, num_cutouts, cutout_power=1.0,
+                 clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0, sat_scale=0.0, use_magnitude=False,
+                 reduce_clip=False, progressive_cutout=False, cached_cutouts=False, make_cutouts=None):
+        self.ctx, self.unet, self.clip, self.diffusion = ctx, unet, clip_tower, diffusion
+        dev = target_embeds.device
+        self.targets_n = F.normalize(target_embeds.float(), dim=-1).contiguous()
+        self.weights = th.as_tensor(weights, dtype=th.float32, device=dev).flatten()
+        self.num_cutouts = num_cutouts
+        self.cgs, self.tvs, self.rs, self.sats = float(clip_guidance_scale), float(tv_scale), float(range_scale), float(sat_scale)
+        self.use_magnitude = bool(use_magnitude)
+        self.reduce_clip, self.progressive_cutout, self.cached_cutouts = reduce_clip, progressive_cutout, cached_cutouts
+        self.make_cutouts = make_cutouts or MakeCutouts(clip_tower.input_resolution, num_cutouts, cutout_power, ctx=ctx)
+        self.current_timestep = None  # closure counter of cgd.py:149,265-267
+        self.scalars = None
+        self.coords_tape = None  # optional replay of cutout coordinates (tests)
+        self.calls = 0
+        self._wm = {}
+        self._buf = {}
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _b(self, name, shape, device, dtype=th.float32):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
+            t = self._buf[name] = th.empty(shape, device=device, dtype=dtype)
+        return t
+
+    def schedule(self):
+        """Returns (skip_guidance, current_cutn) per cgd.py:155-175."""
+        total = self.diffusion.num_timesteps
+        pct = (total - self.current_timestep) / total
+        if self.reduce_clip and pct < 0.7:
+            if int((pct - 0.2) * total) % 4 != 0:
+                return True, 0
+        if self.progressive_cutout:
+            n = self.num_cutouts
+            return False, (max(4, n // 4) if pct < 0.3 else (max(8, n // 2) if pct < 0.7 else n))
+        return False, self.num_cutouts
+
+    def fac_index(self):
+        return self.current_timestep
+
+    # -- the native gradient ---------------------------------------------------------------------------
+    def native(self, x, x0, x_in, coef):
+        """x, x0 = pred_xstart, x_in = blend: (B,3,H,W) on the GPU.  Returns g (B,3,H,W) or None when the
+        reduce_clip gate skips this step (the reference returns zeros_like(x))."""
+        skip, cutn = self.schedule()
+        if skip:
+            return None
+        ctx, lib = self.ctx, self.ctx.lib
+        B, _, H, W = x.shape
+        dev = x.device
+        s = L.stream_ptr()
+        if self.coords_tape is not None:
+            coords = self.coords_tape[self.calls]
+        else:
+            coords = self.make_cutouts.draw(H, W, self.cached_cutouts, cutn)
+        self.calls += 1
+        self.make_cutouts.last_coords = coords
+        cutn = len(coords)
+        geo = th.tensor(crop_geometry(coords, H, W), dtype=th.int32).to(dev, non_blocking=True)
+        cs, patch = self.clip.input_resolution, self.clip.patch
+        gsz = cs // patch
+        N = cutn * B
+        patches = self._b("patches", (N * gsz * gsz, 3 * patch * patch), dev)
+        ctx.check(lib.cgd_cutouts_fwd(ctx.h, x_in.data_ptr(), geo.data_ptr(), patches.data_ptr(), B, H, W, cutn, cs, 1, patch, s))
+        emb = self.clip.encode_image(patches, layout=1, n=N, out=self._b("emb", (N, self.clip.out_dim), dev))
+        P = self.targets_n.shape[0]
+        wm = self._wm.get(B)
+        if wm is None:
+            wm = self._wm[B] = prompt_weight_matrix(self.weights.cpu(), B, dev)
+        demb = self._b("demb", (N, self.clip.out_dim), dev)
+        clip_part = self._b("clip_part", (N,), dev)
+        ctx.check(lib.cgd_spherical_loss(ctx.h, emb.data_ptr(), self.targets_n.data_ptr(), wm.data_ptr(), demb.data_ptr(),
+                                         clip_part.data_ptr(), cutn, B, P, self.clip.out_dim, self.cgs, s))
+        dpatches = self.clip.dgrad(demb, self._b("dpatches", tuple(patches.shape), dev))
+        gclip = self._b("gclip", (B, 3, H, W), dev)
+        ctx.check(lib.cgd_cutouts_bwd(ctx.h, dpatches.data_ptr(), geo.data_ptr(), gclip.data_ptr(), B, H, W, cutn, cs, 1, patch, 0, s))
+        nblk = lib.cgd_guidance_part_blocks(B, H, W)
+        gdir = self._b("gdir", (B, 3, H, W), dev)
+        seed6 = self._b("seed6", (B, 6, H, W), dev)
+        lpart = self._b("lpart", (nblk, 3), dev)
+        ctx.check(lib.cgd_guidance_combine(ctx.h, gclip.data_ptr(), x_in.data_ptr(), x0.data_ptr(), gdir.data_ptr(), seed6.data_ptr(),
+                                           lpart.data_ptr(), B, H, W, coef, self.tvs, self.rs, self.sats, s))
+        gunet = self.unet.dgrad(seed6, self._b("gunet", (B, 3, H, W), dev))
+        g = self._b("g", (B, 3, H, W), dev)
+        gpart = self._b("gpart", (nblk, 2), dev)
+        ctx.check(lib.cgd_grad_finish(ctx.h, gdir.data_ptr(), gunet.data_ptr(), g.data_ptr(), gpart.data_ptr(), B, H, W, s))
+        self.scalars = self._b("scalars", (8,), dev)
+        ctx.check(lib.cgd_scalars(ctx.h, clip_part.data_ptr(), N, lpart.data_ptr(), gpart.data_ptr(), B, H, W, int(self.use_magnitude),
+                                  self.scalars.data_ptr(), s))
+        self._keep = geo
+        self.emb = emb
+        return g
+
+    def log(self):
+        """Scalar log of the last call with the reference's keys (one host sync; call lazily)."""
+        v = self.scalars.tolist()
+        out = {"CLIP Loss": v[0], "Range Loss": v[2], "TV Loss": v[1]}
+        if self.sats != 0:
+            out["Saturation Loss"] = v[3]
+        out["Total Loss"] = v[4]
+        if self.use_magnitude:
+            out["Magnitude"] = v[5]
+        out["Grad"] = v[6]
+        return out
+
+    # -- reference plugin signature ----------------------------------------------------------------------
+    def __call__(self, x, t, out, y=None):
+        """cond_fn(x, t, out, y=None): `out['pred_xstart']` must come from the last `unet.forward(x, ...)`."""
+        coef = self.diffusion.step_coef(int(t.flatten()[0].item()), self.fac_index())
+        x = x.detach().contiguous().float()
+        x0 = out["pred_xstart"].detach().contiguous().float()
+        x_in = (x0 * coef.fac + x * (1 - coef.fac)).contiguous()
+        g = self.native(x, x0, x_in, coef)
+        if g is None:
+            return th.zeros_like(x)
+        if self.use_magnitude:
+            g = g * self.scalars[7]
+        return g.clone()

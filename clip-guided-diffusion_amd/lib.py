@@ -44,6 +44,8 @@ _SIGS = {
     "cgd_last_error": (C.c_char_p, [vp]),
     "cgd_set_precision": (i32, [vp, i32]),
     "cgd_get_precision": (i32, [vp]),
+    "cgd_profile": (i32, [vp, i32]),
+    "cgd_profile_read": (i32, [vp, C.POINTER(C.c_double)]),
     "cgd_unet_create": (i32, [vp, C.POINTER(UNetConfig), C.POINTER(vp)]),
     "cgd_unet_destroy": (None, [vp]),
     "cgd_unet_num_params": (i32, [vp]),

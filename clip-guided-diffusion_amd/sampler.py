@@ -1,0 +1,149 @@
+"""Guided sampling loops on the MI355X: the replacement of guided_diffusion's
+`p_sample_loop_progressive` / `ddim_sample_loop_progressive` (+ `p_sample_with_grad`, `ddim_sample_with_grad`,
+`condition_mean_with_grad`, `condition_score_with_grad`) as the reference calls them at
+/root/reference/cgd/cgd.py:242-262 (same keyword arguments, same yielded dicts {"sample", "pred_xstart"}).
+
+Per step: UNet forward (C ABI) -> p_mean_variance tail + blend (HIP) -> noise draw -> cond_fn -> update (HIP).
+With a `ClipGuidance` cond_fn everything stays native; any other Python callable gets the reference semantics
+through autograd Functions whose forward/backward call the same C ABI (`UNetFunction`).
+"""
+import torch as th
+
+from . import lib as L
+from .guidance import ClipGuidance
+
+
+class UNetFunction(th.autograd.Function):
+    """model(x, ts, y) as an autograd node: backward = cgd_unet_dgrad (only d/dx exists)."""
+
+    @staticmethod
+    def forward(ctx, x, unet, ts, y):
+        ctx.unet = unet
+        return unet.forward(x, ts, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.unet.dgrad(g.contiguous()), None, None, None
+
+
+class GuidedSampler:
+    """`diffusion` object handed to the drop-in generator: owns the host tables (diffusion.SpacedDiffusion) and
+    runs the progressive loops on one GPU."""
+
+    def __init__(self, ctx, tables):
+        self.ctx = ctx
+        self.tables = tables
+        self.num_timesteps = tables.num_timesteps
+        self.sqrt_one_minus_alphas_cumprod = tables.sqrt_one_minus_alphas_cumprod
+        self.timestep_map = tables.timestep_map
+        self.tape = None  # optional {'x_T','noise':[...],'y':[...]} replay (tests / multi-GPU slicing)
+
+    def step_coef(self, i, fac_index=None):
+        return self.tables.step_coef(i, fac_index)
+
+    # ---- one step -------------------------------------------------------------------------------------
+    def _step(self, model, x, i, cond_fn, model_kwargs, noise, mode, bufs):
+        ctx, lib = self.ctx, self.ctx.lib
+        B, _, H, W = x.shape
+        dev = x.device
+        s = L.stream_ptr()
+        native = isinstance(cond_fn, ClipGuidance)
+        fac_index = cond_fn.fac_index() if native else None
+        coef = self.tables.step_coef(i, fac_index)
+        ts = th.full((B,), self.tables.model_timestep(i), device=dev, dtype=th.float32)
+        y = model_kwargs.get("y") if model_kwargs else None
+
+        def buf(name, shape):
+            t = bufs.get(name)
+            if t is None or tuple(t.shape) != tuple(shape):
+                t = bufs[name] = th.empty(shape, device=dev, dtype=th.float32)
+            return t
+
+        x0, mean, logvar, xin = (buf(n, (B, 3, H, W)) for n in ("x0", "mean", "logvar", "xin"))
+        sample, x0_out = th.empty_like(x), th.empty_like(x)
+        if cond_fn is None or native:
+            out6 = model.forward(x, ts, y, out=buf("out6", (B, 6, H, W)))
+            ctx.check(lib.cgd_pmv_blend(ctx.h, x.data_ptr(), out6.data_ptr(), x0.data_ptr(), mean.data_ptr(), logvar.data_ptr(),
+                                        xin.data_ptr(), B, H, W, coef, s))
+            if noise is None:
+                noise = th.randn_like(x)  # drawn before cond_fn, as in p_sample_with_grad
+            g = cond_fn.native(x, x0, xin, coef) if native else None
+            scal = cond_fn.scalars if (native and g is not None and cond_fn.use_magnitude) else None
+            ctx.check(lib.cgd_sample_update(ctx.h, x.data_ptr(), x0.data_ptr(), mean.data_ptr(), logvar.data_ptr(), L.ptr(g),
+                                            noise.data_ptr(), L.ptr(scal), sample.data_ptr(), x0_out.data_ptr(), B, H, W, coef, mode, s))
+        else:
+            # generic plugin path: reference semantics via autograd over the C-ABI UNet node
+            with th.enable_grad():
+                xr = x.detach().requires_grad_()
+                out6 = UNetFunction.apply(xr, model, ts, y)
+                eps, v = out6[:, :3], out6[:, 3:]
+                frac = (v + 1) / 2
+                lv = frac * coef.max_log + (1 - frac) * coef.min_log
+                p0 = coef.sqrt_recip * xr - coef.sqrt_recipm1 * eps
+                mu = coef.coef1 * p0 + coef.coef2 * xr
+                if noise is None:
+                    noise = th.randn_like(x)
+                t_idx = th.full((B,), i, device=dev, dtype=th.long)
+                p = {"mean": mu, "variance": th.exp(lv), "log_variance": lv, "pred_xstart": p0}
+                g = cond_fn(xr, t_idx, p, **(model_kwargs or {}))
+            g = g.detach().float().contiguous()
+            x0.copy_(p0.detach()); mean.copy_(mu.detach()); logvar.copy_(lv.detach())
+            ctx.check(lib.cgd_sample_update(ctx.h, x.data_ptr(), x0.data_ptr(), mean.data_ptr(), logvar.data_ptr(), g.data_ptr(),
+                                            noise.data_ptr(), None, sample.data_ptr(), x0_out.data_ptr(), B, H, W, coef, mode, s))
+        bufs["_keep"] = (noise, g, ts)
+        return {"sample": sample, "pred_xstart": x0_out}
+
+    # ---- loops ------------------------------------------------------------------------------------------
+    def _loop(self, mode, model, shape, noise, clip_denoised, cond_fn, model_kwargs, device, progress, skip_timesteps, init_image,
+              randomize_class, cond_fn_with_grad):
+        if clip_denoised:
+            raise NotImplementedError("the reference samples with clip_denoised=False (cgd.py:253)")
+        if cond_fn is not None and not cond_fn_with_grad:
+            raise NotImplementedError("the reference passes cond_fn_with_grad=True (cgd.py:260)")
+        device = th.device(device or f"cuda:{self.ctx.device}")
+        tape = self.tape
+        if noise is not None:
+            img = noise.to(device).float()
+        elif tape is not None:
+            img = tape["x_T"].to(device).float()
+        else:
+            img = th.randn(*shape, device=device)
+        if skip_timesteps and init_image is None:
+            init_image = th.zeros_like(img)
+        indices = list(range(self.num_timesteps - skip_timesteps))[::-1]
+        if init_image is not None:
+            t0 = indices[0]
+            img = float(self.tables.sqrt_alphas_cumprod[t0]) * init_image.to(device).float() + \
+                float(self.tables.sqrt_one_minus_alphas_cumprod[t0]) * img
+        model_kwargs = dict(model_kwargs or {})
+        it = indices
+        if progress:
+            from tqdm.auto import tqdm
+            it = tqdm(indices)
+        bufs = {}
+        img = img.contiguous()
+        for n, i in enumerate(it):
+            if randomize_class and "y" in model_kwargs:
+                if tape is not None:
+                    model_kwargs["y"] = tape["y"][n].to(device)
+                else:
+                    model_kwargs["y"] = th.randint(0, model.num_classes, model_kwargs["y"].shape, device=device)
+            step_noise = tape["noise"][n].to(device).float().contiguous() if tape is not None else None
+            with th.no_grad():
+                out = self._step(model, img, i, cond_fn, model_kwargs, step_noise, mode, bufs)
+            yield out
+            img = out["sample"]
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                                  randomize_class=False, cond_fn_with_grad=False):
+        return self._loop(0, model, shape, noise, clip_denoised, cond_fn, model_kwargs, device, progress, skip_timesteps, init_image,
+                          randomize_class, cond_fn_with_grad)
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
+                                     randomize_class=False, cond_fn_with_grad=False):
+        if eta != 0.0:
+            raise NotImplementedError("the reference never passes eta (DDIM eta = 0)")
+        return self._loop(1, model, shape, noise, clip_denoised, cond_fn, model_kwargs, device, progress, skip_timesteps, init_image,
+                          randomize_class, cond_fn_with_grad)

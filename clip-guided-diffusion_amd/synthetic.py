@@ -1,0 +1,34 @@
+"""Seeded synthetic weights for benchmarking without checkpoints (no network on the bench box).
+
+Random-init tensors of the exact parameter shapes the handles expect (names from cgd_*_param_info).  Upstream's
+zero-initialised layers get small non-zero values so that no gradient path is dead.
+"""
+import torch as th
+
+
+def synthetic_state_dict(net, seed=1234, device="cuda", std=0.02):
+    g = th.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, numel in net.param_specs():
+        leaf = name.rsplit(".", 1)[-1]
+        is_norm_gain = leaf == "weight" and any(k in name for k in (".in_layers.0.", ".out_layers.0.", ".norm.", "out.0.", "ln_"))
+        if is_norm_gain:
+            t = 1.0 + std * th.randn(numel, device=device, generator=g)
+        elif name == "label_emb.weight":
+            t = th.randn(numel, device=device, generator=g)
+        else:
+            t = std * th.randn(numel, device=device, generator=g)
+        sd[name] = t
+    return sd
+
+
+def flat_pack(sd, names):
+    return th.cat([sd[n].reshape(-1).float() for n in names])
+
+
+def flat_unpack(flat, specs):
+    out, off = {}, 0
+    for name, numel in specs:
+        out[name] = flat[off:off + numel]
+        off += numel
+    return out

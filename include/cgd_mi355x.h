@@ -36,6 +36,10 @@ const char* cgd_last_error(cgd_ctx* ctx);
 int cgd_set_precision(cgd_ctx* ctx, int mode);
 int cgd_get_precision(cgd_ctx* ctx);
 const char* cgd_version(void);
+/* HIP-event timing of every MFMA GEMM/conv launch on its own stream (measurement only; bench.py roofline leg).
+ * cgd_profile_read: out[0] = summed kernel time (ms), out[1] = summed algorithmic FLOP, out[2] = launches; resets. */
+int cgd_profile(cgd_ctx* ctx, int enable);
+int cgd_profile_read(cgd_ctx* ctx, double* out3);
 
 /* ---- UNet epsilon/sigma predictor: replaces guided_diffusion.unet.UNetModel built at
  *      /root/reference/cgd/script_util.py:316 from /root/reference/data/diffusion_model_flags.py ---- */

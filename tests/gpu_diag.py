@@ -23,9 +23,18 @@ GROUPS = {
     "vit": [lambda: pc.check_vit("ViT-B/32", 0), lambda: pc.check_vit("ViT-B/32", 1)],
     "unet64": [lambda: pc.check_unet("cfg64", 0), lambda: pc.check_unet("cfg64", 1), lambda: pc.check_unet("cfg64", 2)],
     "unet256": [lambda: pc.check_unet("cfg256", 1)],
-    "step": [lambda: __import__("tests.step_checks", fromlist=["x"]).check_step("mini", 1),
-             lambda: __import__("tests.step_checks", fromlist=["x"]).check_step("mini", 1, ddim=True)],
+    "step": [lambda: _sc().check_step("mini", 0, respacing="4", steps=4),
+             lambda: _sc().check_step("mini", 1, respacing="4", steps=4),
+             lambda: _sc().check_step("mini", 1, ddim=True, respacing="4", steps=4),
+             lambda: _sc().check_step("mini", 1, respacing="50", steps=3, B=2, P=2, use_magnitude=True, sat_scale=30.0),
+             lambda: _sc().check_step("mini64", 1, respacing="25", schedule="cosine", steps=2, P=3, hw=(32, 48), scales=(5.0, 1e-5, 50.0),
+                                      use_magnitude=True)],
 }
+
+
+def _sc():
+    from tests import step_checks
+    return step_checks
 
 
 def main():

@@ -1,0 +1,96 @@
+"""Whole-step parity (SURVEY.md parity tier T4/T5): the native guided sampler against the CPU oracle's
+`p_sample_loop_progressive` / `ddim_sample_loop_progressive` + autograd cond_fn, on the same seeded synthetic
+weights, with a replayed RNG tape (x_T, per-step noise, class ids, cutout coordinates)."""
+import torch as th
+
+from tests import parity_checks as pc
+from tests.parity_checks import DEV, g, rec
+
+
+def make_tape(B, H, W, nsteps, num_classes, cutn, cut_size, cut_pow=1.0, seed=0):
+    from oracle import guidance as og
+    gen = th.Generator().manual_seed(seed)
+    tape = {"x_T": th.randn(B, 3, H, W, generator=gen), "noise": [], "y": [], "coords": []}
+    for _ in range(nsteps):
+        tape["y"].append(th.randint(0, max(1, num_classes or 1), (B,), generator=gen))
+        tape["noise"].append(th.randn(B, 3, H, W, generator=gen))
+        tape["coords"].append(og.generate_coords(H, W, cutn, cut_size, cut_pow, generator=gen))
+    return tape
+
+
+def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_cfg=(64, 16, 128, 2, 2, 64), P=1, hw=None,
+               respacing="50", schedule="linear", use_magnitude=False, sat_scale=0.0, scales=(1000.0, 150.0, 50.0), skip=0,
+               weights=None):
+    from cgd_amd import diffusion as dd
+    from cgd_amd import guidance as dg
+    from cgd_amd import lib, nets, sampler
+    from oracle import clip_vit as ocv
+    from oracle import diffusion as od
+    from oracle import guidance as og
+
+    ctx = lib.Context(0, precision)
+    kw = pc.UNET_CASES[case]
+    H, W = hw or (kw["image_size"], kw["image_size"])
+    ref_unet, dev_unet = pc.build_unet_pair(ctx, case)
+    # small CLIP tower so that the oracle finishes in seconds; the full ViT-B/32 has its own check
+    res, patch, width, layers, heads, outd = vit_cfg
+    ref_clip = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
+    th.nn.Module.__init__(ref_clip)
+    ref_clip.visual = ocv.VisionTransformer(res, patch, width, layers, heads, outd)
+    ocv.synthetic_init_(ref_clip).eval()
+    for p in ref_clip.parameters():
+        p.requires_grad_(False)
+    dev_clip = nets.ClipImageTower(ctx, config=vit_cfg)
+    dev_clip.load_clip_state_dict({k: v.to(DEV) for k, v in ref_clip.state_dict().items()})
+
+    spec = ("ddim" + respacing) if ddim else respacing
+    rescale = False
+    o_diff = od.create_gaussian_diffusion(1000, schedule, spec, rescale)
+    d_tab = dd.create_gaussian_diffusion(1000, schedule, spec, rescale)
+    smp = sampler.GuidedSampler(ctx, d_tab)
+    N = o_diff.num_timesteps
+    tape = make_tape(B, H, W, steps, kw.get("num_classes"), cutn, res)
+    targets = th.randn(P, outd, generator=g(80))
+    w = th.tensor(weights if weights is not None else [1.0, 0.5, -0.3][:P])
+    w = w / w.sum().abs()
+    cgs, tvs, rs = scales
+
+    # ---- oracle ----
+    mk = og.MakeCutouts(res, cutn)
+    o_cond, o_state = og.make_cond_fn(diffusion=o_diff, clip_model=ref_clip, make_cutouts=mk, target_embeds=targets, weights=w,
+                                      num_cutouts=cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs, sat_scale=sat_scale,
+                                      use_magnitude=use_magnitude, coords_tape=tape["coords"])
+    mkw = {"y": th.zeros(B, dtype=th.long)} if kw.get("num_classes") else {}
+    loop = o_diff.ddim_sample_loop_progressive if ddim else o_diff.p_sample_loop_progressive
+    o_gen = loop(ref_unet, (B, 3, H, W), clip_denoised=False, cond_fn=o_cond, model_kwargs=dict(mkw), device="cpu",
+                 skip_timesteps=N - steps, randomize_class=bool(mkw), cond_fn_with_grad=True, tape=tape)
+    # NB skip_timesteps>0 engages the reference's `current_timestep` offset quirk: the closure
+    # counter still starts at N-1 while t starts at N-1-skip.
+    o_state["current_timestep"] = N - 1
+    o_out = []
+    for out in o_gen:
+        o_state["current_timestep"] -= 1
+        o_out.append((out["sample"].clone(), out["pred_xstart"].clone(), dict(o_state["log"])))
+
+    # ---- device ----
+    guid = dg.ClipGuidance(ctx, dev_unet, dev_clip, smp, targets.to(DEV), w, cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs,
+                           sat_scale=sat_scale, use_magnitude=use_magnitude)
+    guid.coords_tape = tape["coords"]
+    smp.tape = tape
+    dmkw = {"y": th.zeros(B, dtype=th.long, device=DEV)} if kw.get("num_classes") else {}
+    dloop = smp.ddim_sample_loop_progressive if ddim else smp.p_sample_loop_progressive
+    d_gen = dloop(dev_unet, (B, 3, H, W), clip_denoised=False, cond_fn=guid, model_kwargs=dmkw, device=DEV, skip_timesteps=N - steps,
+                  randomize_class=bool(dmkw), cond_fn_with_grad=True)
+    guid.current_timestep = N - 1
+    recs = []
+    tag = f"step[{case} p{precision} {'ddim' if ddim else 'p'} B{B} {H}x{W} mag{int(use_magnitude)} sat{sat_scale}]"
+    for k, out in enumerate(d_gen):
+        guid.current_timestep -= 1
+        th.cuda.synchronize()
+        o_s, o_x0, o_log = o_out[k]
+        recs.append(rec(f"{tag} step{k} sample", out["sample"], o_s))
+        recs.append(rec(f"{tag} step{k} pred_xstart", out["pred_xstart"], o_x0))
+        lg = guid.log()
+        for key in ("CLIP Loss", "TV Loss", "Range Loss", "Total Loss"):
+            recs.append(rec(f"{tag} step{k} {key}", th.tensor([lg[key]]), th.tensor([o_log[key]])))
+    return recs
