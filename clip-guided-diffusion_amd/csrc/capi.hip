@@ -27,7 +27,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
       return -4;
     }
   }
-  ctx->ws_bytes = (size_t)64 << 20;
+  ctx->ws_bytes = (size_t)256 << 20;
   if (hipMalloc((void**)&ctx->ws, ctx->ws_bytes) != hipSuccess) {
     delete ctx;
     return -1;
@@ -50,6 +50,12 @@ int cgd_set_precision(cgd_ctx* ctx, int mode) {
   return 0;
 }
 int cgd_get_precision(cgd_ctx* ctx) { return ctx->precision; }
+
+int cgd_set_tiles(cgd_ctx* ctx, int large, int small) {
+  ctx->tile_large = large;
+  ctx->tile_small = small;
+  return 0;
+}
 
 int cgd_profile(cgd_ctx* ctx, int enable) {
   ctx->prof_on = enable != 0;

@@ -9,6 +9,8 @@
 //   MODE 0  v_mfma_f32_32x32x2_f32        exact fp32 products
 //   MODE 1  v_mfma_f32_32x32x16_bf16 x3   a = hi + lo split, hi*hi + hi*lo + lo*hi
 //   MODE 2  v_mfma_f32_32x32x16_bf16      single product
+// Template parameters: block tile BM x BN, wavefront tile WM x WN (workgroup = (BM/WM)*(BN/WN) wavefronts),
+// PF = register prefetch distance in K tiles (2 keeps two tiles of global loads in flight across the barrier).
 // LDS rows are padded (36 floats / 40 bf16) so that ds_read_b128 fragment reads are conflict free
 // (row stride = 9 resp. 5 sixteen-byte slots, both coprime to the 16 slots of a bank row).
 // blockIdx -> tile mapping is XCD aware: the 8 XCDs each get a contiguous run of tiles so that the
@@ -22,15 +24,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 32;
-constexpr int PF = 36;  // fp32 LDS pitch (floats)
-constexpr int PH = 40;  // bf16 LDS pitch (elements)
+constexpr int PF_ = 36;  // fp32 LDS pitch (floats)
+constexpr int PH = 40;   // bf16 LDS pitch (elements)
 
 template <int MODE, int BM, int BN>
 struct Smem;
 template <int BM, int BN>
 struct Smem<0, BM, BN> {
-  float a[2][BM][PF];
-  float b[2][BN][PF];
+  float a[2][BM][PF_];
+  float b[2][BN][PF_];
 };
 template <int BM, int BN>
 struct Smem<1, BM, BN> {
@@ -55,13 +57,15 @@ __device__ __forceinline__ float4 residual4(const float4 v, const bf16x4 hi) {
   return make_float4(v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]);
 }
 
-template <int MODE, int BM, int BN>
-__global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
+template <int MODE, int BM, int BN, int WM, int WN, int PF>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) Smem<MODE, BM, BN> sm;
-  constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 32, NB = WN / 32;
-  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int NWN = BN / WN, NT = (BM / WM) * NWN * 64;
+  constexpr int MB = WM / 32, NB = WN / 32;
+  constexpr int RPP = NT / 8, RA = BM / RPP, RB = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int l31 = lane & 31, hh = lane >> 5;
 
   // ---- tile id with XCD-contiguous remap (bijective for any grid size) -------------------------
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
   bool a_ok[RA];
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
-    const int m = m0 + r0 + 32 * j;
+    const int m = m0 + r0 + RPP * j;
     a_ok[j] = m < p.M;
     if (p.conv) {
       const int hw = p.H * p.W;
@@ -116,15 +120,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
   bool b_ok[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
-    const int n = n0 + r0 + 32 * j;
+    const int n = n0 + r0 + RPP * j;
     b_ok[j] = n < p.N;
     b_off[j] = (long)n * p.ldb;
   }
 
-  float4 ra[RA], rb[RB];
+  float4 ra0[RA], rb0[RB];
+  float4 ra1[PF == 2 ? RA : 1], rb1[PF == 2 ? RB : 1];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-#define GLOAD(KT)                                                                                  \
+#define GLOAD(KT, RA_, RB_)                                                                        \
   {                                                                                                \
     const int kbase = (KT) * BK;                                                                   \
     const int kk = kbase + c4 * 4;                                                                 \
@@ -138,36 +143,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
           yy >>= 1;                                                                                \
           xx >>= 1;                                                                                \
         }                                                                                          \
-        ra[j] = ok ? *(const float4*)(A + (a_off[j] + (long)yy * Ws + xx) * p.lda + ci) : z4;      \
+        RA_[j] = ok ? *(const float4*)(A + (a_off[j] + (long)yy * Ws + xx) * p.lda + ci) : z4;     \
       }                                                                                            \
     } else {                                                                                       \
       _Pragma("unroll") for (int j = 0; j < RA; ++j)                                               \
-          ra[j] = (a_ok[j] && kk < p.K) ? *(const float4*)(A + a_off[j] + kk) : z4;                \
+          RA_[j] = (a_ok[j] && kk < p.K) ? *(const float4*)(A + a_off[j] + kk) : z4;               \
     }                                                                                              \
     _Pragma("unroll") for (int j = 0; j < RB; ++j)                                                 \
-        rb[j] = (b_ok[j] && kk < p.K) ? *(const float4*)(B + b_off[j] + kk) : z4;                  \
+        RB_[j] = (b_ok[j] && kk < p.K) ? *(const float4*)(B + b_off[j] + kk) : z4;                 \
   }
 
-#define SSTORE(BUF)                                                                                \
+#define SSTORE(BUF, RA_, RB_)                                                                      \
   {                                                                                                \
     _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                               \
-      const int row = r0 + 32 * j;                                                                 \
+      const int row = r0 + RPP * j;                                                                \
       if constexpr (MODE == 0) {                                                                   \
-        *(float4*)&sm.a[BUF][row][c4 * 4] = ra[j];                                                 \
+        *(float4*)&sm.a[BUF][row][c4 * 4] = RA_[j];                                                \
       } else {                                                                                     \
-        const bf16x4 hi = to_bf16x4(ra[j]);                                                        \
+        const bf16x4 hi = to_bf16x4(RA_[j]);                                                       \
         *(bf16x4*)&sm.ah[BUF][row][c4 * 4] = hi;                                                   \
-        if constexpr (MODE == 1) *(bf16x4*)&sm.al[BUF][row][c4 * 4] = to_bf16x4(residual4(ra[j], hi)); \
+        if constexpr (MODE == 1) *(bf16x4*)&sm.al[BUF][row][c4 * 4] = to_bf16x4(residual4(RA_[j], hi)); \
       }                                                                                            \
     }                                                                                              \
     _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                               \
-      const int row = r0 + 32 * j;                                                                 \
+      const int row = r0 + RPP * j;                                                                \
       if constexpr (MODE == 0) {                                                                   \
-        *(float4*)&sm.b[BUF][row][c4 * 4] = rb[j];                                                 \
+        *(float4*)&sm.b[BUF][row][c4 * 4] = RB_[j];                                                \
       } else {                                                                                     \
-        const bf16x4 hi = to_bf16x4(rb[j]);                                                        \
+        const bf16x4 hi = to_bf16x4(RB_[j]);                                                       \
         *(bf16x4*)&sm.bh[BUF][row][c4 * 4] = hi;                                                   \
-        if constexpr (MODE == 1) *(bf16x4*)&sm.bl[BUF][row][c4 * 4] = to_bf16x4(residual4(rb[j], hi)); \
+        if constexpr (MODE == 1) *(bf16x4*)&sm.bl[BUF][row][c4 * 4] = to_bf16x4(residual4(RB_[j], hi)); \
       }                                                                                            \
     }                                                                                              \
   }
@@ -180,71 +185,79 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (kt0 < kt1) {
-    GLOAD(kt0);
-    SSTORE(0);
+#define COMPUTE(BUF)                                                                                                     \
+  {                                                                                                                      \
+    if constexpr (MODE == 0) {                                                                                           \
+      float4 fa[MB][4], fb[NB][4];                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int q = 0; q < 4; ++q)                       \
+          fa[i][q] = *(const float4*)&sm.a[BUF][wm * WM + i * 32 + l31][hh * 16 + q * 4];                               \
+      _Pragma("unroll") for (int j = 0; j < NB; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q)                       \
+          fb[j][q] = *(const float4*)&sm.b[BUF][wn * WN + j * 32 + l31][hh * 16 + q * 4];                               \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
+        _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j) {                  \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].x, fb[j][q].x, acc[i][j], 0, 0, 0);                  \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].y, fb[j][q].y, acc[i][j], 0, 0, 0);                  \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].z, fb[j][q].z, acc[i][j], 0, 0, 0);                  \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].w, fb[j][q].w, acc[i][j], 0, 0, 0);                  \
+        }                                                                                                                \
+      }                                                                                                                  \
+    } else {                                                                                                             \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                 \
+        bf16x8 ah[MB], bh[NB], al[MB], bl[NB];                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MB; ++i) {                                                                 \
+          ah[i] = *(const bf16x8*)&sm.ah[BUF][wm * WM + i * 32 + l31][ks * 16 + hh * 8];                                 \
+          if constexpr (MODE == 1) al[i] = *(const bf16x8*)&sm.al[BUF][wm * WM + i * 32 + l31][ks * 16 + hh * 8];       \
+        }                                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                                 \
+          bh[j] = *(const bf16x8*)&sm.bh[BUF][wn * WN + j * 32 + l31][ks * 16 + hh * 8];                                 \
+          if constexpr (MODE == 1) bl[j] = *(const bf16x8*)&sm.bl[BUF][wn * WN + j * 32 + l31][ks * 16 + hh * 8];       \
+        }                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j) {                  \
+          if constexpr (MODE == 1) {                                                                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);                       \
+          }                                                                                                              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);                         \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }                                                                                                                    \
   }
-  __syncthreads();
 
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
-    if (more) GLOAD(kt + 1);
-
-    if constexpr (MODE == 0) {
-      float4 fa[MB][4], fb[NB][4];
-#pragma unroll
-      for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fa[i][q] = *(const float4*)&sm.a[buf][wm * WM + i * 32 + l31][hh * 16 + q * 4];
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fb[j][q] = *(const float4*)&sm.b[buf][wn * WN + j * 32 + l31][hh * 16 + q * 4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].x, fb[j][q].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].y, fb[j][q].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].z, fb[j][q].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].w, fb[j][q].w, acc[i][j], 0, 0, 0);
-          }
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 ah[MB], bh[NB], al[MB], bl[NB];
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-          ah[i] = *(const bf16x8*)&sm.ah[buf][wm * WM + i * 32 + l31][ks * 16 + hh * 8];
-          if constexpr (MODE == 1) al[i] = *(const bf16x8*)&sm.al[buf][wm * WM + i * 32 + l31][ks * 16 + hh * 8];
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          bh[j] = *(const bf16x8*)&sm.bh[buf][wn * WN + j * 32 + l31][ks * 16 + hh * 8];
-          if constexpr (MODE == 1) bl[j] = *(const bf16x8*)&sm.bl[buf][wn * WN + j * 32 + l31][ks * 16 + hh * 8];
-        }
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            if constexpr (MODE == 1) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
-      }
+  if constexpr (PF == 1) {
+    if (kt0 < kt1) {
+      GLOAD(kt0, ra0, rb0);
+      SSTORE(0, ra0, rb0);
     }
-
-    if (more) SSTORE(buf ^ 1);
     __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      if (more) GLOAD(kt + 1, ra0, rb0);
+      COMPUTE(buf);
+      if (more) SSTORE(buf ^ 1, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    // two K tiles of global loads in flight: tile kt+1 sits in one register set while kt+2 is being fetched
+    if (kt0 < kt1) GLOAD(kt0, ra0, rb0);
+    if (kt0 + 1 < kt1) GLOAD(kt0 + 1, ra1, rb1);
+    if (kt0 < kt1) SSTORE(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      if (kt + 2 < kt1) GLOAD(kt + 2, ra0, rb0);
+      COMPUTE(0);
+      if (kt + 1 < kt1) SSTORE(1, ra1, rb1);
+      __syncthreads();
+      if (kt + 1 >= kt1) break;
+      if (kt + 3 < kt1) GLOAD(kt + 3, ra1, rb1);
+      COMPUTE(1);
+      if (kt + 2 < kt1) SSTORE(0, ra0, rb0);
+      __syncthreads();
+    }
   }
 #undef GLOAD
 #undef SSTORE
+#undef COMPUTE
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   if (p.splitk > 1) {
@@ -294,120 +307,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, int WM, int WN, int PF>
 void launch_cfg(const GemmParams& p, hipStream_t s) {
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, p.splitk > 1 ? p.splitk : p.nbatch);
-  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, PF>), grid, dim3(NT), 0, s, p);
 }
 
+// tile codes: 64 = 64x64, 128 = 128x128, 256 = 256x128 (8 waves), 257 = 128x256 (wave tile 64x128);
+// +1000 selects the 2-deep register prefetch variant
 template <int MODE>
-void launch_mode(const GemmParams& p, int tile, hipStream_t s) {
-  if (tile == 128)
-    launch_cfg<MODE, 128, 128>(p, s);
-  else
-    launch_cfg<MODE, 64, 64>(p, s);
-}
-
-// ---- thin direct convolutions for the 3/6-channel ends of the UNet ----------------------------------
-// conv_in: NCHW input with CIN <= 8 channels -> NHWC output, weights [Cout][ky][kx][CIN].
-template <int CIN>
-__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, float* __restrict__ y, int Bn, int H,
-                                                      int W, int Cout, int pix_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [9*CIN][Cout]
-  const int KK = 9 * CIN;
-  for (int i = threadIdx.x; i < KK * Cout; i += blockDim.x) {
-    const int co = i / KK, k = i - co * KK;
-    wsm[k * Cout + co] = w[i];
+int launch_mode(cgd_ctx* ctx, const GemmParams& p, int tile, hipStream_t s) {
+  switch (tile) {
+    case 64: launch_cfg<MODE, 64, 64, 32, 32, 1>(p, s); break;
+    case 1064: launch_cfg<MODE, 64, 64, 32, 32, 2>(p, s); break;
+    case 128: launch_cfg<MODE, 128, 128, 64, 64, 1>(p, s); break;
+    case 1128: launch_cfg<MODE, 128, 128, 64, 64, 2>(p, s); break;
+    case 256: launch_cfg<MODE, 256, 128, 64, 64, 1>(p, s); break;
+    case 1256: launch_cfg<MODE, 256, 128, 64, 64, 2>(p, s); break;
+    case 257: launch_cfg<MODE, 128, 256, 64, 128, 1>(p, s); break;
+    default: CGD_FAIL(ctx, "cgd_launch_gemm: unknown tile code " + std::to_string(tile));
   }
-  __syncthreads();
-  const int cq = Cout >> 2;             // float4 columns per pixel
-  const int ppi = blockDim.x / cq;      // pixels per iteration
-  const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
-  if (pl >= ppi) return;
-  const long npix = (long)Bn * H * W;
-  const long pbase = (long)blockIdx.x * pix_per_block;
-  float4 bv = bias ? *(const float4*)(bias + q * 4) : make_float4(0, 0, 0, 0);
-  for (int it = pl; it < pix_per_block; it += ppi) {
-    const long pix = pbase + it;
-    if (pix >= npix) break;
-    const int b = (int)(pix / ((long)H * W));
-    const int rem = (int)(pix - (long)b * H * W);
-    const int yy = rem / W, xx = rem - yy * W;
-    float4 acc = bv;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int sy = yy + ky - 1;
-      if ((unsigned)sy >= (unsigned)H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int sx = xx + kx - 1;
-        if ((unsigned)sx >= (unsigned)W) continue;
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-          const float v = x[(((long)b * CIN + ci) * H + sy) * W + sx];
-          const float4 wv = *(const float4*)&wsm[((ky * 3 + kx) * CIN + ci) * Cout + q * 4];
-          acc.x += v * wv.x;
-          acc.y += v * wv.y;
-          acc.z += v * wv.z;
-          acc.w += v * wv.w;
-        }
-      }
-    }
-    *(float4*)(y + pix * Cout + q * 4) = acc;
-  }
-}
-
-// conv_thin_out: NHWC input (Cin multiple of 4, row stride ldx) -> NCHW output with COUT <= 8 channels,
-// weights [COUT][9*Cin].  One wavefront per output pixel, lanes split the input channels.
-template <int COUT>
-__global__ __launch_bounds__(256) void conv_thin_out_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, float* __restrict__ y, int Bn,
-                                                            int H, int W, int Cin, int pix_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [COUT][9*Cin]
-  const int KK = 9 * Cin;
-  for (int i = threadIdx.x; i < COUT * KK; i += blockDim.x) wsm[i] = w[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long npix = (long)Bn * H * W;
-  const long pbase = (long)blockIdx.x * pix_per_block;
-  for (int it = wave; it < pix_per_block; it += 4) {
-    const long pix = pbase + it;
-    if (pix >= npix) break;
-    const int b = (int)(pix / ((long)H * W));
-    const int rem = (int)(pix - (long)b * H * W);
-    const int yy = rem / W, xx = rem - yy * W;
-    float acc[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-    for (int tap = 0; tap < 9; ++tap) {
-      const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
-      if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
-      const float* xp = x + (((long)b * H + sy) * W + sx) * ldx;
-      for (int c = lane * 4; c < Cin; c += 256) {
-        const float4 v = *(const float4*)(xp + c);
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) {
-          const float4 wv = *(const float4*)&wsm[co * KK + tap * Cin + c];
-          acc[co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
-        }
-      }
-    }
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-      float v = acc[co];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      acc[co] = v;
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int co = 0; co < COUT; ++co) y[(((long)b * COUT + co) * H + yy) * W + xx] = acc[co] + (bias ? bias[co] : 0.f);
-    }
-  }
+  return 0;
 }
 
 }  // namespace
+
+static void tile_dims(int tile, int* bm, int* bn) {
+  switch (tile % 1000) {
+    case 64: *bm = 64; *bn = 64; break;
+    case 128: *bm = 128; *bn = 128; break;
+    case 256: *bm = 256; *bn = 128; break;
+    default: *bm = 128; *bn = 256; break;
+  }
+}
 
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return 0;
@@ -415,14 +348,27 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) CGD_FAIL(ctx, "cgd_launch_gemm: A/B must be 16-byte aligned");
   if (p.conv && (p.Cin % BK)) CGD_FAIL(ctx, "cgd_launch_gemm: conv Cin must be a multiple of 32");
   if (p.conv) p.K = 9 * p.Cin;
-  int tile = p.force_tile;
-  if (!tile) tile = (p.M > 64 && p.N > 64 && (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.nbatch >= ctx->num_cu) ? 128 : 64;
-  const long ntiles = (long)cdiv(p.M, tile) * cdiv(p.N, tile);
   const int nkt = cdiv(p.K, BK);
   if (p.splitk <= 0) p.splitk = 1;
-  if (p.splitk == 1 && p.nbatch == 1 && ntiles < ctx->num_cu) {
-    long want = (2L * ctx->num_cu) / ntiles;
-    if (want > nkt / 4) want = nkt / 4;
+  int tile = p.force_tile;
+  bool auto_split = p.splitk == 1 && p.nbatch == 1;
+  if (!tile) {
+    // largest tile that still fills the chip (>= 2 workgroups per CU), using split-K for the deficit
+    const long want_wg = 2L * ctx->num_cu;
+    const long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.nbatch;
+    const long sk128 = auto_split ? std::max<long>(1, std::min<long>(cdiv(want_wg, t128), nkt / 8)) : 1;
+    if (p.M > 64 && p.N > 64 && t128 * sk128 >= ctx->num_cu)
+      tile = ctx->tile_large;
+    else
+      tile = ctx->tile_small;
+  }
+  int bm, bn;
+  tile_dims(tile, &bm, &bn);
+  const long ntiles = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
+  if (auto_split && ntiles < 2L * ctx->num_cu) {
+    long want = cdiv(2L * ctx->num_cu, ntiles);
+    const int min_kt = bm >= 128 ? 8 : 4;
+    if (want > nkt / min_kt) want = nkt / min_kt;
     while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
     if (want >= 2) p.splitk = (int)want;
   }
@@ -448,9 +394,9 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     CGD_HIP(ctx, hipEventRecord(pr.a, s));
   }
   switch (ctx->precision) {
-    case CGD_PREC_F32: launch_mode<0>(p, tile, s); break;
-    case CGD_PREC_BF16X3: launch_mode<1>(p, tile, s); break;
-    default: launch_mode<2>(p, tile, s); break;
+    case CGD_PREC_F32: CGD_TRY(launch_mode<0>(ctx, p, tile, s)); break;
+    case CGD_PREC_BF16X3: CGD_TRY(launch_mode<1>(ctx, p, tile, s)); break;
+    default: CGD_TRY(launch_mode<2>(ctx, p, tile, s)); break;
   }
   if (p.splitk > 1) {
     const long total = (long)p.M * p.N;
@@ -462,40 +408,6 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     CGD_HIP(ctx, hipEventRecord(pr.b, s));
     ctx->prof_recs.push_back(pr);
   }
-  CGD_HIP(ctx, hipGetLastError());
-  return 0;
-}
-
-int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int Bn, int H, int W, int Cin,
-                       int Cout, hipStream_t s) {
-  if (Cout % 4 || Cout / 4 > 256) CGD_FAIL(ctx, "conv_in: Cout must be a multiple of 4 and <= 1024");
-  const int ppb = 64;
-  const long npix = (long)Bn * H * W;
-  const size_t sh = (size_t)9 * Cin * Cout * sizeof(float);
-  dim3 grid(cdiv(npix, ppb));
-  if (Cin == 3)
-    hipLaunchKernelGGL((conv_in_kernel<3>), grid, dim3(256), sh, s, x, w, bias, y, Bn, H, W, Cout, ppb);
-  else if (Cin == 6)
-    hipLaunchKernelGGL((conv_in_kernel<6>), grid, dim3(256), sh, s, x, w, bias, y, Bn, H, W, Cout, ppb);
-  else
-    CGD_FAIL(ctx, "conv_in: Cin must be 3 or 6");
-  CGD_HIP(ctx, hipGetLastError());
-  return 0;
-}
-
-int cgd_launch_conv_thin_out(cgd_ctx* ctx, const float* x, int ldx, const float* w, const float* bias, float* y, int Bn, int H,
-                             int W, int Cin, int Cout, hipStream_t s) {
-  const int ppb = 64;
-  const long npix = (long)Bn * H * W;
-  const size_t sh = (size_t)9 * Cin * Cout * sizeof(float);
-  if (sh > 160 * 1024) CGD_FAIL(ctx, "conv_thin_out: weights do not fit LDS");
-  dim3 grid(cdiv(npix, ppb));
-  if (Cout == 3)
-    hipLaunchKernelGGL((conv_thin_out_kernel<3>), grid, dim3(256), sh, s, x, ldx, w, bias, y, Bn, H, W, Cin, ppb);
-  else if (Cout == 6)
-    hipLaunchKernelGGL((conv_thin_out_kernel<6>), grid, dim3(256), sh, s, x, ldx, w, bias, y, Bn, H, W, Cin, ppb);
-  else
-    CGD_FAIL(ctx, "conv_thin_out: Cout must be 3 or 6");
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }

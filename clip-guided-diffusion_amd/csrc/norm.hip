@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __re
 
 // merge chunks -> stats[b][g] = (mean, rstd); one wavefront per (b, g)
 __global__ __launch_bounds__(64) void gn_stats_final_kernel(const float* __restrict__ part, int nchunk, int HW, int chunk, int cpg,
-                                                            float eps, float* __restrict__ stats /*[B][32][2]*/) {
+                                                            float eps, float* __restrict__ stats /*[B][32][2]*/,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ film /*[B][ldfilm] scale|shift or null*/,
+                                                            int ldfilm, float* __restrict__ coef) {
   const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
   double wsum = 0.0;
   for (int ck = lane; ck < nchunk; ck += 64) {
@@ -115,31 +118,27 @@ __global__ __launch_bounds__(64) void gn_stats_final_kernel(const float* __restr
     m2 += (double)pp[1] + (double)n * cpg * d * d;
   }
   for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+  const double var = m2 / ((double)HW * cpg);
+  const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
   if (lane == 0) {
-    const double var = m2 / ((double)HW * cpg);
-    stats[((long)b * 32 + g) * 2 + 0] = (float)mean;
-    stats[((long)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    stats[((long)b * 32 + g) * 2 + 0] = meanf;
+    stats[((long)b * 32 + g) * 2 + 1] = rstd;
   }
-}
-
-// fold (mean, rstd, gamma, beta, film) into per-channel y = x*a + b; coef[b][c] = {a, b, gcoef = gamma*(1+scale), mean}
-__global__ void gn_coef_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                               const float* __restrict__ film /*[B][ldfilm] scale|shift or null*/, int ldfilm, int C, float* __restrict__ coef) {
-  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int g = c / (C / 32);
-  const float mean = stats[((long)b * 32 + g) * 2], rstd = stats[((long)b * 32 + g) * 2 + 1];
-  float gm = gamma[c], bt = beta[c];
-  if (film) {
-    const float sc = 1.f + film[(long)b * ldfilm + c], sh = film[(long)b * ldfilm + C + c];
-    gm *= sc;
-    bt = bt * sc + sh;
+  // fold (mean, rstd, gamma, beta, film) into per-channel y = x*a + b; coef[b][c] = {a, b, gcoef = gamma*(1+scale), mean}
+  const int C = cpg * 32;
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    float gm = gamma[c], bt = beta[c];
+    if (film) {
+      const float sc = 1.f + film[(long)b * ldfilm + c], sh = film[(long)b * ldfilm + C + c];
+      gm *= sc;
+      bt = bt * sc + sh;
+    }
+    float* o = coef + ((long)b * C + c) * 4;
+    o[0] = gm * rstd;
+    o[1] = bt - meanf * gm * rstd;
+    o[2] = gm;
+    o[3] = meanf;
   }
-  float* o = coef + ((long)b * C + c) * 4;
-  o[0] = gm * rstd;
-  o[1] = bt - mean * gm * rstd;
-  o[2] = gm;
-  o[3] = mean;
 }
 
 // y = act(x*a + b)
@@ -246,22 +245,29 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
 // dx = du*A1 - (x-mean)*A2 - A3
 __global__ void gn_bwd_coef_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ stats,
                                    const float* __restrict__ coef, int C, int HW, float* __restrict__ bcoef) {
-  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int cpg = C / 32, g = c / cpg;
+  // one wavefront per (b, group): reduce the chunk partials, then write the group's channels
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  const int cpg = C / 32;
   double p1 = 0.0, p2 = 0.0;
-  for (int ck = 0; ck < nchunk; ++ck) {
+  for (int ck = lane; ck < nchunk; ck += 64) {
     const float* pp = part + (((long)b * nchunk + ck) * 32 + g) * 2;
     p1 += pp[0];
     p2 += pp[1];
   }
+  for (int o = 32; o > 0; o >>= 1) {
+    p1 += __shfl_xor(p1, o, 64);
+    p2 += __shfl_xor(p2, o, 64);
+  }
   const double N = (double)HW * cpg;
   const float rstd = stats[((long)b * 32 + g) * 2 + 1];
-  float* o = bcoef + ((long)b * C + c) * 4;
-  o[0] = rstd * coef[((long)b * C + c) * 4 + 2];
-  o[1] = (float)((double)rstd * rstd * rstd * p2 / N);
-  o[2] = (float)((double)rstd * p1 / N);
-  o[3] = 0.f;
+  const float a2 = (float)((double)rstd * rstd * rstd * p2 / N), a3 = (float)((double)rstd * p1 / N);
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    float* o = bcoef + ((long)b * C + c) * 4;
+    o[0] = rstd * coef[((long)b * C + c) * 4 + 2];
+    o[1] = a2;
+    o[2] = a3;
+    o[3] = 0.f;
+  }
 }
 
 template <int ACT>
@@ -401,8 +407,8 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ldx, HW, C, chunk, part);
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(64), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats);
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, stats, gamma, beta, film, ldfilm, C, coef);
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(64), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats, gamma, beta, film,
+                     ldfilm, coef);
   if (act)
     hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
   else
@@ -421,7 +427,7 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
   } else {
     hipLaunchKernelGGL((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, HW, C, chunk, coef, part);
   }
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(32, B), dim3(64), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
   if (act) {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C,
                        chunk, coef, bcoef);

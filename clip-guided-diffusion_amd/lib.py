@@ -44,6 +44,7 @@ _SIGS = {
     "cgd_last_error": (C.c_char_p, [vp]),
     "cgd_set_precision": (i32, [vp, i32]),
     "cgd_get_precision": (i32, [vp]),
+    "cgd_set_tiles": (i32, [vp, i32, i32]),
     "cgd_profile": (i32, [vp, i32]),
     "cgd_profile_read": (i32, [vp, C.POINTER(C.c_double)]),
     "cgd_unet_create": (i32, [vp, C.POINTER(UNetConfig), C.POINTER(vp)]),

@@ -38,6 +38,8 @@ int cgd_get_precision(cgd_ctx* ctx);
 const char* cgd_version(void);
 /* HIP-event timing of every MFMA GEMM/conv launch on its own stream (measurement only; bench.py roofline leg).
  * cgd_profile_read: out[0] = summed kernel time (ms), out[1] = summed algorithmic FLOP, out[2] = launches; resets. */
+/* tuning knob: GEMM tile codes for the automatic selection (64, 128, 256 = 256x128, 257 = 128x256; +1000 = 2-deep prefetch) */
+int cgd_set_tiles(cgd_ctx* ctx, int large_tile, int small_tile);
 int cgd_profile(cgd_ctx* ctx, int enable);
 int cgd_profile_read(cgd_ctx* ctx, double* out3);
 

@@ -1,0 +1,71 @@
+"""Micro-benchmark of the MFMA implicit-GEMM conv kernel on the UNet's layer shapes, per tile variant.
+Usage: python tests/bench_ops.py [tag] [precision]   -> gpurun_out/ops_<tag>.json + table on stdout."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch as th  # noqa: E402
+
+import cgd_amd  # noqa: E402,F401
+from cgd_amd import lib, ops  # noqa: E402
+
+SHAPES = [  # (H=W, Cin, Cout, launches per step in config 2 (fwd+dgrad, approximate))
+    (256, 256, 256, 18), (256, 512, 256, 3), (256, 256, 512, 3),
+    (128, 256, 256, 22), (128, 512, 256, 3), (128, 256, 512, 3),
+    (64, 256, 512, 2), (64, 512, 512, 14), (64, 1024, 512, 3), (64, 512, 1024, 3), (64, 768, 512, 1),
+    (32, 512, 512, 14), (32, 1024, 512, 4), (32, 512, 1024, 4),
+    (16, 512, 1024, 2), (16, 1024, 1024, 14), (16, 2048, 1024, 3), (16, 1024, 2048, 3), (16, 1536, 1024, 1),
+    (8, 1024, 1024, 18), (8, 2048, 1024, 3), (8, 1024, 2048, 3),
+]
+TILES = [64, 1064, 128, 1128, 256, 1256, 257]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "run"
+    prec = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ctx = lib.Context(0, prec)
+    os.makedirs("gpurun_out", exist_ok=True)
+    res = []
+    print(f"{'shape':<22s}" + "".join(f"{t:>14d}" for t in TILES) + "   (us | TFLOP/s algorithmic)")
+    for (H, ci, co, cnt) in SHAPES:
+        x = th.randn(1, H, H, ci, device="cuda")
+        w = (th.randn(co, 9 * ci, device="cuda") * 0.02).contiguous()
+        b = th.randn(co, device="cuda")
+        flop = 2.0 * H * H * co * 9 * ci
+        row = {"H": H, "cin": ci, "cout": co, "count": cnt, "flop": flop, "us": {}}
+        line = f"{H:>3d}^2 {ci:>4d}->{co:<4d} x{cnt:<3d}"
+        for t in TILES:
+            if (t % 1000) >= 128 and (H * H < 128 or co < 128):
+                line += f"{'-':>14s}"
+                continue
+            try:
+                for _ in range(3):
+                    ops.conv3x3(ctx, x, w, b, force_tile=t)
+                th.cuda.synchronize()
+                e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+                n = 10
+                e0.record()
+                for _ in range(n):
+                    ops.conv3x3(ctx, x, w, b, force_tile=t)
+                e1.record()
+                th.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / n
+                row["us"][str(t)] = us
+                line += f"{us:>8.1f}|{flop / us / 1e6:>5.0f}"
+            except Exception as e:  # noqa: BLE001
+                row["us"][str(t)] = None
+                line += f"{'ERR':>14s}"
+                print("   ", type(e).__name__, str(e)[:150])
+        print(line, flush=True)
+        res.append(row)
+    with open(f"gpurun_out/ops_{tag}.json", "w") as f:
+        json.dump(res, f, indent=1)
+    # best-per-shape projection
+    tot_best = sum(min(v for v in r["us"].values() if v) * r["count"] for r in res)
+    tot_cur = sum((r["us"].get("128") or r["us"].get("64")) * r["count"] for r in res)
+    print(f"projected conv time/step: default-ish {tot_cur / 1e3:.2f} ms, best-per-shape {tot_best / 1e3:.2f} ms")
+
+
+if __name__ == "__main__":
+    main()
