@@ -52,7 +52,8 @@ int cgd_set_precision(cgd_ctx* ctx, int mode) {
 int cgd_get_precision(cgd_ctx* ctx) { return ctx->precision; }
 
 int cgd_set_tiles(cgd_ctx* ctx, int large, int small) {
-  ctx->tile_large = large;
+  ctx->tile_huge = large >= 1000000 ? large / 1000000 : ctx->tile_huge;  // optional: huge*1e6 + large
+  ctx->tile_large = large % 1000000;
   ctx->tile_small = small;
   return 0;
 }

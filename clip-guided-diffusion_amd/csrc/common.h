@@ -25,7 +25,7 @@ struct cgd_ctx {
   float* ws = nullptr;       // split-K partial slabs
   size_t ws_bytes = 0;
   int num_cu = 256;
-  int tile_large = 128, tile_small = 64;  // GEMM tile codes used by the automatic selection (see gemm.hip)
+  int tile_huge = 1256, tile_large = 128, tile_small = 64;  // GEMM tile codes of the automatic selection (gemm.hip)
   // optional HIP-event timing of every MFMA GEMM/conv launch (bench.py roofline leg)
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;

@@ -297,6 +297,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             float* __restrict__ C, int ldc, const float* __restrict__ bias,
                                                             const float* __restrict__ R, int ldr, float alpha) {
   const long total = (long)M * N;
+  if (!(N & 3) && !(ldc & 3) && !(ldr & 3) && !((uintptr_t)C & 15) && !((uintptr_t)R & 15) && !((uintptr_t)bias & 15)) {
+    const long tq = total >> 2;
+    const int nq = N >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tq; i += (long)gridDim.x * blockDim.x) {
+      const int m = (int)(i / nq), n = (int)(i - (long)m * nq) * 4;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < splitk; ++k) {
+        const float4 v = *(const float4*)(ws + (long)k * total + i * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float4 o = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+      if (bias) {
+        const float4 bv = *(const float4*)(bias + n);
+        o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+      }
+      if (R) {
+        const float4 rv = *(const float4*)(R + (long)m * ldr + n);
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      }
+      *(float4*)(C + (long)m * ldc + n) = o;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int m = (int)(i / N), n = (int)(i - (long)m * N);
     float s = 0.f;
@@ -357,7 +380,10 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     const long want_wg = 2L * ctx->num_cu;
     const long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.nbatch;
     const long sk128 = auto_split ? std::max<long>(1, std::min<long>(cdiv(want_wg, t128), nkt / 8)) : 1;
-    if (p.M > 64 && p.N > 64 && t128 * sk128 >= ctx->num_cu)
+    const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.nbatch;
+    if (p.N > 64 && t256 >= ctx->num_cu)
+      tile = ctx->tile_huge;  // 256x128, 8 wavefronts, 2-deep prefetch: best on the >= 128^2-pixel convs (ops_r1c)
+    else if (p.M > 64 && p.N > 64 && t128 * sk128 >= ctx->num_cu)
       tile = ctx->tile_large;
     else
       tile = ctx->tile_small;
