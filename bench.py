@@ -31,20 +31,16 @@ FLOP_PER_STEP = 4.775e12  # UNet 2*(1119.8+1125.9) GMAC + CLIP 1
 def build_device(ctx, rank, world, precision, clip_name="ViT-B/32"):
     from cgd_amd import diffusion as dd
     from cgd_amd import guidance as dg
-    from cgd_amd import nets, sampler, synthetic
+    from cgd_amd import nets, sampler, shard, synthetic
     dev = f"cuda:{ctx.device}"
     unet = nets.UNet(ctx, **UNET_256)
     clip = nets.ClipImageTower(ctx, clip_name)
     for net, seed in ((unet, 1234), (clip, 4321)):
         specs = net.param_specs()
-        total = sum(n for _, n in specs)
-        if rank == 0:
-            sd = synthetic.synthetic_state_dict(net, seed=seed, device=dev)
-            flat = synthetic.flat_pack(sd, [n for n, _ in specs])
-        else:
-            flat = th.empty(total, device=dev)
-        if world > 1:
-            dist.broadcast(flat, src=0)  # the single collective of the whole job: weights over xGMI (RCCL)
+        names = [n for n, _ in specs]
+        # the single collective of the whole job: rank 0 materialises the weights, one RCCL broadcast over xGMI
+        flat = shard.broadcast_flat(lambda: synthetic.flat_pack(synthetic.synthetic_state_dict(net, seed=seed, device=dev), names),
+                                    sum(n for _, n in specs), dev)
         net.load_state_dict(synthetic.flat_unpack(flat, specs))
         del flat
     tables = dd.create_gaussian_diffusion(1000, "linear", "250", False)
@@ -53,21 +49,6 @@ def build_device(ctx, rank, world, precision, clip_name="ViT-B/32"):
     targets = th.randn(1, clip.out_dim, generator=gt).to(dev)
     guid = dg.ClipGuidance(ctx, unet, clip, smp, targets, [1.0], 16, clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0)
     return unet, clip, smp, guid
-
-
-def run_steps(smp, guid, unet, nsteps, dev, seed):
-    th.manual_seed(seed)
-    y0 = th.zeros(1, dtype=th.long, device=dev)
-    gen = smp.p_sample_loop_progressive(unet, (1, 3, 256, 256), clip_denoised=False, model_kwargs={"y": y0}, cond_fn=guid, device=dev,
-                                        progress=False, skip_timesteps=0, randomize_class=True, cond_fn_with_grad=True)
-    guid.current_timestep = smp.num_timesteps - 1
-    last = None
-    for k, out in enumerate(gen):
-        guid.current_timestep -= 1
-        last = out
-        if k + 1 >= nsteps:
-            break
-    return last
 
 
 def cpu_baseline(steps=2, warmup=1):

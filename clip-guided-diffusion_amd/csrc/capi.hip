@@ -66,21 +66,34 @@ int cgd_profile(cgd_ctx* ctx, int enable) {
 // out[0] = summed MFMA GEMM/conv time (ms), out[1] = summed algorithmic FLOP, out[2] = launches; resets the records
 int cgd_profile_read(cgd_ctx* ctx, double* out) {
   CGD_HIP(ctx, hipDeviceSynchronize());
-  double ms = 0.0, fl = 0.0;
-  for (ProfRec& r : ctx->prof_recs) {
+  CGD_TRY(cgd_prof_fold(ctx, 0));
+  out[0] = ctx->prof_ms;
+  out[1] = ctx->prof_flops;
+  out[2] = ctx->prof_n;
+  ctx->prof_ms = ctx->prof_flops = ctx->prof_n = 0.0;
+  return 0;
+}
+}  // extern "C"
+
+int cgd_prof_fold(cgd_ctx* ctx, size_t keep_last) {
+  if (ctx->prof_recs.size() <= keep_last) return 0;
+  const size_t n = ctx->prof_recs.size() - keep_last;
+  for (size_t i = 0; i < n; ++i) {
+    ProfRec& r = ctx->prof_recs[i];
     float t = 0.f;
+    CGD_HIP(ctx, hipEventSynchronize(r.b));  // long retired for everything but the newest records
     CGD_HIP(ctx, hipEventElapsedTime(&t, r.a, r.b));
-    ms += t;
-    fl += r.flops;
+    ctx->prof_ms += t;
+    ctx->prof_flops += r.flops;
+    ctx->prof_n += 1.0;
     ctx->prof_pool.push_back(r.a);
     ctx->prof_pool.push_back(r.b);
   }
-  out[0] = ms;
-  out[1] = fl;
-  out[2] = (double)ctx->prof_recs.size();
-  ctx->prof_recs.clear();
+  ctx->prof_recs.erase(ctx->prof_recs.begin(), ctx->prof_recs.begin() + n);
   return 0;
 }
+
+extern "C" {
 
 int cgd_cutouts_fwd(cgd_ctx* ctx, const float* x_in, const int32_t* coords, float* out, int B, int H, int W, int cutn, int cut_size,
                     int layout, int patch, void* stream) {

@@ -30,7 +30,11 @@ struct cgd_ctx {
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
+  double prof_ms = 0.0, prof_flops = 0.0, prof_n = 0.0;  // folded totals of already-retired records
 };
+
+// fold the oldest records (all but `keep_last`) into the running totals and recycle their events
+int cgd_prof_fold(cgd_ctx* ctx, size_t keep_last);
 
 #define CGD_HIP(ctx, expr)                                                                   \
   do {                                                                                       \

@@ -405,6 +405,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   }
   ProfRec pr;
   if (ctx->prof_on) {
+    // bound the number of live events: retire all but the newest 1024 records (they completed long ago)
+    if (ctx->prof_recs.size() >= 3072) CGD_TRY(cgd_prof_fold(ctx, 1024));
     auto get = [&](hipEvent_t* e) -> int {
       if (!ctx->prof_pool.empty()) {
         *e = ctx->prof_pool.back();

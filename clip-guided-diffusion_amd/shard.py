@@ -1,0 +1,54 @@
+"""Sample-parallel sharding: independent samples, one per GPU, no per-step collective.
+
+Shared across ranks: packed weights (ONE broadcast over RCCL/xGMI at start-up), prompt embeddings, cutout coordinates
+(the reference uses the same crop boxes for every batch element, /root/reference/cgd/modules.py:60-61), class-randomisation
+draws and schedule tables.  Per rank: slice `b` of x_T and of each step's noise (the reference draws one (B,3,H,W) tensor;
+rank b takes [b]).  Works with any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+"""
+import torch as th
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def broadcast_flat(make_flat, numel, device, src=0, dtype=th.float32):
+    """Rank `src` materialises the flat parameter vector (make_flat()); everyone else receives it in one broadcast."""
+    rank, n = world()
+    flat = make_flat().to(device=device, dtype=dtype).contiguous() if rank == src else th.empty(numel, device=device, dtype=dtype)
+    if flat.numel() != numel:
+        raise ValueError(f"flat parameter vector has {flat.numel()} elements, expected {numel}")
+    if n > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+def rank_samples(global_batch, rank=None, nranks=None):
+    """Indices of the global batch owned by a rank (contiguous blocks; 1 sample per GPU when global_batch == world)."""
+    r, n = world()
+    rank = r if rank is None else rank
+    nranks = n if nranks is None else nranks
+    per, extra = divmod(global_batch, nranks)
+    start = rank * per + min(rank, extra)
+    return list(range(start, start + per + (1 if rank < extra else 0)))
+
+
+def slice_tape(tape, idx):
+    """Per-rank view of a global RNG tape {'x_T': (B,..), 'noise': [(B,..)], 'y': [(B,)], 'coords': [...]}."""
+    out = {"x_T": tape["x_T"][idx], "noise": [n[idx] for n in tape["noise"]], "y": [y[idx] for y in tape["y"]]}
+    if "coords" in tape:
+        out["coords"] = tape["coords"]  # shared: same crop boxes for every sample
+    return out
+
+
+def gather_images(img, dst=0):
+    """Optional end-of-run gather of the finished (b,3,H,W) images to rank `dst` (each rank may also write its own PNGs)."""
+    rank, n = world()
+    if n == 1:
+        return [img]
+    bufs = [th.empty_like(img) for _ in range(n)] if rank == dst else None
+    dist.gather(img, bufs, dst=dst)
+    return bufs

@@ -1,0 +1,107 @@
+"""CPU tests of the host side: schedule tables vs the oracle, the drop-in surface (CLI flags, generator signature,
+prompt parsing, log naming) vs golden data extracted from the real reference, prompt broadcast rules."""
+import inspect
+import json
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+import cgd_amd  # noqa: F401
+from cgd_amd import diffusion as dd
+from cgd_amd import guidance as dg
+from oracle import diffusion as od
+
+HOST = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_host.json")))
+TABLES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+          "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+          "posterior_mean_coef1", "posterior_mean_coef2"]
+
+
+@pytest.mark.parametrize("sched,spec", [("linear", "250"), ("cosine", "25"), ("linear", "ddim250"), ("linear", "ddim25"), ("linear", "1000"),
+                                        ("linear", "500"), ("linear", "10,15,20"), ("cosine", "ddim50")])
+def test_tables_bit_equal_to_oracle(sched, spec):
+    a, b = dd.create_gaussian_diffusion(1000, sched, spec), od.create_gaussian_diffusion(1000, sched, spec)
+    assert a.timestep_map == b.timestep_map and a.num_timesteps == b.num_timesteps
+    for n in TABLES:
+        assert np.array_equal(getattr(a, n), getattr(b, n)), n
+
+
+def test_step_coef_and_rescale():
+    d = dd.create_gaussian_diffusion(1000, "linear", "250", rescale_timesteps=False)
+    k = d.step_coef(249, fac_index=249)
+    assert abs(k.fac - 0.99998) < 1e-5 and k.nonzero == 1 and d.step_coef(0).nonzero == 0
+    assert d.model_timestep(249) == 999.0 and d.model_timestep(1) == 4.0
+    r = dd.create_gaussian_diffusion(1000, "linear", "500", rescale_timesteps=True)
+    assert r.model_timestep(499) == 999.0  # 1000/original_num_steps == 1
+    with pytest.raises(ValueError):
+        dd.space_timesteps(1000, "ddim333")
+
+
+def test_parse_prompt_and_log_path_golden():
+    from cgd import script_util
+    for prompt, (text, weight) in HOST["parse_prompt"]:
+        assert script_util.parse_prompt(prompt) == (text, weight)
+    assert script_util.clean_and_combine_prompts("base", ["a", "b", "c"], 4) == HOST["log_path"]
+    assert script_util.clean_and_combine_prompts("out", ["A photo, of: things!", "x y"], 12) == HOST["log_path2"]
+
+
+def test_log_image_writes_expected_path(tmp_path, monkeypatch):
+    from cgd import script_util
+    monkeypatch.chdir(tmp_path)
+    out = script_util.log_image(th.rand(3, 3, 3), str(tmp_path), ["a", "b", "c"], 1, 4)  # reference test.py:106-119
+    assert out == os.path.join(str(tmp_path), "a_b_c/04/0001.png") and os.path.isfile(out) and os.path.isfile(tmp_path / "current.png")
+
+
+def test_cli_flags_match_reference():
+    from cgd import cgd as mine
+    acts = {a.dest: a for a in mine.build_parser()._actions if a.option_strings and a.dest != "help"}
+    ref = {f["dest"]: f for f in HOST["cli_flags"]}
+    assert set(acts) == set(ref)
+    for dest, f in ref.items():
+        a = acts[dest]
+        assert a.option_strings == f["opts"], dest
+        assert (a.nargs == 0) == f["nargs0"], dest
+        assert (str(a.default) if a.default is not None else None) == f["default"], dest
+        assert getattr(a.type, "__name__", None) == f["type"], dest
+
+
+def test_generator_signature_matches_reference():
+    from cgd import cgd as mine
+    sig = inspect.signature(mine.clip_guided_diffusion)
+    assert [[k, repr(p.default)] for k, p in sig.parameters.items()] == HOST["generator_signature"]
+    assert inspect.isgeneratorfunction(mine.clip_guided_diffusion)
+
+
+def test_cli_kwargs_quirks():
+    from cgd import cgd as mine
+    args = mine.build_parser().parse_args(["-txts", "a cat:2|a dog:-1", "-size", "256", "-respace", "250", "-cutn", "16", "--use_augs", "-mag", "-uncond"])
+    kw = mine.kwargs_from_args(args)
+    assert kw["prompts"] == ["a cat:2", "a dog:-1"] and kw["image_prompts"] == []
+    assert kw["use_augs"] is False and kw["use_magnitude"] is False  # parsed but ignored, as in the reference (cgd.py:402-403)
+    assert kw["class_cond"] is False and kw["randomize_class"] is False
+    assert set(kw) <= set(inspect.signature(mine.clip_guided_diffusion).parameters)
+
+
+def test_prompt_weight_broadcast_rules():
+    w = th.tensor([1.0, 0.5, -0.3]) / 1.2
+    m = dg.prompt_weight_matrix(w, 1, "cpu")
+    assert m.shape == (1, 3) and th.allclose(m[0], w)
+    assert th.allclose(dg.prompt_weight_matrix(th.tensor([2.0]), 3, "cpu"), th.full((3, 1), 2.0))
+    m = dg.prompt_weight_matrix(w, 3, "cpu")  # B == P > 1: sample b vs prompt b only, scaled by sum(w)
+    assert th.allclose(m, th.eye(3) * w.sum())
+    with pytest.raises(RuntimeError):
+        dg.prompt_weight_matrix(w, 2, "cpu")
+
+
+def test_crop_geometry_truncation():
+    assert dg.crop_geometry([(10, 5, 250), (0, 31, 256)], 256, 288) == [(5, 10, 250, 250), (31, 0, 225, 256)]
+
+
+def test_model_config_overrides():
+    from cgd import script_util
+    cfg = script_util.model_config(64, True, 1000, "25", True, "linear", 0.0)
+    # user-level noise_schedule/dropout override the per-checkpoint flags
+    assert cfg["noise_schedule"] == "linear" and cfg["dropout"] == 0.0 and cfg["num_channels"] == 192 and cfg["use_new_attention_order"]
+    assert script_util.model_config(512, False, 1000, "1000")["rescale_timesteps"] is True
