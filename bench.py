@@ -51,13 +51,41 @@ def build_device(ctx, rank, world, precision, clip_name="ViT-B/32"):
     return unet, clip, smp, guid
 
 
+def usable_cores(cap=64):
+    """Cores this process may really use: affinity mask and cgroup quota, not os.cpu_count() (a container that sees 256
+    logical CPUs but owns 8 would oversubscribe the OpenMP pool by 32x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline_subprocess(timeout_s=300):
+    """Runs cpu_baseline() in a child with a hard time limit so that a slow host can never stall the GPU number."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True,
+                             timeout=timeout_s)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": "no result", "stderr": out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"CPU oracle did not finish 1+2 steps within {timeout_s} s on {usable_cores()} cores", "kind": "port",
+                "cores": usable_cores()}
+
+
 def cpu_baseline(steps=2, warmup=1):
     """CPU oracle = plain-PyTorch fp32 restatement of the reference's --device cpu path, same workload."""
     from oracle import clip_vit as ocv
     from oracle import diffusion as od
     from oracle import guidance as og
     from oracle import unet as ou
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     th.set_num_threads(cores)
     unet = ou.synthetic_init_(ou.UNetModel(**UNET_256)).eval()
     clip = ocv.synthetic_init_(ocv.ClipImageModel("ViT-B/32")).eval().float()
@@ -94,7 +122,11 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,7 +223,7 @@ def main():
             res["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline()
+                res["cpu_baseline"] = cpu_baseline_subprocess()
             except Exception as e:  # never lose the GPU number to a host-side problem
                 res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res), flush=True)

@@ -139,9 +139,18 @@ int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, 
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.force_tile = force_tile; p.splitk = splitk;
   return cgd_launch_gemm(ctx, p, S(stream));
 }
-int cgd_op_conv3x3(cgd_ctx* ctx, const float* x, int ldx, const float* w, float* y, int ldy, const float* bias, const float* R, int ldr,
-                   int Bn, int H, int W, int Cin, int Cout, int ups, int force_tile, int splitk, void* stream) {
+int cgd_op_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, void* stream) {
+  return cgd_pack_conv3x3_frag(ctx, w, out, Co, Ci, dgrad, S(stream));
+}
+int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m) {
+  ctx->hconv_mode = mode;
+  ctx->hconv_min_m = min_m;
+  return 0;
+}
+int cgd_op_conv3x3(cgd_ctx* ctx, const float* x, int ldx, const float* w, const float* w_frag, float* y, int ldy, const float* bias,
+                   const float* R, int ldr, int Bn, int H, int W, int Cin, int Cout, int ups, int force_tile, int splitk, void* stream) {
   GemmParams p;
+  p.Bpk = w_frag;
   p.A = x; p.lda = ldx; p.B = w; p.ldb = 9 * Cin; p.C = y; p.ldc = ldy; p.bias = bias; p.R = R; p.ldr = ldr;
   p.M = Bn * H * W; p.N = Cout; p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.ups = ups; p.force_tile = force_tile; p.splitk = splitk;
   return cgd_launch_gemm(ctx, p, S(stream));

@@ -26,6 +26,7 @@ struct cgd_ctx {
   size_t ws_bytes = 0;
   int num_cu = 256;
   int tile_huge = 1256, tile_large = 128, tile_small = 64;  // GEMM tile codes of the automatic selection (gemm.hip)
+  int hconv_mode = 1, hconv_min_m = 4096;                    // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m
   // optional HIP-event timing of every MFMA GEMM/conv launch (bench.py roofline leg)
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
@@ -79,8 +80,15 @@ struct GemmParams {
   int conv = 0, H = 0, W = 0, Cin = 0, ups = 0;
   int splitk = 1;
   float* ws = nullptr;
-  int force_tile = 0;  // 0 auto, 64, 128
+  int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel
+  const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
 };
+
+// ---- halo-staged conv (hconv.hip) ---------------------------------------------------------------------
+size_t cgd_hconv_packed_floats(int Co, int Ci);
+int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w /*[Co][Ci][3][3]*/, float* out, int Co, int Ci, int dgrad, hipStream_t s);
+bool cgd_hconv_supported(const GemmParams& p, int precision);
+int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s);
 

@@ -375,6 +375,21 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (p.splitk <= 0) p.splitk = 1;
   int tile = p.force_tile;
   bool auto_split = p.splitk == 1 && p.nbatch == 1;
+  // halo-staged conv kernel (hconv.hip): tile code 512
+  bool use_h = false;
+  if (cgd_hconv_supported(p, ctx->precision)) use_h = tile == 512 || (!tile && ctx->hconv_mode && p.M >= ctx->hconv_min_m);
+  if (tile == 512 && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel does not support this problem");
+  if (use_h) {
+    tile = 512;
+    const long tiles = (long)(p.M / 256) * cdiv(p.N, 128);
+    const int nchunk = p.Cin / 32;
+    if (auto_split && tiles < ctx->num_cu) {
+      long want = std::min<long>(cdiv(ctx->num_cu, tiles), nchunk / 2);
+      while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
+      if (want >= 2) p.splitk = (int)want;
+    }
+    auto_split = false;
+  }
   if (!tile) {
     // largest tile that still fills the chip (>= 2 workgroups per CU), using split-K for the deficit
     const long want_wg = 2L * ctx->num_cu;
@@ -388,8 +403,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     else
       tile = ctx->tile_small;
   }
-  int bm, bn;
-  tile_dims(tile, &bm, &bn);
+  int bm = 256, bn = 128;
+  if (!use_h) tile_dims(tile, &bm, &bn);
   const long ntiles = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
   if (auto_split && ntiles < 2L * ctx->num_cu) {
     long want = cdiv(2L * ctx->num_cu, ntiles);
@@ -421,10 +436,14 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     pr.flops = 2.0 * p.M * p.N * p.K * p.nbatch;
     CGD_HIP(ctx, hipEventRecord(pr.a, s));
   }
-  switch (ctx->precision) {
-    case CGD_PREC_F32: CGD_TRY(launch_mode<0>(ctx, p, tile, s)); break;
-    case CGD_PREC_BF16X3: CGD_TRY(launch_mode<1>(ctx, p, tile, s)); break;
-    default: CGD_TRY(launch_mode<2>(ctx, p, tile, s)); break;
+  if (use_h) {
+    CGD_TRY(cgd_launch_hconv(ctx, p, s));
+  } else {
+    switch (ctx->precision) {
+      case CGD_PREC_F32: CGD_TRY(launch_mode<0>(ctx, p, tile, s)); break;
+      case CGD_PREC_BF16X3: CGD_TRY(launch_mode<1>(ctx, p, tile, s)); break;
+      default: CGD_TRY(launch_mode<2>(ctx, p, tile, s)); break;
+    }
   }
   if (p.splitk > 1) {
     const long total = (long)p.M * p.N;

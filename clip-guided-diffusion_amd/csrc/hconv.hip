@@ -1,0 +1,305 @@
+// Halo-staged 3x3 convolution (implicit GEMM, bf16x3 / bf16 MFMA) for gfx950 — the UNet's dominant kernel.
+//
+// Differences to the generic igemm kernel (gemm.hip), both aimed at its measured bottleneck (staging traffic and
+// one barrier per 32-deep K tile, profiles/prof_r1d):
+//   * A operand: a workgroup owns 256 consecutive pixels (one 256-wide row segment, or 256/W full rows).  For each
+//     32-channel chunk the (rows+2) x (W+2) halo patch is loaded, split into bf16 hi/lo and written to LDS ONCE, then
+//     reused by all 9 taps: a tap is just a constant row offset into the patch (zero rows implement the padding).
+//     Staging work per MFMA drops ~6x, and the patch is read-only for 9 K tiles.
+//   * B operand (weights): pre-packed at load time in MFMA B-fragment order, bf16 hi/lo planes,
+//     [N/32][Cin/32][tap][kstep][plane][lane][8]: every wavefront fetches its fragments with fully coalesced 1 KiB
+//     loads straight from L2 into registers — no LDS round trip, no conversion, no weight-related barrier.
+//   => one barrier pair per chunk (9 K tiles) instead of one per K tile; wavefronts drift apart inside a chunk so
+//      MFMA, LDS reads and global loads of different wavefronts overlap.
+// 8 wavefronts (4 x 2), each 64 x 64 of the 256 x 128 output tile; 123,840 B LDS (1 workgroup / CU).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int HB_M = 256, HB_N = 128, HPH = 40;  // tile, LDS row pitch (bf16 elements)
+constexpr int MAX_NP = 774;                      // 3 x 258 patch rows (W >= 256)
+constexpr int NPASS = 13;                        // ceil(774 / 64) staging passes of 64 rows
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
+  bf16x4 r;
+  r[0] = (__bf16)v.x;
+  r[1] = (__bf16)v.y;
+  r[2] = (__bf16)v.z;
+  r[3] = (__bf16)v.w;
+  return r;
+}
+__device__ __forceinline__ float4 residual4(const float4 v, const bf16x4 hi) {
+  return make_float4(v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]);
+}
+
+struct HConvParams {
+  const float* A;
+  const uint4* Bp;  // packed fragments (16 B = 8 bf16 per lane)
+  float* C;
+  const float* bias;
+  const float* R;
+  float* ws;
+  int lda, ldc, ldr;
+  int M, N, H, W, Cin, ups, splitk;
+  float alpha;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void hconv_kernel(const HConvParams p) {
+  __shared__ __attribute__((aligned(16))) __bf16 ph[MAX_NP][HPH];
+  __shared__ __attribute__((aligned(16))) __bf16 pl[MODE == 1 ? MAX_NP : 1][HPH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int ntn = (p.N + HB_N - 1) / HB_N;
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / ntn) * HB_M, n0 = (bid % ntn) * HB_N;
+
+  // ---- tile geometry ---------------------------------------------------------------------------------
+  const int HW = p.H * p.W;
+  const int img = m0 / HW, rem = m0 - img * HW;
+  const int y0 = rem / p.W, x0 = rem - y0 * p.W;
+  const bool wide = p.W >= HB_M;
+  const int TW = wide ? HB_M : p.W;     // pixels per tile row
+  const int TR = wide ? 1 : HB_M / p.W; // tile rows
+  const int PW = TW + 2, NP = (TR + 2) * PW;
+  const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
+  const float* __restrict__ Aimg = p.A + (long)img * Hs * Ws * p.lda;
+
+  // per-thread patch staging slots: 64 patch rows per pass, 8 float4 per row
+  const int c4 = tid & 7;
+  int poff[NPASS];
+#pragma unroll
+  for (int j = 0; j < NPASS; ++j) {
+    const int prow = (tid >> 3) + 64 * j;
+    poff[j] = -2;  // beyond the patch
+    if (prow < NP) {
+      const int py = prow / PW, px = prow - py * PW;
+      int yy = y0 + py - 1, xx = x0 + px - 1;
+      const bool inb = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      if (p.ups) {
+        yy >>= 1;
+        xx >>= 1;
+      }
+      poff[j] = inb ? (yy * Ws + xx) * p.lda + c4 * 4 : -1;  // -1: zero padding
+    }
+  }
+  // A-fragment rows of this lane inside the patch (tap adds a constant)
+  int frow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = wm * 64 + i * 32 + l31;
+    const int ry = wide ? 0 : pix / p.W, x = wide ? pix : pix - ry * p.W;
+    frow[i] = ry * PW + x;
+  }
+
+  const int nchunk = p.Cin >> 5;
+  int c0 = 0, c1 = nchunk;
+  if (p.splitk > 1) {
+    const int per = (nchunk + p.splitk - 1) / p.splitk;
+    c0 = blockIdx.z * per;
+    c1 = min(nchunk, c0 + per);
+  }
+  // packed weights: block (nb, chunk, tap, ks, plane) = 64 uint4
+  const int nb0 = (n0 + wn * 64) >> 5;
+  const int nbN = p.N >> 5;
+  const long bstride_nb = (long)nchunk * 9 * 4 * 64;
+  const uint4* __restrict__ Bw0 = p.Bp + (long)nb0 * bstride_nb + lane;
+  const bool bok[2] = {nb0 < nbN, nb0 + 1 < nbN};
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 pr[NPASS];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint4 zu = make_uint4(0u, 0u, 0u, 0u);
+
+#define PATCH_LOAD(CH)                                                                              \
+  {                                                                                                 \
+    const float* __restrict__ Ac = Aimg + (CH) * 32;                                                \
+    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) pr[j] = poff[j] >= 0 ? *(const float4*)(Ac + poff[j]) : z4; \
+  }
+#define PATCH_STORE()                                                                               \
+  {                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                             \
+      if (poff[j] != -2) {                                                                          \
+        const int prow = (tid >> 3) + 64 * j;                                                       \
+        const bf16x4 hi = to_bf16x4(pr[j]);                                                         \
+        *(bf16x4*)&ph[prow][c4 * 4] = hi;                                                           \
+        if constexpr (MODE == 1) *(bf16x4*)&pl[prow][c4 * 4] = to_bf16x4(residual4(pr[j], hi));     \
+      }                                                                                             \
+    }                                                                                               \
+  }
+  // B fragments of one tap: [block j][kstep][plane]
+#define BFRAG_LOAD(DST, CH, TAP)                                                                    \
+  {                                                                                                 \
+    const long o = ((long)(CH) * 9 + (TAP)) * 4 * 64;                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+      const uint4* q = Bw0 + j * bstride_nb + o + ks * 128;                                         \
+      DST[j][ks][0] = bok[j] ? q[0] : zu;                                                           \
+      if constexpr (MODE == 1) DST[j][ks][1] = bok[j] ? q[64] : zu;                                 \
+    }                                                                                               \
+  }
+#define TAP_COMPUTE(BQ, TAP)                                                                        \
+  {                                                                                                 \
+    const int toff = ((TAP) / 3) * PW + ((TAP) % 3);                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+      bf16x8 ah[2], al[2];                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
+        ah[i] = *(const bf16x8*)&ph[frow[i] + toff][ks * 16 + hh * 8];                              \
+        if constexpr (MODE == 1) al[i] = *(const bf16x8*)&pl[frow[i] + toff][ks * 16 + hh * 8];     \
+      }                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) { \
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, BQ[j][ks][0]);                                 \
+        if constexpr (MODE == 1) {                                                                  \
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, BQ[j][ks][1]);                               \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);       \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);       \
+        }                                                                                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);         \
+      }                                                                                             \
+    }                                                                                               \
+  }
+
+  uint4 b0[2][2][MODE == 1 ? 2 : 1], b1[2][2][MODE == 1 ? 2 : 1];
+  if (c0 < c1) {
+    PATCH_LOAD(c0);
+    BFRAG_LOAD(b0, c0, 0);
+    PATCH_STORE();
+  }
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    const bool more = c + 1 < c1;
+    if (more) PATCH_LOAD(c + 1);  // stays in flight during the 9 taps
+    BFRAG_LOAD(b1, c, 1); TAP_COMPUTE(b0, 0);
+    BFRAG_LOAD(b0, c, 2); TAP_COMPUTE(b1, 1);
+    BFRAG_LOAD(b1, c, 3); TAP_COMPUTE(b0, 2);
+    BFRAG_LOAD(b0, c, 4); TAP_COMPUTE(b1, 3);
+    BFRAG_LOAD(b1, c, 5); TAP_COMPUTE(b0, 4);
+    BFRAG_LOAD(b0, c, 6); TAP_COMPUTE(b1, 5);
+    BFRAG_LOAD(b1, c, 7); TAP_COMPUTE(b0, 6);
+    BFRAG_LOAD(b0, c, 8); TAP_COMPUTE(b1, 7);
+    TAP_COMPUTE(b0, 8);
+    if (more) BFRAG_LOAD(b0, c + 1, 0);  // overlaps the chunk-boundary barriers and the patch store
+    __syncthreads();                     // every wavefront is done reading patch c
+    if (more) {
+      PATCH_STORE();
+      __syncthreads();
+    }
+  }
+#undef PATCH_LOAD
+#undef PATCH_STORE
+#undef BFRAG_LOAD
+#undef TAP_COMPUTE
+
+  // ---- epilogue (32x32 MFMA C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----------
+  if (p.splitk > 1) {
+    float* __restrict__ ws = p.ws + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (col < p.N) ws[(long)row * p.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (col < p.N) {
+          float v = p.alpha * acc[i][j][r] + bv;
+          if (p.R) v += p.R[(long)row * p.ldr + col];
+          p.C[(long)row * p.ldc + col] = v;
+        }
+      }
+    }
+}
+
+// w: torch conv weight [Co][Ci][3][3].  dgrad = 0: B[n=co][tap][k=ci] = w[co][ci][ky][kx];
+// dgrad = 1: B[n=ci][tap][k=co] = w[co][ci][2-ky][2-kx].  Output: fragment order, see header.
+__global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Co, int Ci, int dgrad) {
+  const int N = dgrad ? Ci : Co, K = dgrad ? Co : Ci;
+  const int nchunk = K >> 5;
+  const long total = (long)N * K * 9;  // elements per plane
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    // decode t -> (nb, chunk, tap, ks, lane, e)  (plane handled below)
+    const int e = (int)(t & 7);
+    long u = t >> 3;
+    const int lane = (int)(u & 63);
+    u >>= 6;
+    const int ks = (int)(u & 1);
+    u >>= 1;
+    const int tap = (int)(u % 9);
+    u /= 9;
+    const int chunk = (int)(u % nchunk), nb = (int)(u / nchunk);
+    const int n = nb * 32 + (lane & 31), k = chunk * 32 + ks * 16 + (lane >> 5) * 8 + e;
+    const int ky = tap / 3, kx = tap % 3;
+    const float v = dgrad ? w[(((long)k * Ci + n) * 3 + (2 - ky)) * 3 + (2 - kx)] : w[(((long)n * Ci + k) * 3 + ky) * 3 + kx];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const long blk = ((((long)nb * nchunk + chunk) * 9 + tap) * 2 + ks) * 2;  // + plane
+    out[(blk + 0) * 512 + lane * 8 + e] = hi;
+    out[(blk + 1) * 512 + lane * 8 + e] = lo;
+  }
+}
+
+}  // namespace
+
+size_t cgd_hconv_packed_floats(int Co, int Ci) { return (size_t)Co * Ci * 9; }  // 2 bf16 planes = one float per weight
+
+int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, hipStream_t s) {
+  if ((Co & 31) || (Ci & 31)) CGD_FAIL(ctx, "pack_conv3x3_frag: channels must be multiples of 32");
+  const long total = (long)Co * Ci * 9;
+  hipLaunchKernelGGL(pack_frag_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+bool cgd_hconv_supported(const GemmParams& p, int precision) {
+  if (!p.conv || !p.Bpk || precision == CGD_PREC_F32 || p.nbatch != 1) return false;
+  if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
+  if (p.H <= 0 || p.W <= 0) return false;
+  const long hw = (long)p.H * p.W;
+  if (hw % HB_M) return false;
+  if (p.W >= HB_M ? (p.W % HB_M) != 0 : (HB_M % p.W) != 0) return false;
+  if (p.ups && ((p.H | p.W) & 1)) return false;
+  return p.M % HB_M == 0;
+}
+
+int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
+  HConvParams p;
+  p.A = g.A; p.Bp = (const uint4*)g.Bpk; p.C = g.C; p.bias = g.bias; p.R = g.R; p.ws = g.ws;
+  p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
+  p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
+  dim3 grid((g.M / HB_M) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
+  if (ctx->precision == CGD_PREC_BF16X3)
+    hipLaunchKernelGGL((hconv_kernel<1>), grid, dim3(512), 0, s, p);
+  else
+    hipLaunchKernelGGL((hconv_kernel<2>), grid, dim3(512), 0, s, p);
+  return 0;
+}

@@ -60,6 +60,7 @@ struct ResBlock : Module {
   // params / packed
   float *g1 = 0, *b1 = 0, *cw1f = 0, *cw1d = 0, *cb1 = 0, *g2 = 0, *b2 = 0, *cw2f = 0, *cw2d = 0, *cb2 = 0, *skw = 0, *skwT = 0,
         *skb = 0;
+  float *cw1fp = 0, *cw1dp = 0, *cw2fp = 0, *cw2dp = 0;  // MFMA-fragment-order bf16 hi/lo copies for the halo conv kernel
   // runtime
   int B = 0, H = 0, W = 0, Ho = 0, Wo = 0;
   TV x;
@@ -145,7 +146,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   }
   // conv1 (the nearest-2x upsample of an `up` block is folded into the conv's gather)
   GemmParams c1;
-  c1.A = conv_in; c1.lda = cin; c1.B = cw1f; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
+  c1.A = conv_in; c1.lda = cin; c1.B = cw1f; c1.Bpk = cw1fp; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
   c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
   // out_layers: GN * (1+scale) + shift -> SiLU -> conv2 (+ skip)
@@ -162,7 +163,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
     ldr = cout;
   }
   GemmParams c2;
-  c2.A = h3.p; c2.lda = cout; c2.B = cw2f; c2.ldb = 9 * cout; c2.C = out.p; c2.ldc = cout; c2.bias = cb2; c2.R = R; c2.ldr = ldr;
+  c2.A = h3.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.ldb = 9 * cout; c2.C = out.p; c2.ldc = cout; c2.bias = cb2; c2.R = R; c2.ldr = ldr;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   CGD_TRY(cgd_launch_gemm(ctx, c2, s));
   Hh = Ho; Ww = Wo;
@@ -179,14 +180,14 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   CGD_TRY(u.ensure(dx, npi * cin));
   // conv2 dgrad
   GemmParams c2;
-  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
+  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   CGD_TRY(cgd_launch_gemm(ctx, c2, s));
   // GN2 + FiLM + SiLU backward
   CGD_TRY(cgd_launch_gn_bwd(ctx, h2.p, cout, d3.p, cout, d2.p, cout, nullptr, 0, B, Ho * Wo, cout, 1, s2.p, s));
   // conv1 dgrad (at the conv's own resolution)
   GemmParams c1;
-  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
+  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
   c1.M = (int)npo; c1.N = cin; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cout;
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
   // skip path first into dx, then GN1 backward accumulates on top
@@ -408,7 +409,15 @@ int UNet::finalize(hipStream_t s) {
       CGD_TRY(alloc(&rb->cw1d, (size_t)rb->cout * rb->cin * 9));
       CGD_TRY(alloc(&rb->cw2f, (size_t)rb->cout * rb->cout * 9));
       CGD_TRY(alloc(&rb->cw2d, (size_t)rb->cout * rb->cout * 9));
+      CGD_TRY(alloc(&rb->cw1fp, (size_t)rb->cout * rb->cin * 9));
+      CGD_TRY(alloc(&rb->cw1dp, (size_t)rb->cout * rb->cin * 9));
+      CGD_TRY(alloc(&rb->cw2fp, (size_t)rb->cout * rb->cout * 9));
+      CGD_TRY(alloc(&rb->cw2dp, (size_t)rb->cout * rb->cout * 9));
     }
+    CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".in_layers.2.weight"), rb->cw1fp, rb->cout, rb->cin, 0, s));
+    CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".in_layers.2.weight"), rb->cw1dp, rb->cout, rb->cin, 1, s));
+    CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".out_layers.3.weight"), rb->cw2fp, rb->cout, rb->cout, 0, s));
+    CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".out_layers.3.weight"), rb->cw2dp, rb->cout, rb->cout, 1, s));
     CGD_TRY(cgd_pack_conv3x3(ctx, P(p + ".in_layers.2.weight"), rb->cw1f, rb->cw1d, rb->cout, rb->cin, s));
     CGD_TRY(cgd_pack_conv3x3(ctx, P(p + ".out_layers.3.weight"), rb->cw2f, rb->cw2d, rb->cout, rb->cout, s));
     if (rb->skip_conv) {

@@ -33,13 +33,22 @@ def gemm(ctx, A, B, bias=None, R=None, alpha=1.0, force_tile=0, splitk=1, out=No
     return out
 
 
-def conv3x3(ctx, x_nhwc, w_packed, bias=None, R=None, upsample_input=False, force_tile=0, splitk=1):
+def pack_conv3x3_frag(ctx, w, dgrad=False):
+    """torch conv weight [Co][Ci][3][3] (on the GPU) -> MFMA-fragment-order bf16 hi/lo planes for the halo conv kernel."""
+    co, ci = w.shape[:2]
+    out = th.empty(co * ci * 9, device=w.device, dtype=th.float32)
+    wc = w.contiguous().float()
+    ctx.check(ctx.lib.cgd_op_pack_conv3x3_frag(ctx.h, wc.data_ptr(), out.data_ptr(), co, ci, int(dgrad), _s()))
+    return out
+
+
+def conv3x3(ctx, x_nhwc, w_packed, bias=None, R=None, upsample_input=False, force_tile=0, splitk=1, w_frag=None):
     """x (B,H,W,Cin) NHWC (H,W = OUTPUT size; with upsample_input the tensor holds (B,H/2,W/2,Cin))."""
     Bn, Hs, Ws, Cin = x_nhwc.shape
     H, W = (Hs * 2, Ws * 2) if upsample_input else (Hs, Ws)
     Cout = w_packed.shape[0]
     y = th.empty((Bn, H, W, Cout), device=x_nhwc.device, dtype=th.float32)
-    ctx.check(ctx.lib.cgd_op_conv3x3(ctx.h, x_nhwc.data_ptr(), Cin, w_packed.data_ptr(), y.data_ptr(), Cout, L.ptr(bias),
+    ctx.check(ctx.lib.cgd_op_conv3x3(ctx.h, x_nhwc.data_ptr(), Cin, w_packed.data_ptr(), L.ptr(w_frag), y.data_ptr(), Cout, L.ptr(bias),
                                      L.ptr(R), Cout, Bn, H, W, Cin, Cout, int(upsample_input), force_tile, splitk, _s()))
     return y
 

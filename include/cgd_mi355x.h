@@ -143,9 +143,15 @@ int cgd_sample_update(cgd_ctx* ctx, const float* x, const float* pred_xstart, co
 /* C[M][N] = alpha * A[M][K] B[N][K]^T (+bias[N]) (+R[M][N]); conv3x3: A is NHWC (Bn,H,W,Cin), B = [N][9*Cin] */
 int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, const float* R,
                 int ldr, int M, int N, int K, float alpha, int force_tile, int splitk, void* stream);
-int cgd_op_conv3x3(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_packed, float* y_nhwc, int ldy, const float* bias,
-                   const float* R, int ldr, int Bn, int H, int W, int Cin, int Cout, int upsample_input, int force_tile, int splitk,
-                   void* stream);
+/* w_packed: [Cout][9*Cin] fp32 (generic kernel); w_frag (optional): the same weights in MFMA-fragment order, bf16 hi/lo planes,
+ * produced by cgd_op_pack_conv3x3_frag from the torch layout [Co][Ci][3][3] (dgrad=1: rotated/transposed) — enables the
+ * halo-staged kernel (force_tile 512 or automatic for large images) */
+int cgd_op_pack_conv3x3_frag(cgd_ctx* ctx, const float* w_torch, float* out /* Co*Ci*9 floats of storage */, int Co, int Ci, int dgrad,
+                             void* stream);
+int cgd_set_hconv(cgd_ctx* ctx, int mode /*0 off, 1 auto*/, int min_m);
+int cgd_op_conv3x3(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_packed, const float* w_frag, float* y_nhwc, int ldy,
+                   const float* bias, const float* R, int ldr, int Bn, int H, int W, int Cin, int Cout, int upsample_input, int force_tile,
+                   int splitk, void* stream);
 int cgd_op_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w, const float* bias, float* y_nhwc, int Bn, int H, int W, int Cin,
                    int Cout, void* stream);
 int cgd_op_conv_thin_out(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w, const float* bias, float* y_nchw, int Bn, int H,
