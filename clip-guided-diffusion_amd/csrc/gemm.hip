@@ -20,6 +20,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -45,7 +46,7 @@ struct Smem<2, BM, BN> {
   __bf16 bh[2][BN][PH];
 };
 
-__device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
+__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4 v) {
   bf16x4 r;
   r[0] = (__bf16)v.x;
   r[1] = (__bf16)v.y;
@@ -53,12 +54,16 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
   r[3] = (__bf16)v.w;
   return r;
 }
-__device__ __forceinline__ float4 residual4(const float4 v, const bf16x4 hi) {
-  return make_float4(v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]);
+__device__ __forceinline__ f32x4 residual4(const f32x4 v, const bf16x4 hi) {
+  return f32x4{v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]};
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, int PF>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const float* __restrict__ Ag, const float* __restrict__ Bg, float* Cg,
+                                                                          const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
+                                                                          const GemmParams p) {
+  // pointers arrive as kernel arguments (not inside the by-value struct) so that the backend knows they are global:
+  // global_load/global_store instead of flat_* (flat loads tick lgkmcnt too and serialise LDS waits with HBM waits)
   __shared__ __attribute__((aligned(16))) Smem<MODE, BM, BN> sm;
   constexpr int NWN = BN / WN, NT = (BM / WM) * NWN * 64;
   constexpr int MB = WM / 32, NB = WN / 32;
@@ -77,10 +82,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
   }
   const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
 
-  const float* __restrict__ A = p.A;
-  const float* __restrict__ B = p.B;
-  float* __restrict__ C = p.C;
-  const float* __restrict__ R = p.R;
+  const float* __restrict__ A = Ag;
+  const float* __restrict__ B = Bg;
+  float* C = Cg;
+  const float* R = Rg;
   const int nkt = (p.K + BK - 1) / BK;
   int kt0 = 0, kt1 = nkt;
   if (p.splitk > 1) {
@@ -125,9 +130,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     b_off[j] = (long)n * p.ldb;
   }
 
-  float4 ra0[RA], rb0[RB];
-  float4 ra1[PF == 2 ? RA : 1], rb1[PF == 2 ? RB : 1];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 ra0[RA], rb0[RB];
+  f32x4 ra1[PF == 2 ? RA : 1], rb1[PF == 2 ? RB : 1];
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define GLOAD(KT, RA_, RB_)                                                                        \
   {                                                                                                \
@@ -143,14 +148,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
           yy >>= 1;                                                                                \
           xx >>= 1;                                                                                \
         }                                                                                          \
-        RA_[j] = ok ? *(const float4*)(A + (a_off[j] + (long)yy * Ws + xx) * p.lda + ci) : z4;     \
+        /* always load from a valid global address, then select the VALUE: `ok ? *p : 0` would let the compiler   \
+           select between the global pointer and a stack slot holding 0 (flat_load + scratch + coupled waitcnts) */   \
+        const f32x4 t = *(const f32x4*)(A + (ok ? (a_off[j] + (long)yy * Ws + xx) * p.lda + ci : 0L)); \
+        RA_[j] = ok ? t : z4;                                                                      \
       }                                                                                            \
     } else {                                                                                       \
-      _Pragma("unroll") for (int j = 0; j < RA; ++j)                                               \
-          RA_[j] = (a_ok[j] && kk < p.K) ? *(const float4*)(A + a_off[j] + kk) : z4;               \
+      _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                             \
+        const bool ok = a_ok[j] && kk < p.K;                                                       \
+        const f32x4 t = *(const f32x4*)(A + (ok ? a_off[j] + kk : 0L));                          \
+        RA_[j] = ok ? t : z4;                                                                      \
+      }                                                                                            \
     }                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < RB; ++j)                                                 \
-        RB_[j] = (b_ok[j] && kk < p.K) ? *(const float4*)(B + b_off[j] + kk) : z4;                 \
+    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                               \
+      const bool ok = b_ok[j] && kk < p.K;                                                         \
+      const f32x4 t = *(const f32x4*)(B + (ok ? b_off[j] + kk : 0L));                            \
+      RB_[j] = ok ? t : z4;                                                                        \
+    }                                                                                              \
   }
 
 #define SSTORE(BUF, RA_, RB_)                                                                      \
@@ -158,7 +172,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                               \
       const int row = r0 + RPP * j;                                                                \
       if constexpr (MODE == 0) {                                                                   \
-        *(float4*)&sm.a[BUF][row][c4 * 4] = RA_[j];                                                \
+        *(f32x4*)&sm.a[BUF][row][c4 * 4] = RA_[j];                                                \
       } else {                                                                                     \
         const bf16x4 hi = to_bf16x4(RA_[j]);                                                       \
         *(bf16x4*)&sm.ah[BUF][row][c4 * 4] = hi;                                                   \
@@ -168,7 +182,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                               \
       const int row = r0 + RPP * j;                                                                \
       if constexpr (MODE == 0) {                                                                   \
-        *(float4*)&sm.b[BUF][row][c4 * 4] = RB_[j];                                                \
+        *(f32x4*)&sm.b[BUF][row][c4 * 4] = RB_[j];                                                \
       } else {                                                                                     \
         const bf16x4 hi = to_bf16x4(RB_[j]);                                                       \
         *(bf16x4*)&sm.bh[BUF][row][c4 * 4] = hi;                                                   \
@@ -188,11 +202,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 #define COMPUTE(BUF)                                                                                                     \
   {                                                                                                                      \
     if constexpr (MODE == 0) {                                                                                           \
-      float4 fa[MB][4], fb[NB][4];                                                                                       \
+      f32x4 fa[MB][4], fb[NB][4];                                                                                       \
       _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int q = 0; q < 4; ++q)                       \
-          fa[i][q] = *(const float4*)&sm.a[BUF][wm * WM + i * 32 + l31][hh * 16 + q * 4];                               \
+          fa[i][q] = *(const f32x4*)&sm.a[BUF][wm * WM + i * 32 + l31][hh * 16 + q * 4];                               \
       _Pragma("unroll") for (int j = 0; j < NB; ++j) _Pragma("unroll") for (int q = 0; q < 4; ++q)                       \
-          fb[j][q] = *(const float4*)&sm.b[BUF][wn * WN + j * 32 + l31][hh * 16 + q * 4];                               \
+          fb[j][q] = *(const f32x4*)&sm.b[BUF][wn * WN + j * 32 + l31][hh * 16 + q * 4];                               \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
         _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j) {                  \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q].x, fb[j][q].x, acc[i][j], 0, 0, 0);                  \
@@ -261,7 +275,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   if (p.splitk > 1) {
-    float* __restrict__ ws = p.ws + (long)blockIdx.z * p.M * p.N;
+    float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -280,7 +294,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int col = n0 + wn * WN + j * 32 + l31;
-      const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+      float bv = 0.f;
+      if (biasg) bv = biasg[col < p.N ? col : p.N - 1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -334,7 +349,7 @@ template <int MODE, int BM, int BN, int WM, int WN, int PF>
 void launch_cfg(const GemmParams& p, hipStream_t s) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, p.splitk > 1 ? p.splitk : p.nbatch);
-  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, PF>), grid, dim3(NT), 0, s, p);
+  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, PF>), grid, dim3(NT), 0, s, p.A, p.B, p.C, p.bias, p.R, p.ws, p);
 }
 
 // tile codes: 64 = 64x64, 128 = 128x128, 256 = 256x128 (8 waves), 257 = 128x256 (wave tile 64x128);

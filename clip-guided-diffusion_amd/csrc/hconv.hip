@@ -24,7 +24,9 @@ constexpr int HB_M = 256, HB_N = 128, HPH = 40;  // tile, LDS row pitch (bf16 el
 constexpr int MAX_NP = 774;                      // 3 x 258 patch rows (W >= 256)
 constexpr int NPASS = 13;                        // ceil(774 / 64) staging passes of 64 rows
 
-__device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: value selects stay in registers
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4 v) {
   bf16x4 r;
   r[0] = (__bf16)v.x;
   r[1] = (__bf16)v.y;
@@ -32,8 +34,8 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
   r[3] = (__bf16)v.w;
   return r;
 }
-__device__ __forceinline__ float4 residual4(const float4 v, const bf16x4 hi) {
-  return make_float4(v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]);
+__device__ __forceinline__ f32x4 residual4(const f32x4 v, const bf16x4 hi) {
+  return f32x4{v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]};
 }
 
 struct HConvParams {
@@ -48,8 +50,13 @@ struct HConvParams {
   float alpha;
 };
 
+// Pointers are passed as kernel arguments (not inside the by-value struct) so that the backend knows they are global
+// and emits global_load / global_store: flat_* accesses tick lgkmcnt as well and would serialise every LDS wait with
+// the weight-fragment loads that are meant to stay in flight.
 template <int MODE>
-__global__ __launch_bounds__(512) void hconv_kernel(const HConvParams p) {
+__global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+                                                    const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
+                                                    const HConvParams p) {
   __shared__ __attribute__((aligned(16))) __bf16 ph[MAX_NP][HPH];
   __shared__ __attribute__((aligned(16))) __bf16 pl[MODE == 1 ? MAX_NP : 1][HPH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(512) void hconv_kernel(const HConvParams p) {
   const int TR = wide ? 1 : HB_M / p.W; // tile rows
   const int PW = TW + 2, NP = (TR + 2) * PW;
   const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
-  const float* __restrict__ Aimg = p.A + (long)img * Hs * Ws * p.lda;
+  const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
 
   // per-thread patch staging slots: 64 patch rows per pass, 8 float4 per row
   const int c4 = tid & 7;
@@ -113,8 +120,9 @@ __global__ __launch_bounds__(512) void hconv_kernel(const HConvParams p) {
   const int nb0 = (n0 + wn * 64) >> 5;
   const int nbN = p.N >> 5;
   const long bstride_nb = (long)nchunk * 9 * 4 * 64;
-  const uint4* __restrict__ Bw0 = p.Bp + (long)nb0 * bstride_nb + lane;
-  const bool bok[2] = {nb0 < nbN, nb0 + 1 < nbN};
+  const int nbc = nb0 < nbN ? nb0 : nbN - 1;  // clamped first block
+  const int bj[2] = {0, (nb0 + 1 < nbN) ? 1 : 0};
+  const uint4* __restrict__ Bw0 = Bg + (long)nbc * bstride_nb + lane;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -124,14 +132,19 @@ __global__ __launch_bounds__(512) void hconv_kernel(const HConvParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 pr[NPASS];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 pr[NPASS];
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint4 zu = make_uint4(0u, 0u, 0u, 0u);
 
 #define PATCH_LOAD(CH)                                                                              \
   {                                                                                                 \
     const float* __restrict__ Ac = Aimg + (CH) * 32;                                                \
-    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) pr[j] = poff[j] >= 0 ? *(const float4*)(Ac + poff[j]) : z4; \
+    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                             \
+      /* unconditional load from a clamped (valid) address + value select: a `cond ? *p : 0` lets the compiler select   \
+         between the global pointer and a stack slot holding 0, which forces flat_load + scratch */                      \
+      const f32x4 t = *(const f32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4));                       \
+      pr[j] = poff[j] >= 0 ? t : z4;                                                                \
+    }                                                                                               \
   }
 #define PATCH_STORE()                                                                               \
   {                                                                                                 \
@@ -149,9 +162,10 @@ __global__ __launch_bounds__(512) void hconv_kernel(const HConvParams p) {
   {                                                                                                 \
     const long o = ((long)(CH) * 9 + (TAP)) * 4 * 64;                                               \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
-      const uint4* q = Bw0 + j * bstride_nb + o + ks * 128;                                         \
-      DST[j][ks][0] = bok[j] ? q[0] : zu;                                                           \
-      if constexpr (MODE == 1) DST[j][ks][1] = bok[j] ? q[64] : zu;                                 \
+      /* columns beyond N are never stored: read a valid (clamped) block instead of branching */   \
+      const uint4* q = Bw0 + bj[j] * bstride_nb + o + ks * 128;                                     \
+      DST[j][ks][0] = q[0];                                                                         \
+      if constexpr (MODE == 1) DST[j][ks][1] = q[64];                                               \
     }                                                                                               \
   }
 #define TAP_COMPUTE(BQ, TAP)                                                                        \
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(512) void hconv_kernel(const HConvParams p) {
 
   // ---- epilogue (32x32 MFMA C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----------
   if (p.splitk > 1) {
-    float* __restrict__ ws = p.ws + (long)blockIdx.z * p.M * p.N;
+    float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -227,14 +241,15 @@ __global__ __launch_bounds__(512) void hconv_kernel(const HConvParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + l31;
-      const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+      float bv = 0.f;
+      if (biasg) bv = biasg[col < p.N ? col : p.N - 1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (col < p.N) {
           float v = p.alpha * acc[i][j][r] + bv;
-          if (p.R) v += p.R[(long)row * p.ldr + col];
-          p.C[(long)row * p.ldc + col] = v;
+          if (Rg) v += Rg[(long)row * p.ldr + col];
+          Cg[(long)row * p.ldc + col] = v;
         }
       }
     }
@@ -298,8 +313,8 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   dim3 grid((g.M / HB_M) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
   if (ctx->precision == CGD_PREC_BF16X3)
-    hipLaunchKernelGGL((hconv_kernel<1>), grid, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((hconv_kernel<1>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p);
   else
-    hipLaunchKernelGGL((hconv_kernel<2>), grid, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((hconv_kernel<2>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p);
   return 0;
 }
