@@ -134,10 +134,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
   f32x4 ra1[PF == 2 ? RA : 1], rb1[PF == 2 ? RB : 1];
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define GLOAD(KT, RA_, RB_)                                                                        \
+  // validity bit masks of the staged rows: the zero fill is applied when the registers are written to LDS, so the
+  // loads stay in flight across the MFMA block instead of being waited for by an early select
+  unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;
+
+#define GLOAD(KT, RA_, RB_, MA_, MB_)                                                              \
   {                                                                                                \
     const int kbase = (KT) * BK;                                                                   \
     const int kk = kbase + c4 * 4;                                                                 \
+    MA_ = 0;                                                                                       \
+    MB_ = 0;                                                                                       \
     if (p.conv) {                                                                                  \
       const int tap = kbase / p.Cin, ci = kbase - tap * p.Cin + c4 * 4;                            \
       const int ky = tap / 3, kx = tap - 3 * ky;                                                   \
@@ -150,43 +156,45 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
         }                                                                                          \
         /* always load from a valid global address, then select the VALUE: `ok ? *p : 0` would let the compiler   \
            select between the global pointer and a stack slot holding 0 (flat_load + scratch + coupled waitcnts) */   \
-        const f32x4 t = *(const f32x4*)(A + (ok ? (a_off[j] + (long)yy * Ws + xx) * p.lda + ci : 0L)); \
-        RA_[j] = ok ? t : z4;                                                                      \
+        RA_[j] = *(const f32x4*)(A + (ok ? (a_off[j] + (long)yy * Ws + xx) * p.lda + ci : 0L));    \
+        MA_ |= ok ? (1u << j) : 0u;                                                                \
       }                                                                                            \
     } else {                                                                                       \
       _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                             \
         const bool ok = a_ok[j] && kk < p.K;                                                       \
-        const f32x4 t = *(const f32x4*)(A + (ok ? a_off[j] + kk : 0L));                          \
-        RA_[j] = ok ? t : z4;                                                                      \
+        RA_[j] = *(const f32x4*)(A + (ok ? a_off[j] + kk : 0L));                                   \
+        MA_ |= ok ? (1u << j) : 0u;                                                                \
       }                                                                                            \
     }                                                                                              \
     _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                               \
       const bool ok = b_ok[j] && kk < p.K;                                                         \
-      const f32x4 t = *(const f32x4*)(B + (ok ? b_off[j] + kk : 0L));                            \
-      RB_[j] = ok ? t : z4;                                                                        \
+      RB_[j] = *(const f32x4*)(B + (ok ? b_off[j] + kk : 0L));                                     \
+      MB_ |= ok ? (1u << j) : 0u;                                                                  \
     }                                                                                              \
   }
 
-#define SSTORE(BUF, RA_, RB_)                                                                      \
+#define SSTORE(BUF, RA_, RB_, MA_, MB_)                                                            \
   {                                                                                                \
     _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                               \
       const int row = r0 + RPP * j;                                                                \
+      const f32x4 v = (MA_ >> j) & 1u ? RA_[j] : z4;                                               \
       if constexpr (MODE == 0) {                                                                   \
-        *(f32x4*)&sm.a[BUF][row][c4 * 4] = RA_[j];                                                \
+        *(f32x4*)&sm.a[BUF][row][c4 * 4] = v;                                                      \
       } else {                                                                                     \
-        const bf16x4 hi = to_bf16x4(RA_[j]);                                                       \
+        const bf16x4 hi = to_bf16x4(v);                                                            \
         *(bf16x4*)&sm.ah[BUF][row][c4 * 4] = hi;                                                   \
-        if constexpr (MODE == 1) *(bf16x4*)&sm.al[BUF][row][c4 * 4] = to_bf16x4(residual4(RA_[j], hi)); \
+        if constexpr (MODE == 1) *(bf16x4*)&sm.al[BUF][row][c4 * 4] = to_bf16x4(residual4(v, hi)); \
       }                                                                                            \
     }                                                                                              \
     _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                               \
       const int row = r0 + RPP * j;                                                                \
+      const f32x4 v = (MB_ >> j) & 1u ? RB_[j] : z4;                                               \
       if constexpr (MODE == 0) {                                                                   \
-        *(f32x4*)&sm.b[BUF][row][c4 * 4] = RB_[j];                                                \
+        *(f32x4*)&sm.b[BUF][row][c4 * 4] = v;                                                      \
       } else {                                                                                     \
-        const bf16x4 hi = to_bf16x4(RB_[j]);                                                       \
+        const bf16x4 hi = to_bf16x4(v);                                                            \
         *(bf16x4*)&sm.bh[BUF][row][c4 * 4] = hi;                                                   \
-        if constexpr (MODE == 1) *(bf16x4*)&sm.bl[BUF][row][c4 * 4] = to_bf16x4(residual4(RB_[j], hi)); \
+        if constexpr (MODE == 1) *(bf16x4*)&sm.bl[BUF][row][c4 * 4] = to_bf16x4(residual4(v, hi)); \
       }                                                                                            \
     }                                                                                              \
   }
@@ -239,33 +247,33 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 
   if constexpr (PF == 1) {
     if (kt0 < kt1) {
-      GLOAD(kt0, ra0, rb0);
-      SSTORE(0, ra0, rb0);
+      GLOAD(kt0, ra0, rb0, ma0, mb0);
+      SSTORE(0, ra0, rb0, ma0, mb0);
     }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
       const int buf = (kt - kt0) & 1;
       const bool more = kt + 1 < kt1;
-      if (more) GLOAD(kt + 1, ra0, rb0);
+      if (more) GLOAD(kt + 1, ra0, rb0, ma0, mb0);
       COMPUTE(buf);
-      if (more) SSTORE(buf ^ 1, ra0, rb0);
+      if (more) SSTORE(buf ^ 1, ra0, rb0, ma0, mb0);
       __syncthreads();
     }
   } else {
     // two K tiles of global loads in flight: tile kt+1 sits in one register set while kt+2 is being fetched
-    if (kt0 < kt1) GLOAD(kt0, ra0, rb0);
-    if (kt0 + 1 < kt1) GLOAD(kt0 + 1, ra1, rb1);
-    if (kt0 < kt1) SSTORE(0, ra0, rb0);
+    if (kt0 < kt1) GLOAD(kt0, ra0, rb0, ma0, mb0);
+    if (kt0 + 1 < kt1) GLOAD(kt0 + 1, ra1, rb1, ma1, mb1);
+    if (kt0 < kt1) SSTORE(0, ra0, rb0, ma0, mb0);
     __syncthreads();
     for (int kt = kt0; kt < kt1; kt += 2) {
-      if (kt + 2 < kt1) GLOAD(kt + 2, ra0, rb0);
+      if (kt + 2 < kt1) GLOAD(kt + 2, ra0, rb0, ma0, mb0);
       COMPUTE(0);
-      if (kt + 1 < kt1) SSTORE(1, ra1, rb1);
+      if (kt + 1 < kt1) SSTORE(1, ra1, rb1, ma1, mb1);
       __syncthreads();
       if (kt + 1 >= kt1) break;
-      if (kt + 3 < kt1) GLOAD(kt + 3, ra1, rb1);
+      if (kt + 3 < kt1) GLOAD(kt + 3, ra1, rb1, ma1, mb1);
       COMPUTE(1);
-      if (kt + 2 < kt1) SSTORE(0, ra0, rb0);
+      if (kt + 2 < kt1) SSTORE(0, ra0, rb0, ma0, mb0);
       __syncthreads();
     }
   }
@@ -296,14 +304,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
       const int col = n0 + wn * WN + j * 32 + l31;
       float bv = 0.f;
       if (biasg) bv = biasg[col < p.N ? col : p.N - 1];
+      // residual values are fetched for the whole block first (clamped addresses), then one wait: a load inside the
+      // per-element bounds branch would be waited for 16 times in a row
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      if (R) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const bool ok = row < p.M && col < p.N;
+          rv[r] = R[ok ? (long)row * p.ldr + col : 0L];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < p.M && col < p.N) {
-          float v = p.alpha * acc[i][j][r] + bv;
-          if (R) v += R[(long)row * p.ldr + col];
-          C[(long)row * p.ldc + col] = v;
-        }
+        if (row < p.M && col < p.N) C[(long)row * p.ldc + col] = p.alpha * acc[i][j][r] + bv + rv[r];
       }
     }
 }

@@ -142,8 +142,7 @@ __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag
     _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                             \
       /* unconditional load from a clamped (valid) address + value select: a `cond ? *p : 0` lets the compiler select   \
          between the global pointer and a stack slot holding 0, which forces flat_load + scratch */                      \
-      const f32x4 t = *(const f32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4));                       \
-      pr[j] = poff[j] >= 0 ? t : z4;                                                                \
+      pr[j] = *(const f32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4));  /* zeroed at store time: no early wait */ \
     }                                                                                               \
   }
 #define PATCH_STORE()                                                                               \
@@ -151,9 +150,10 @@ __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag
     _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                             \
       if (poff[j] != -2) {                                                                          \
         const int prow = (tid >> 3) + 64 * j;                                                       \
-        const bf16x4 hi = to_bf16x4(pr[j]);                                                         \
+        const f32x4 v = poff[j] >= 0 ? pr[j] : z4;                                                  \
+        const bf16x4 hi = to_bf16x4(v);                                                             \
         *(bf16x4*)&ph[prow][c4 * 4] = hi;                                                           \
-        if constexpr (MODE == 1) *(bf16x4*)&pl[prow][c4 * 4] = to_bf16x4(residual4(pr[j], hi));     \
+        if constexpr (MODE == 1) *(bf16x4*)&pl[prow][c4 * 4] = to_bf16x4(residual4(v, hi));         \
       }                                                                                             \
     }                                                                                               \
   }
@@ -243,14 +243,21 @@ __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag
       const int col = n0 + wn * 64 + j * 32 + l31;
       float bv = 0.f;
       if (biasg) bv = biasg[col < p.N ? col : p.N - 1];
+      float rv[16];  // residual block fetched up front (clamped column), one wait instead of 16
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      if (Rg) {
+        const int colc = col < p.N ? col : p.N - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          rv[r] = Rg[(long)row * p.ldr + colc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (col < p.N) {
-          float v = p.alpha * acc[i][j][r] + bv;
-          if (Rg) v += Rg[(long)row * p.ldr + col];
-          Cg[(long)row * p.ldc + col] = v;
-        }
+        if (col < p.N) Cg[(long)row * p.ldc + col] = p.alpha * acc[i][j][r] + bv + rv[r];
       }
     }
 }
