@@ -64,6 +64,118 @@ HeadOff head_off(const AttnShape& sh) {
   return h;
 }
 
+// ---- fused attention for short sequences (T <= 64, d = 64): CLIP ViT-B/32 (T = 50) and the UNet's 8x8 level (T = 64) -----
+// One workgroup per (sequence, head): q, k, v (and dO) live in LDS, scores / softmax / PV in exact fp32 FMAs.  Replaces
+// 4 launches (transpose, QK^T, softmax, PV) forward and 8 backward; these sizes are launch-bound, not FLOP-bound.
+constexpr int AS_T = 64, AS_D = 64, AS_P = AS_D + 1;
+
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo,
+                                                             float* __restrict__ P, int T, int Tp, int H, long qo, long ko, long vo, long step,
+                                                             float alpha) {
+  __shared__ float q[AS_T][AS_P], k[AS_T][AS_P], v[AS_T][AS_P], sc[AS_T][AS_T + 1];
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const float* base = qkv + (long)n * T * ldq + h * step;
+  for (int e = tid; e < T * AS_D; e += 256) {
+    const int t = e >> 6, c = e & 63;
+    const float* r = base + (long)t * ldq + c;
+    q[t][c] = r[qo];
+    k[t][c] = r[ko];
+    v[t][c] = r[vo];
+  }
+  __syncthreads();
+  for (int e = tid; e < T * T; e += 256) {
+    const int t = e / T, s = e - t * T;
+    float a = 0.f;
+#pragma unroll 16
+    for (int c = 0; c < AS_D; ++c) a += q[t][c] * k[s][c];
+    sc[t][s] = a * alpha;
+  }
+  __syncthreads();
+  if (tid < T) {
+    float mx = -INFINITY;
+    for (int s = 0; s < T; ++s) mx = fmaxf(mx, sc[tid][s]);
+    float sum = 0.f;
+    for (int s = 0; s < T; ++s) {
+      const float e = __expf(sc[tid][s] - mx);
+      sc[tid][s] = e;
+      sum += e;
+    }
+    const float inv = 1.f / sum;
+    for (int s = 0; s < T; ++s) sc[tid][s] *= inv;
+  }
+  __syncthreads();
+  float* Pz = P + ((long)n * H + h) * T * Tp;
+  for (int e = tid; e < T * Tp; e += 256) {
+    const int t = e / Tp, s = e - t * Tp;
+    Pz[e] = s < T ? sc[t][s] : 0.f;
+  }
+  float* ob = out + (long)n * T * ldo + h * AS_D;
+  for (int e = tid; e < T * AS_D; e += 256) {
+    const int t = e >> 6, c = e & 63;
+    float a = 0.f;
+    for (int s = 0; s < T; ++s) a += sc[t][s] * v[s][c];
+    ob[(long)t * ldo + c] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout, int lddo,
+                                                             float* __restrict__ dqkv, int lddq, const float* __restrict__ P, int T, int Tp,
+                                                             int H, long qo, long ko, long vo, long step, float alpha) {
+  __shared__ float q[AS_T][AS_P], k[AS_T][AS_P], v[AS_T][AS_P], go[AS_T][AS_P], pr[AS_T][AS_T + 1], ds[AS_T][AS_T + 1];
+  __shared__ float rs[AS_T];
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const float* base = qkv + (long)n * T * ldq + h * step;
+  const float* gob = dout + (long)n * T * lddo + h * AS_D;
+  const float* Pz = P + ((long)n * H + h) * T * Tp;
+  for (int e = tid; e < T * AS_D; e += 256) {
+    const int t = e >> 6, c = e & 63;
+    const float* r = base + (long)t * ldq + c;
+    q[t][c] = r[qo];
+    k[t][c] = r[ko];
+    v[t][c] = r[vo];
+    go[t][c] = gob[(long)t * lddo + c];
+  }
+  for (int e = tid; e < T * T; e += 256) {
+    const int t = e / T, s = e - t * T;
+    pr[t][s] = Pz[(long)t * Tp + s];
+  }
+  __syncthreads();
+  // dP = dO v^T
+  for (int e = tid; e < T * T; e += 256) {
+    const int t = e / T, s = e - t * T;
+    float a = 0.f;
+#pragma unroll 16
+    for (int c = 0; c < AS_D; ++c) a += go[t][c] * v[s][c];
+    ds[t][s] = a;
+  }
+  __syncthreads();
+  if (tid < T) {
+    float a = 0.f;
+    for (int s = 0; s < T; ++s) a += ds[tid][s] * pr[tid][s];
+    rs[tid] = a;
+  }
+  __syncthreads();
+  for (int e = tid; e < T * T; e += 256) {
+    const int t = e / T, s = e - t * T;
+    ds[t][s] = pr[t][s] * (ds[t][s] - rs[t]);
+  }
+  __syncthreads();
+  float* ob = dqkv + (long)n * T * lddq + h * step;
+  for (int e = tid; e < T * AS_D; e += 256) {
+    const int t = e >> 6, c = e & 63;  // t plays the role of the output row (t for dQ, s for dK / dV)
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int s = 0; s < T; ++s) {
+      dq += ds[t][s] * k[s][c];
+      dk += ds[s][t] * q[s][c];
+      dv += pr[s][t] * go[s][c];
+    }
+    float* r = ob + (long)t * lddq + c;
+    r[qo] = dq * alpha;
+    r[ko] = dk * alpha;
+    r[vo] = dv;
+  }
+}
+
 }  // namespace
 
 int cgd_launch_softmax_rows(cgd_ctx* ctx, float* S, long rows, int T, int ld, hipStream_t s) {
@@ -82,6 +194,12 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
   const HeadOff ho = head_off(sh);
+  if (T <= AS_T && d == AS_D) {
+    hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v,
+                       ho.step, 1.f / sqrtf((float)d));
+    CGD_HIP(ctx, hipGetLastError());
+    return 0;
+  }
   // qkvT[n][3C][Tp] <- qkv[n][T][3C]
   CGD_TRY(cgd_launch_transpose(ctx, qkv, ldq, (long)T * ldq, bufs.qkvT, Tp, 3L * C * Tp, T, 3 * C, sh.nb, s));
   // S = q k^T / sqrt(d)
@@ -117,6 +235,12 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   const HeadOff ho = head_off(sh);
   const float alpha = 1.f / sqrtf((float)d);
   const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
+  if (T <= AS_T && d == AS_D) {
+    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q,
+                       ho.k, ho.v, ho.step, alpha);
+    CGD_HIP(ctx, hipGetLastError());
+    return 0;
+  }
   // dP = dO v^T  (A = dO head slice, B = v token-major)
   GemmParams g;
   g.A = dout;  g.lda = lddo;

@@ -143,7 +143,8 @@ int cgd_op_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, i
   return cgd_pack_conv3x3_frag(ctx, w, out, Co, Ci, dgrad, S(stream));
 }
 int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m) {
-  ctx->hconv_mode = mode;
+  ctx->hconv_mode = mode & 15;
+  ctx->hconv_var = mode >> 4;
   ctx->hconv_min_m = min_m;
   return 0;
 }

@@ -26,6 +26,7 @@ struct cgd_ctx {
   size_t ws_bytes = 0;
   int num_cu = 256;
   int tile_huge = 1256, tile_large = 128, tile_small = 64;  // GEMM tile codes of the automatic selection (gemm.hip)
+  int hconv_var = 1;  // scheduling variant of hconv_kernel: 1 = sched_barrier after the fragment prefetch (ops_r1o: +3..10%)
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   // optional HIP-event timing of every MFMA GEMM/conv launch (bench.py roofline leg)
   bool prof_on = false;

@@ -67,6 +67,19 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ a
   }
 }
 
+// out[r][0:Ca] = a[r][:], out[r][Ca:Ca+Cb] = b[r][:]   (skip-connection concat in one launch)
+__global__ __launch_bounds__(256) void concat2_kernel(const float* __restrict__ a, int lda, int Ca, const float* __restrict__ b, int ldb,
+                                                      int Cb, float* __restrict__ out, int ldo, long rows) {
+  const int qa = Ca >> 2, cq = (Ca + Cb) >> 2;
+  const long total = rows * cq;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % cq);
+    const long r = i / cq;
+    const float4 v = q < qa ? *(const float4*)(a + r * lda + q * 4) : *(const float4*)(b + r * ldb + (q - qa) * 4);
+    *(float4*)(out + r * ldo + q * 4) = v;
+  }
+}
+
 __device__ __forceinline__ float act_f(float u, int act) {
   const float k = act == 2 ? 1.702f : 1.f;
   return u / (1.f + __expf(-k * u));
@@ -183,6 +196,14 @@ int cgd_launch_copy2d(cgd_ctx* ctx, const float* a, int lda, const float* b, int
                       hipStream_t s) {
   if ((C & 3) || (lda & 3) || (ldo & 3) || (b && (ldb & 3))) CGD_FAIL(ctx, "copy2d: C and strides must be multiples of 4");
   hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int cgd_launch_concat2(cgd_ctx* ctx, const float* a, int lda, int Ca, const float* b, int ldb, int Cb, float* out, int ldo, long rows,
+                       hipStream_t s) {
+  if ((Ca & 3) || (Cb & 3) || (lda & 3) || (ldb & 3) || (ldo & 3)) CGD_FAIL(ctx, "concat2: channels and strides must be multiples of 4");
+  hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * ((Ca + Cb) / 4))), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, out, ldo, rows);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }

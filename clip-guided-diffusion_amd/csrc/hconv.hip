@@ -53,7 +53,9 @@ struct HConvParams {
 // Pointers are passed as kernel arguments (not inside the by-value struct) so that the backend knows they are global
 // and emits global_load / global_store: flat_* accesses tick lgkmcnt as well and would serialise every LDS wait with
 // the weight-fragment loads that are meant to stay in flight.
-template <int MODE>
+// VAR: scheduling experiments (bit 0: sched_barrier after the fragment prefetch so the loads are issued a full tap ahead;
+// bit 1: s_setprio(1) around each MFMA cluster)
+template <int MODE, int VAR>
 __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                     const HConvParams p) {
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag
       DST[j][ks][0] = q[0];                                                                         \
       if constexpr (MODE == 1) DST[j][ks][1] = q[64];                                               \
     }                                                                                               \
+    if constexpr (VAR & 1) __builtin_amdgcn_sched_barrier(0);                                       \
   }
 #define TAP_COMPUTE(BQ, TAP)                                                                        \
   {                                                                                                 \
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag
         ah[i] = *(const bf16x8*)&ph[frow[i] + toff][ks * 16 + hh * 8];                              \
         if constexpr (MODE == 1) al[i] = *(const bf16x8*)&pl[frow[i] + toff][ks * 16 + hh * 8];     \
       }                                                                                             \
+      if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);                                         \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) { \
         const bf16x8 bh = __builtin_bit_cast(bf16x8, BQ[j][ks][0]);                                 \
         if constexpr (MODE == 1) {                                                                  \
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag
         }                                                                                           \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);         \
       }                                                                                             \
+      if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);                                         \
     }                                                                                               \
   }
 
@@ -319,9 +324,17 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   dim3 grid((g.M / HB_M) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
-  if (ctx->precision == CGD_PREC_BF16X3)
-    hipLaunchKernelGGL((hconv_kernel<1>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p);
-  else
-    hipLaunchKernelGGL((hconv_kernel<2>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p);
+#define HC_LAUNCH(M_, V_) hipLaunchKernelGGL((hconv_kernel<M_, V_>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
+  if (ctx->precision == CGD_PREC_BF16X3) {
+    switch (ctx->hconv_var & 3) {
+      case 0: HC_LAUNCH(1, 0); break;
+      case 1: HC_LAUNCH(1, 1); break;
+      case 2: HC_LAUNCH(1, 2); break;
+      default: HC_LAUNCH(1, 3); break;
+    }
+  } else {
+    HC_LAUNCH(2, 0);
+  }
+#undef HC_LAUNCH
   return 0;
 }

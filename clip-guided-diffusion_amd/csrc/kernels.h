@@ -27,6 +27,9 @@ int cgd_launch_upsample2x(cgd_ctx* ctx, const float* in, int ldi, float* out, in
 // out = a (+ b), 2-D with row strides
 int cgd_launch_copy2d(cgd_ctx* ctx, const float* a, int lda, const float* b, int ldb, float* out, int ldo, long rows, int C,
                       hipStream_t s);
+// out[:, 0:Ca] = a, out[:, Ca:Ca+Cb] = b
+int cgd_launch_concat2(cgd_ctx* ctx, const float* a, int lda, int Ca, const float* b, int ldb, int Cb, float* out, int ldo, long rows,
+                       hipStream_t s);
 // act: 1 SiLU, 2 QuickGELU.   fwd: y = act(x);  bwd: dx = dy * act'(x)
 int cgd_launch_act_fwd(cgd_ctx* ctx, const float* x, float* y, long n, int act, hipStream_t s);
 int cgd_launch_act_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx, long n, int act, hipStream_t s);

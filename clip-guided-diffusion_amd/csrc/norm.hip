@@ -371,6 +371,251 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   }
 }
 
+// ---- single-launch GroupNorm for small feature maps (<= 32x32 pixels): one workgroup per (sample, group) -------------
+// At these sizes a GroupNorm is launch-bound (3 kernels of ~6 us each); here statistics, coefficient folding and the
+// apply pass share one kernel, the second pass re-reading an L2-resident group slab.  1024 threads; thread = (pixel row r,
+// channel vector q) with a power-of-two row width so no division is needed; loads are VEC-wide and 4 pixels are in flight
+// per thread (independent loads) because the kernel is latency-, not bandwidth-bound.  Writes the same stats / coef
+// records as the 3-kernel path so forward and backward variants can be mixed.
+constexpr int GS_NT = 1024, GS_U = 4;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < GS_NT / 64; ++i) t += red[i];
+  return t;
+}
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> {
+  typedef float T;
+};
+template <>
+struct VecT<4> {
+  typedef float __attribute__((ext_vector_type(4))) T;
+};
+template <int VEC>
+__device__ __forceinline__ float vget(const typename VecT<VEC>::T& v, int i) {
+  if constexpr (VEC == 1) return v; else return v[i];
+}
+template <int VEC>
+__device__ __forceinline__ void vset(typename VecT<VEC>::T& v, int i, float x) {
+  if constexpr (VEC == 1) v = x; else v[i] = x;
+}
+
+template <int ACT, int VEC>
+__global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int HW,
+                                                             int C, int lg, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ film, int ldfilm, float eps,
+                                                             float* __restrict__ stats, float* __restrict__ coef) {
+  typedef typename VecT<VEC>::T V;
+  __shared__ float red[GS_NT / 64];
+  __shared__ float ca[128], cb[128];
+  const int g = blockIdx.x, b = blockIdx.y, cpg = C / 32, cq = cpg / VEC, n = HW * cpg;
+  const int q = threadIdx.x & ((1 << lg) - 1), r = threadIdx.x >> lg, rows = GS_NT >> lg;
+  const bool act_q = q < cq;
+  const float* xg = x + (long)b * HW * ldx + g * cpg + q * VEC;
+  float* yg = y + (long)b * HW * ldy + g * cpg + q * VEC;
+  const float k0 = x[(long)b * HW * ldx + g * cpg];
+  float s = 0.f, ss = 0.f;
+  if (act_q) {
+    for (int p0 = r; p0 < HW; p0 += rows * GS_U) {
+      V v[GS_U];
+#pragma unroll
+      for (int u = 0; u < GS_U; ++u) {
+        const int p = p0 + u * rows;
+        v[u] = *(const V*)(xg + (long)(p < HW ? p : r) * ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < GS_U; ++u) {
+        if (p0 + u * rows < HW) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float d = vget<VEC>(v[u], e) - k0;
+            s += d;
+            ss += d * d;
+          }
+        }
+      }
+    }
+  }
+  s = block_sum(s, red);
+  ss = block_sum(ss, red);
+  const float ms = s / n;
+  const float mean = k0 + ms, var = fmaxf(ss / n - ms * ms, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    stats[((long)b * 32 + g) * 2] = mean;
+    stats[((long)b * 32 + g) * 2 + 1] = rstd;
+  }
+  if (threadIdx.x < cpg) {
+    const int c = g * cpg + threadIdx.x;
+    float gm = gamma[c], bt = beta[c];
+    if (film) {
+      const float sc = 1.f + film[(long)b * ldfilm + c], sh = film[(long)b * ldfilm + C + c];
+      gm *= sc;
+      bt = bt * sc + sh;
+    }
+    float* o = coef + ((long)b * C + c) * 4;
+    o[0] = ca[threadIdx.x] = gm * rstd;
+    o[1] = cb[threadIdx.x] = bt - mean * gm * rstd;
+    o[2] = gm;
+    o[3] = mean;
+  }
+  __syncthreads();
+  if (!act_q) return;
+  float a[VEC], bb[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    a[e] = ca[q * VEC + e];
+    bb[e] = cb[q * VEC + e];
+  }
+  for (int p0 = r; p0 < HW; p0 += rows * GS_U) {
+    V v[GS_U];
+#pragma unroll
+    for (int u = 0; u < GS_U; ++u) {
+      const int p = p0 + u * rows;
+      v[u] = *(const V*)(xg + (long)(p < HW ? p : r) * ldx);
+    }
+#pragma unroll
+    for (int u = 0; u < GS_U; ++u) {
+      const int p = p0 + u * rows;
+      if (p < HW) {
+        V o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float t = vget<VEC>(v[u], e) * a[e] + bb[e];
+          if (ACT == 1) t = silu_f(t);
+          vset<VEC>(o, e, t);
+        }
+        *(V*)(yg + (long)p * ldy) = o;
+      }
+    }
+  }
+}
+
+template <int ACT, int VEC>
+__global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int lddz,
+                                                             float* dx, int lddx, const float* add, int ldadd, int HW, int C, int lg,
+                                                             const float* __restrict__ stats, const float* __restrict__ coef) {
+  typedef typename VecT<VEC>::T V;
+  __shared__ float red[GS_NT / 64];
+  const int g = blockIdx.x, b = blockIdx.y, cpg = C / 32, cq = cpg / VEC, n = HW * cpg;
+  const int q = threadIdx.x & ((1 << lg) - 1), r = threadIdx.x >> lg, rows = GS_NT >> lg;
+  const bool act_q = q < cq;
+  const int qc = act_q ? q : 0;
+  const float* xg = x + (long)b * HW * ldx + g * cpg + qc * VEC;
+  const float* dg = dz + (long)b * HW * lddz + g * cpg + qc * VEC;
+  float* og = dx + (long)b * HW * lddx + g * cpg + qc * VEC;
+  const float* ag = add ? add + (long)b * HW * ldadd + g * cpg + qc * VEC : nullptr;
+  const float mean = stats[((long)b * 32 + g) * 2], rstd = stats[((long)b * 32 + g) * 2 + 1];
+  float a[VEC], bb[VEC], gc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const float* o = coef + ((long)b * C + g * cpg + qc * VEC + e) * 4;
+    a[e] = o[0];
+    bb[e] = o[1];
+    gc[e] = o[2];
+  }
+  float p1 = 0.f, p2 = 0.f;
+  if (act_q) {
+    for (int p0 = r; p0 < HW; p0 += rows * GS_U) {
+      V xv[GS_U], dv[GS_U];
+#pragma unroll
+      for (int u = 0; u < GS_U; ++u) {
+        const int p = p0 + u * rows, pc = p < HW ? p : r;
+        xv[u] = *(const V*)(xg + (long)pc * ldx);
+        dv[u] = *(const V*)(dg + (long)pc * lddz);
+      }
+#pragma unroll
+      for (int u = 0; u < GS_U; ++u) {
+        if (p0 + u * rows < HW) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float xe = vget<VEC>(xv[u], e);
+            float du = vget<VEC>(dv[u], e);
+            if (ACT == 1) du *= dsilu_f(xe * a[e] + bb[e]);
+            du *= gc[e];
+            p1 += du;
+            p2 += du * (xe - mean);
+          }
+        }
+      }
+    }
+  }
+  p1 = block_sum(p1, red);
+  p2 = block_sum(p2, red);
+  if (!act_q) return;
+  const float a2 = rstd * rstd * rstd * p2 / n, a3 = rstd * p1 / n;
+  for (int p0 = r; p0 < HW; p0 += rows * GS_U) {
+    V xv[GS_U], dv[GS_U], av[GS_U];
+#pragma unroll
+    for (int u = 0; u < GS_U; ++u) {
+      const int p = p0 + u * rows, pc = p < HW ? p : r;
+      xv[u] = *(const V*)(xg + (long)pc * ldx);
+      dv[u] = *(const V*)(dg + (long)pc * lddz);
+      if (ag) av[u] = *(const V*)(ag + (long)pc * ldadd);
+    }
+#pragma unroll
+    for (int u = 0; u < GS_U; ++u) {
+      const int p = p0 + u * rows;
+      if (p < HW) {
+        V o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float xe = vget<VEC>(xv[u], e);
+          float du = vget<VEC>(dv[u], e);
+          if (ACT == 1) du *= dsilu_f(xe * a[e] + bb[e]);
+          float t = du * gc[e] * rstd - (xe - mean) * a2 - a3;
+          if (ag) t += vget<VEC>(av[u], e);
+          vset<VEC>(o, e, t);
+        }
+        *(V*)(og + (long)p * lddx) = o;
+      }
+    }
+  }
+}
+
+template <int ACT>
+void launch_gn_small_fwd(const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma, const float* beta,
+                         const float* film, int ldfilm, float eps, float* stats, float* coef, hipStream_t s) {
+  const int cpg = C / 32;
+  const bool v4 = !(cpg & 3) && !(ldx & 3) && !(ldy & 3);
+  const int cq = v4 ? cpg / 4 : cpg;
+  int lg = 0;
+  while ((1 << lg) < cq) ++lg;
+  if (v4)
+    hipLaunchKernelGGL((gn_small_fwd_kernel<ACT, 4>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps,
+                       stats, coef);
+  else
+    hipLaunchKernelGGL((gn_small_fwd_kernel<ACT, 1>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps,
+                       stats, coef);
+}
+
+template <int ACT>
+void launch_gn_small_bwd(const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add, int ldadd, int B, int HW,
+                         int C, const float* stats, const float* coef, hipStream_t s) {
+  const int cpg = C / 32;
+  const bool v4 = !(cpg & 3) && !(ldx & 3) && !(lddz & 3) && !(lddx & 3) && !(ldadd & 3);
+  const int cq = v4 ? cpg / 4 : cpg;
+  int lg = 0;
+  while ((1 << lg) < cq) ++lg;
+  if (v4)
+    hipLaunchKernelGGL((gn_small_bwd_kernel<ACT, 4>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C, lg, stats,
+                       coef);
+  else
+    hipLaunchKernelGGL((gn_small_bwd_kernel<ACT, 1>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C, lg, stats,
+                       coef);
+}
+
+constexpr int GN_SMALL_HW = 1024;  // <= 32x32 pixels: launch-bound sizes
+
 int pick_chunk(int HW, int B) {
   // aim at >= ~1024 workgroups for big tensors, >= 8 pixels per chunk
   int chunk = HW * B / 1024;
@@ -406,6 +651,14 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  if (HW <= GN_SMALL_HW) {
+    if (act)
+      launch_gn_small_fwd<1>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s);
+    else
+      launch_gn_small_fwd<0>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s);
+    CGD_HIP(ctx, hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ldx, HW, C, chunk, part);
   hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(64), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats, gamma, beta, film,
                      ldfilm, coef);
@@ -422,6 +675,14 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  if (HW <= GN_SMALL_HW) {
+    if (act)
+      launch_gn_small_bwd<1>(x, ldx, dz, lddz, dx, lddx, add, ldadd, B, HW, C, stats, coef, s);
+    else
+      launch_gn_small_bwd<0>(x, ldx, dz, lddz, dx, lddx, add, ldadd, B, HW, C, stats, coef, s);
+    CGD_HIP(ctx, hipGetLastError());
+    return 0;
+  }
   if (act) {
     hipLaunchKernelGGL((gn_bwd_partial_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, HW, C, chunk, coef, part);
   } else {

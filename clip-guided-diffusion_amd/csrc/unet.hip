@@ -517,8 +517,7 @@ int UNet::forward(const float* x, const float* t, const int64_t* y, float* out, 
     const int ct = h.C + sk.C;
     const long np = (long)B * ch * cw;
     CGD_TRY(ensure(cats[k], (size_t)np * ct));
-    CGD_TRY(cgd_launch_copy2d(ctx, h.p, h.ld, nullptr, 0, cats[k].p, ct, np, h.C, s));
-    CGD_TRY(cgd_launch_copy2d(ctx, sk.p, sk.ld, nullptr, 0, cats[k].p + h.C, ct, np, sk.C, s));
+    CGD_TRY(cgd_launch_concat2(ctx, h.p, h.ld, h.C, sk.p, sk.ld, sk.C, cats[k].p, ct, np, s));
     cat_c1.push_back(h.C);
     cat_hw.push_back({ch, cw});
     h = TV{cats[k].p, ct, ct};

@@ -18,7 +18,7 @@ SHAPES = [  # (H=W, Cin, Cout, launches per step in config 2 (fwd+dgrad, approxi
     (16, 512, 1024, 2), (16, 1024, 1024, 14), (16, 2048, 1024, 3), (16, 1024, 2048, 3), (16, 1536, 1024, 1),
     (8, 1024, 1024, 18), (8, 2048, 1024, 3), (8, 1024, 2048, 3),
 ]
-TILES = [64, 128, 1256, 512]  # 512 = halo-staged conv kernel
+TILES = [128, 1256, 5120, 5121, 5122, 5123]  # 512x = halo-staged conv kernel, scheduling variant x
 
 
 def main():
@@ -38,18 +38,22 @@ def main():
         row = {"H": H, "cin": ci, "cout": co, "count": cnt, "flop": flop, "us": {}}
         line = f"{H:>3d}^2 {ci:>4d}->{co:<4d} x{cnt:<3d}"
         for t in TILES:
-            if ((t % 1000) >= 128 and (H * H < 128 or co < 128)) or (t == 512 and H * H < 256):
+            if ((t % 1000) >= 128 and (H * H < 128 or co < 128)) or (t >= 5120 and H * H < 256):
                 line += f"{'-':>14s}"
                 continue
+            tcode = t
+            if t >= 5120:
+                ctx.check(ctx.lib.cgd_set_hconv(ctx.h, 1 + 16 * (t - 5120), 256))
+                tcode, t = 512, t
             try:
                 for _ in range(3):
-                    ops.conv3x3(ctx, x, w, b, force_tile=t, w_frag=wfrag)
+                    ops.conv3x3(ctx, x, w, b, force_tile=tcode, w_frag=wfrag)
                 th.cuda.synchronize()
                 e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
                 n = 10
                 e0.record()
                 for _ in range(n):
-                    ops.conv3x3(ctx, x, w, b, force_tile=t, w_frag=wfrag)
+                    ops.conv3x3(ctx, x, w, b, force_tile=tcode, w_frag=wfrag)
                 e1.record()
                 th.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / n
@@ -64,9 +68,9 @@ def main():
     with open(f"gpurun_out/ops_{tag}.json", "w") as f:
         json.dump(res, f, indent=1)
     # best-per-shape projection
-    tot_best = sum(min(v for v in r["us"].values() if v) * r["count"] for r in res)
-    tot_cur = sum((r["us"].get("1256") or r["us"].get("128") or r["us"].get("64")) * r["count"] for r in res)
-    tot_h = sum((r["us"].get("512") or r["us"].get("128") or r["us"].get("64")) * r["count"] for r in res)
+    tot_best = sum(min([v for v in r["us"].values() if v] or [0]) * r["count"] for r in res)
+    tot_cur = sum((r["us"].get("1256") or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
+    tot_h = sum((r["us"].get("5121") or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
     print(f"halo conv kernel wherever supported: {tot_h / 1e3:.2f} ms")
     print(f"projected conv time/step: default-ish {tot_cur / 1e3:.2f} ms, best-per-shape {tot_best / 1e3:.2f} ms")
 

@@ -136,7 +136,9 @@ def check_norm():
     ctx = _ctx(1)
     out = []
     for (B, HW, Cc, film, act) in [(2, 96, 64, False, 1), (1, 1024, 192, True, 1), (2, 64, 1344, True, 1), (1, 4096, 256, False, 0),
-                                   (3, 16, 2048, True, 1), (1, 300, 96, False, 1)]:
+                                   (3, 16, 2048, True, 1), (1, 300, 96, False, 1),
+                                   # > 4096 pixels: the chunked 3-kernel path (smaller maps take the single-launch kernel)
+                                   (1, 8192, 64, False, 1), (2, 5000, 96, True, 1), (1, 16384, 160, True, 0)]:
         x = th.randn(B, HW, Cc, generator=g(20)) * 2 + 0.7
         gamma = 1 + 0.1 * th.randn(Cc, generator=g(21))
         beta = 0.1 * th.randn(Cc, generator=g(22))
