@@ -49,11 +49,22 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __re
     float4 k4 = *(const float4*)(xb + (long)p0 * ldx + q * 4);
     float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
     if (m.active) {
-      for (int p = p0 + m.r; p < p1; p += m.rows) {
-        const float4 v = *(const float4*)(xb + (long)p * ldx + q * 4);
-        const float dx = v.x - k4.x, dy = v.y - k4.y, dz = v.z - k4.z, dw = v.w - k4.w;
-        s.x += dx; s.y += dy; s.z += dz; s.w += dw;
-        ss.x += dx * dx; ss.y += dy * dy; ss.z += dz * dz; ss.w += dw * dw;
+      // 4 independent loads in flight per thread: these kernels are latency-, not bandwidth-limited per wavefront
+      for (int pb = p0 + m.r; pb < p1; pb += 4 * m.rows) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = pb + u * m.rows;
+          v[u] = *(const float4*)(xb + (long)(p < p1 ? p : pb) * ldx + q * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (pb + u * m.rows < p1) {
+            const float dx = v[u].x - k4.x, dy = v[u].y - k4.y, dz = v[u].z - k4.z, dw = v[u].w - k4.w;
+            s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+            ss.x += dx * dx; ss.y += dy * dy; ss.z += dz * dz; ss.w += dw * dw;
+          }
+        }
       }
     }
     if (m.rows > 1) {
@@ -156,17 +167,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     if (q >= m.cq) break;
     const float4* cf = (const float4*)(coef + ((long)b * C + q * 4) * 4);
     const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
-    for (int p = p0 + m.r; p < p1; p += m.rows) {
-      const float4 v = *(const float4*)(xb + (long)p * ldx + q * 4);
-      float4 o;
-      o.x = v.x * c0.x + c0.y;
-      o.y = v.y * c1.x + c1.y;
-      o.z = v.z * c2.x + c2.y;
-      o.w = v.w * c3.x + c3.y;
-      if (ACT == 1) {
-        o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w);
+    for (int pb = p0 + m.r; pb < p1; pb += 4 * m.rows) {
+      float4 vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = pb + u * m.rows;
+        vv[u] = *(const float4*)(xb + (long)(p < p1 ? p : pb) * ldx + q * 4);
       }
-      *(float4*)(yb + (long)p * ldy + q * 4) = o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = pb + u * m.rows;
+        if (p < p1) {
+          const float4 v = vv[u];
+          float4 o;
+          o.x = v.x * c0.x + c0.y;
+          o.y = v.y * c1.x + c1.y;
+          o.z = v.z * c2.x + c2.y;
+          o.w = v.w * c3.x + c3.y;
+          if (ACT == 1) {
+            o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w);
+          }
+          *(float4*)(yb + (long)p * ldy + q * 4) = o;
+        }
+      }
     }
   }
 }
@@ -192,9 +215,19 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
     const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     if (m.active) {
-      for (int p = p0 + m.r; p < p1; p += m.rows) {
-        const float4 v = *(const float4*)(xb + (long)p * ldx + q * 4);
-        float4 d = *(const float4*)(db + (long)p * lddz + q * 4);
+      for (int pb = p0 + m.r; pb < p1; pb += 4 * m.rows) {
+       float4 vv[4], dd[4];
+#pragma unroll
+       for (int u = 0; u < 4; ++u) {
+         const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
+         vv[u] = *(const float4*)(xb + (long)pc * ldx + q * 4);
+         dd[u] = *(const float4*)(db + (long)pc * lddz + q * 4);
+       }
+#pragma unroll
+       for (int u = 0; u < 4; ++u) {
+        if (pb + u * m.rows >= p1) continue;
+        const float4 v = vv[u];
+        float4 d = dd[u];
         if (ACT == 1) {
           d.x *= dsilu_f(v.x * c0.x + c0.y);
           d.y *= dsilu_f(v.y * c1.x + c1.y);
@@ -203,6 +236,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
         }
         s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
         s2.x += d.x * (v.x - c0.w); s2.y += d.y * (v.y - c1.w); s2.z += d.z * (v.z - c2.w); s2.w += d.w * (v.w - c3.w);
+       }
       }
     }
     if (m.rows > 1) {
@@ -290,9 +324,21 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const float4* bf = (const float4*)(bcoef + ((long)b * C + q * 4) * 4);
     const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
     const float4 b0 = bf[0], b1 = bf[1], b2 = bf[2], b3 = bf[3];
-    for (int p = p0 + m.r; p < p1; p += m.rows) {
-      const float4 v = *(const float4*)(xb + (long)p * ldx + q * 4);
-      float4 d = *(const float4*)(db + (long)p * lddz + q * 4);
+    for (int pb = p0 + m.r; pb < p1; pb += 4 * m.rows) {
+     float4 vv[4], dd[4], aa[4];
+#pragma unroll
+     for (int u = 0; u < 4; ++u) {
+       const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
+       vv[u] = *(const float4*)(xb + (long)pc * ldx + q * 4);
+       dd[u] = *(const float4*)(db + (long)pc * lddz + q * 4);
+       if (ab) aa[u] = *(const float4*)(ab + (long)pc * ldadd + q * 4);
+     }
+#pragma unroll
+     for (int u = 0; u < 4; ++u) {
+      const int p = pb + u * m.rows;
+      if (p >= p1) continue;
+      const float4 v = vv[u];
+      float4 d = dd[u];
       if (ACT == 1) {
         d.x *= dsilu_f(v.x * c0.x + c0.y);
         d.y *= dsilu_f(v.y * c1.x + c1.y);
@@ -305,10 +351,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       o.z = d.z * b2.x - (v.z - c2.w) * b2.y - b2.z;
       o.w = d.w * b3.x - (v.w - c3.w) * b3.y - b3.z;
       if (ab) {
-        const float4 a = *(const float4*)(ab + (long)p * ldadd + q * 4);
+        const float4 a = aa[u];
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
       }
       *(float4*)(ob + (long)p * lddx + q * 4) = o;
+     }
     }
   }
 }
@@ -614,7 +661,16 @@ void launch_gn_small_bwd(const float* x, int ldx, const float* dz, int lddz, flo
                        coef);
 }
 
-constexpr int GN_SMALL_HW = 1024;  // <= 32x32 pixels: launch-bound sizes
+// <= 32x32 pixels: launch-bound sizes take the single-launch kernels (CGD_GN_SMALL_HW overrides, for tuning)
+static int gn_small_hw() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CGD_GN_SMALL_HW");
+    v = e ? atoi(e) : 1024;
+  }
+  return v;
+}
+#define GN_SMALL_HW gn_small_hw()
 
 int pick_chunk(int HW, int B) {
   // aim at >= ~1024 workgroups for big tensors, >= 8 pixels per chunk
