@@ -7,8 +7,10 @@ batch 1, CLIP ViT-B/32, clip_guidance_scale 1000 / tv 150 / range 50, randomize_
 N GPUs run N independent samples (1 per GPU, no per-step collective; one RCCL broadcast of the packed weights at init).
 
 Prints ONE JSON line (see the driver contract) with two extra objects:
-  roofline     : dominant kernel = MFMA implicit-GEMM conv/GEMM (`igemm_kernel`): algorithmic FLOP of all its launches
-                 in the timed region / their summed HIP-event duration, against the dense bf16 MFMA peak (2.5 PF/s).
+  roofline     : dominant kernel = the halo-staged MFMA 3x3 conv (`hconv_kernel`, 44% of the step): algorithmic FLOP of its
+                 launches in the timed region / their summed HIP-event duration (events recorded by the library on the launch
+                 stream), against the dense bf16 MFMA peak (2.5 PF/s).  bf16x3 issues 3 MFMA products per algorithmic product
+                 (`mfma_issue_frac` = 3 x frac).  `traffic` = HBM bytes/launch from the committed PMC passes (profiles/).
   cpu_baseline : the CPU oracle (plain PyTorch fp32 port of the reference path) timed on the host cores (rank 0, N=1).
 """
 import argparse
@@ -49,6 +51,17 @@ def build_device(ctx, rank, world, precision, clip_name="ViT-B/32"):
     targets = th.randn(1, clip.out_dim, generator=gt).to(dev)
     guid = dg.ClipGuidance(ctx, unet, clip, smp, targets, [1.0], 16, clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0)
     return unet, clip, smp, guid
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (tests/run_profile.sh ->
+    profiles/pmc_traffic.json: FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE); None when not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f)["kernels"][kernel]
+        return rec["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def usable_cores(cap=64):
@@ -183,16 +196,20 @@ def main():
     dt = time.perf_counter() - t0
     roof = None
     if prof:
-        buf = (C.c_double * 3)()
+        buf = (C.c_double * 6)()
         ctx.check(ctx.lib.cgd_profile_read(ctx.h, buf))
         ctx.check(ctx.lib.cgd_profile(ctx.h, 0))
-        gemm_ms, gemm_flop, launches = buf[0], buf[1], buf[2]
-        ach = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": f"igemm_kernel<{args.precision}> (implicit-GEMM conv3x3 / GEMM)", "achieved": round(ach, 2),
-                "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
-                "launches_per_step": launches / args.steps, "avg_launch_us": round(gemm_ms * 1e3 / max(launches, 1), 2),
-                "flop_per_launch": gemm_flop / max(launches, 1), "kernel_time_share": round(gemm_ms * 1e-3 / dt, 4),
-                "mfma_products_per_flop": {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]}
+        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n = list(buf)
+        ach = h_flop / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
+        nprod = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+        roof = {"bound": "mfma", "kernel": f"hconv_kernel<{args.precision}> (halo-staged 3x3 conv, hconv.hip)", "achieved": round(ach, 2),
+                "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": pmc_traffic("hconv_kernel"),
+                "launches_per_step": h_n / args.steps, "avg_launch_us": round(h_ms * 1e3 / max(h_n, 1), 2),
+                "flop_per_launch": h_flop / max(h_n, 1), "kernel_time_share": round(h_ms * 1e-3 / dt, 4),
+                "mfma_products_per_flop": nprod, "mfma_issue_frac": round(nprod * ach / 2500.0, 4),
+                "other_mfma_kernel": {"kernel": "igemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / args.steps,
+                                      "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
+                                      "kernel_time_share": round(ig_ms * 1e-3 / dt, 4)}}
     assert th.isfinite(out["sample"]).all().item(), "non-finite sample"
     tmax = th.tensor([dt], device=dev, dtype=th.float64)
     if world > 1:

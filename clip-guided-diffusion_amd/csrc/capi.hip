@@ -63,14 +63,17 @@ int cgd_profile(cgd_ctx* ctx, int enable) {
   return 0;
 }
 
-// out[0] = summed MFMA GEMM/conv time (ms), out[1] = summed algorithmic FLOP, out[2] = launches; resets the records
+// out[0..2] = igemm_kernel launches (with their split-K reduce): summed time (ms), algorithmic FLOP, launches;
+// out[3..5] = the same for hconv_kernel launches alone.  Resets the records.
 int cgd_profile_read(cgd_ctx* ctx, double* out) {
   CGD_HIP(ctx, hipDeviceSynchronize());
   CGD_TRY(cgd_prof_fold(ctx, 0));
-  out[0] = ctx->prof_ms;
-  out[1] = ctx->prof_flops;
-  out[2] = ctx->prof_n;
-  ctx->prof_ms = ctx->prof_flops = ctx->prof_n = 0.0;
+  for (int k = 0; k < 2; ++k) {
+    out[3 * k + 0] = ctx->prof_ms[k];
+    out[3 * k + 1] = ctx->prof_flops[k];
+    out[3 * k + 2] = ctx->prof_n[k];
+    ctx->prof_ms[k] = ctx->prof_flops[k] = ctx->prof_n[k] = 0.0;
+  }
   return 0;
 }
 }  // extern "C"
@@ -83,9 +86,9 @@ int cgd_prof_fold(cgd_ctx* ctx, size_t keep_last) {
     float t = 0.f;
     CGD_HIP(ctx, hipEventSynchronize(r.b));  // long retired for everything but the newest records
     CGD_HIP(ctx, hipEventElapsedTime(&t, r.a, r.b));
-    ctx->prof_ms += t;
-    ctx->prof_flops += r.flops;
-    ctx->prof_n += 1.0;
+    ctx->prof_ms[r.kind] += t;
+    ctx->prof_flops[r.kind] += r.flops;
+    ctx->prof_n[r.kind] += 1.0;
     ctx->prof_pool.push_back(r.a);
     ctx->prof_pool.push_back(r.b);
   }

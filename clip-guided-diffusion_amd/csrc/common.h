@@ -16,6 +16,7 @@ enum { CGD_PREC_F32 = 0, CGD_PREC_BF16X3 = 1, CGD_PREC_BF16 = 2 };
 struct ProfRec {
   hipEvent_t a, b;
   double flops;
+  int kind;  // 0: igemm_kernel (+ its split-K reduce), 1: hconv_kernel alone (the dominant kernel of the step)
 };
 
 struct cgd_ctx {
@@ -32,7 +33,7 @@ struct cgd_ctx {
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
-  double prof_ms = 0.0, prof_flops = 0.0, prof_n = 0.0;  // folded totals of already-retired records
+  double prof_ms[2] = {0.0, 0.0}, prof_flops[2] = {0.0, 0.0}, prof_n[2] = {0.0, 0.0};  // folded totals per ProfRec::kind
 };
 
 // fold the oldest records (all but `keep_last`) into the running totals and recycle their events

@@ -466,10 +466,12 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     CGD_TRY(get(&pr.a));
     CGD_TRY(get(&pr.b));
     pr.flops = 2.0 * p.M * p.N * p.K * p.nbatch;
+    pr.kind = use_h ? 1 : 0;
     CGD_HIP(ctx, hipEventRecord(pr.a, s));
   }
   if (use_h) {
     CGD_TRY(cgd_launch_hconv(ctx, p, s));
+    if (ctx->prof_on) CGD_HIP(ctx, hipEventRecord(pr.b, s));  // the halo conv kernel alone, without its split-K reduce
   } else {
     switch (ctx->precision) {
       case CGD_PREC_F32: CGD_TRY(launch_mode<0>(ctx, p, tile, s)); break;
@@ -484,7 +486,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
                        p.ldr, p.alpha);
   }
   if (ctx->prof_on) {
-    CGD_HIP(ctx, hipEventRecord(pr.b, s));
+    if (!use_h) CGD_HIP(ctx, hipEventRecord(pr.b, s));
     ctx->prof_recs.push_back(pr);
   }
   CGD_HIP(ctx, hipGetLastError());

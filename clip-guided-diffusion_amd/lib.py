@@ -133,6 +133,10 @@ class Context:
         self.device = int(device)
         if precision is not None:
             self.set_precision(precision)
+        tiles = os.environ.get("CGD_TILES")  # tuning only: "<large>,<small>" igemm tile codes (see cgd_set_tiles)
+        if tiles:
+            large, small = (int(v) for v in tiles.split(","))
+            self.check(self.lib.cgd_set_tiles(self.h, large, small))
 
     def check(self, rc):
         if rc != 0:

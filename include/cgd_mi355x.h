@@ -37,11 +37,12 @@ int cgd_set_precision(cgd_ctx* ctx, int mode);
 int cgd_get_precision(cgd_ctx* ctx);
 const char* cgd_version(void);
 /* HIP-event timing of every MFMA GEMM/conv launch on its own stream (measurement only; bench.py roofline leg).
- * cgd_profile_read: out[0] = summed kernel time (ms), out[1] = summed algorithmic FLOP, out[2] = launches; resets. */
+ * cgd_profile_read: out[0..2] = igemm_kernel launches incl. their split-K reduce {summed ms, algorithmic FLOP, launches},
+ * out[3..5] = the same for hconv_kernel launches alone (the dominant kernel); resets. */
 /* tuning knob: GEMM tile codes for the automatic selection (64, 128, 256 = 256x128, 257 = 128x256; +1000 = 2-deep prefetch) */
 int cgd_set_tiles(cgd_ctx* ctx, int large_tile, int small_tile);
 int cgd_profile(cgd_ctx* ctx, int enable);
-int cgd_profile_read(cgd_ctx* ctx, double* out3);
+int cgd_profile_read(cgd_ctx* ctx, double* out6);
 
 /* ---- UNet epsilon/sigma predictor: replaces guided_diffusion.unet.UNetModel built at
  *      /root/reference/cgd/script_util.py:316 from /root/reference/data/diffusion_model_flags.py ---- */

@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BE
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $BENCH > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o m -- $BENCH > "$OUT/pmc_mfma.log" 2>&1
-python "$ROOT/tests/summarize_profile.py" "$OUT" > "$OUT/summary.txt" 2>&1
+python "$ROOT/tests/summarize_profile.py" "$OUT" "$OUT/pmc_traffic.json" > "$OUT/summary.txt" 2>&1
 # keep the merged-back payload small: the raw per-dispatch CSVs of the PMC passes are reduced to the summary
 find "$OUT" -name '*kernel_trace.csv' -size +20M -delete
 tail -40 "$OUT/summary.txt"

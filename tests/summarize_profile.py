@@ -57,5 +57,32 @@ def main():
             print(f"{k:<72s}{cells}")
 
 
+def traffic_json(root, out_path):
+    """Per-kernel HBM bytes per launch: FETCH_SIZE and WRITE_SIZE are reported in KiB; gfx950 counts a wide (16 B/lane)
+    coalesced read at half its bytes (MI355X_MICROARCH.md, HBM section) -> reads x2."""
+    import json
+    fetch, write = pmc(root, "pmc_fetch"), pmc(root, "pmc_write")
+    ks = {short(r["Name"]): r for r in kernel_stats(root)}
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, tests/run_profile.sh",
+           "correction": "hbm_bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024", "kernels": {}}
+    for k in fetch:
+        f = fetch[k].get("FETCH_SIZE")
+        w = write.get(k, {}).get("WRITE_SIZE")
+        if not f or not w:
+            continue
+        fb, wb = f[0] / max(f[1], 1) * 1024 * 2, w[0] / max(w[1], 1) * 1024
+        key = k.split("<")[0]
+        rec = {"full_name": k, "launches_sampled": f[1], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+               "hbm_bytes_per_launch": fb + wb}
+        if k in ks:
+            rec["avg_us_kernel_trace"] = float(ks[k]["AverageNs"]) / 1e3
+        if key not in out["kernels"] or out["kernels"][key]["launches_sampled"] < f[1]:
+            out["kernels"][key] = rec
+    with open(out_path, "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
 if __name__ == "__main__":
     main()
+    if len(sys.argv) > 2:
+        traffic_json(sys.argv[1], sys.argv[2])
