@@ -409,7 +409,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   bool auto_split = p.splitk == 1 && p.nbatch == 1;
   // halo-staged conv kernel (hconv.hip): tile code 512
   bool use_h = false;
-  if (cgd_hconv_supported(p, ctx->precision)) use_h = tile == 512 || (!tile && ctx->hconv_mode && p.M >= ctx->hconv_min_m);
+  if (cgd_hconv_supported(ctx, p)) use_h = tile == 512 || (!tile && ctx->hconv_mode && p.M >= ctx->hconv_min_m);
   if (tile == 512 && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel does not support this problem");
   if (use_h) {
     tile = 512;

@@ -267,6 +267,266 @@ __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// hconv2: same operands and packed weights, re-tiled and software-pipelined.
+//   * tile = 16 x 16 pixels (any H, W that are multiples of 16): the halo patch is 18 x 18 = 324 rows (1.27x the tile,
+//     against 3.0x for a 256-wide row segment), 6 staging passes instead of 13 -> 28 fewer registers, 51.8 KB per buffer;
+//   * the patch is DOUBLE-buffered in LDS (103,680 B): chunk c+1 is loaded at the start of chunk c, converted and written
+//     into the other buffer in the middle of chunk c's taps (VALU/LDS work hidden under MFMA), ONE barrier per chunk;
+//   * explicit register software pipeline over the 18 k-steps of a chunk: A fragments (ds_read_b128) one k-step ahead,
+//     B fragments (global -> registers) two k-steps ahead in a 3-deep ring (18 % 3 == 0, so the ring is chunk-periodic and
+//     runs across chunk boundaries without a drain); sched_barrier keeps "issue loads" and "MFMA" sections apart;
+//   * MFMA operands are swapped (D = W_frag x X_frag^T): a lane then owns 4 consecutive output CHANNELS of one pixel per
+//     accumulator quad, so residual loads and output stores are 16-byte accesses along the NHWC channel axis.
+constexpr int TS = 16, PW2 = TS + 2, NP2 = PW2 * PW2;  // 324 patch rows
+constexpr int NPASS2 = 6;                               // ceil(324 / 64)
+
+// DBG (timing experiments only, results are wrong): 1 = no B-fragment loads in the loop, 2 = no A-fragment LDS reads,
+// 4 = no patch global loads, 8 = no patch convert + LDS store, 16 = B-fragment loads always from chunk 0 (L1 hits)
+template <int MODE, int DBG = 0, int SCHED = 0>
+__global__ __launch_bounds__(512) void hconv2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+                                                     const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
+                                                     const HConvParams p) {
+  constexpr int NPL = MODE == 1 ? 2 : 1;   // bf16 planes (hi, lo)
+  constexpr int PLANE = NP2 * HPH;         // elements per plane
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int ntn = (p.N + HB_N - 1) / HB_N;
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = bid / ntn, n0 = (bid % ntn) * HB_N;
+  const int tpr = p.W >> 4, tpi = (p.H >> 4) * tpr;
+  const int img = mt / tpi, trem = mt - img * tpi;
+  const int y0 = (trem / tpr) << 4, x0 = (trem % tpr) << 4;
+  const int HW = p.H * p.W;
+  const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
+  const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
+
+  // per-thread patch staging slots: 64 patch rows per pass, 8 float4 per row
+  const int c4 = tid & 7;
+  int poff[NPASS2];
+#pragma unroll
+  for (int j = 0; j < NPASS2; ++j) {
+    const int prow = (tid >> 3) + 64 * j;
+    poff[j] = -2;  // beyond the patch
+    if (prow < NP2) {
+      const int py = prow / PW2, px = prow - py * PW2;
+      int yy = y0 + py - 1, xx = x0 + px - 1;
+      const bool inb = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      if (p.ups) {
+        yy >>= 1;
+        xx >>= 1;
+      }
+      poff[j] = inb ? (yy * Ws + xx) * p.lda + c4 * 4 : -1;  // -1: zero padding
+    }
+  }
+  // this lane's two pixels (one per 32-pixel block of the wavefront's 64): patch row and output row
+  int fro[2];
+  long mrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = wm * 64 + i * 32 + l31;
+    const int ty = pix >> 4, tx = pix & 15;
+    fro[i] = (ty * PW2 + tx) * HPH + hh * 8;
+    mrow[i] = (long)img * HW + (long)(y0 + ty) * p.W + x0 + tx;
+  }
+
+  const int nchunk = p.Cin >> 5;
+  int c0 = 0, c1 = nchunk;
+  if (p.splitk > 1) {
+    const int per = (nchunk + p.splitk - 1) / p.splitk;
+    c0 = blockIdx.z * per;
+    c1 = min(nchunk, c0 + per);
+  }
+  const int nb0 = (n0 + wn * 64) >> 5;
+  const int nbN = p.N >> 5;
+  const long bstride_nb = (long)nchunk * 9 * 4 * 64;
+  const int nbc = nb0 < nbN ? nb0 : nbN - 1;  // clamped first block
+  const long bj1 = (nb0 + 1 < nbN) ? bstride_nb : 0;
+  const uint4* __restrict__ Bw0 = Bg + (long)nbc * bstride_nb + lane;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 pr[NPASS2];
+  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define PATCH_LOAD2(CH)                                                                             \
+  {                                                                                                 \
+    const float* __restrict__ Ac = Aimg + (CH) * 32;                                                \
+    _Pragma("unroll") for (int j = 0; j < NPASS2; ++j)                                              \
+        pr[j] = *(const f32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4)); /* zeroed at store time */  \
+  }
+#define PATCH_STORE2(DSTB, J0, J1)                                                                  \
+  {                                                                                                 \
+    _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                               \
+      if (j < NPASS2 - 1 || poff[j] != -2) { /* only the last pass has rows beyond the patch */     \
+        const int prow = (tid >> 3) + 64 * j;                                                       \
+        const f32x4 v = poff[j] >= 0 ? pr[j] : z4;                                                  \
+        const bf16x4 hi = to_bf16x4(v);                                                             \
+        *(bf16x4*)&(DSTB)[prow * HPH + c4 * 4] = hi;                                                \
+        if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + prow * HPH + c4 * 4] = to_bf16x4(residual4(v, hi)); \
+      }                                                                                             \
+    }                                                                                               \
+  }
+  // A fragments of k-step (TAP, KS): [pixel block i][plane]
+#define A_LOAD2(DST, SRCB, TAP, KS)                                                                 \
+  {                                                                                                 \
+    constexpr int o_ = (((TAP) / 3) * PW2 + ((TAP) % 3)) * HPH + (KS) * 16;                         \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+      DST[i][0] = *(const bf16x8*)&(SRCB)[fro[i] + o_];                                             \
+      if constexpr (MODE == 1) DST[i][1] = *(const bf16x8*)&(SRCB)[PLANE + fro[i] + o_];            \
+    }                                                                                               \
+  }
+  // B fragments of k-step (TAP, KS) of the chunk whose block base is BASE: [channel block j][plane]
+#define B_LOAD2(DST, BASE, TAP, KS)                                                                 \
+  {                                                                                                 \
+    const uint4* q_ = (BASE) + ((TAP) * 4 + (KS) * 2) * 64;                                         \
+    DST[0][0] = q_[0];                                                                              \
+    if constexpr (MODE == 1) DST[0][1] = q_[64];                                                    \
+    DST[1][0] = q_[bj1];                                                                            \
+    if constexpr (MODE == 1) DST[1][1] = q_[bj1 + 64];                                              \
+  }
+  // 12 MFMAs of one k-step; product-major so that the same accumulator recurs only every 4th instruction
+#define MFMA12(AQ, BQ)                                                                              \
+  {                                                                                                 \
+    if constexpr (MODE == 1) {                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)   \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[j][0]), AQ[i][1], acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)   \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[j][1]), AQ[i][0], acc[i][j], 0, 0, 0); \
+    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[j][0]), AQ[i][0], acc[i][j], 0, 0, 0); \
+  }
+
+  bf16x8 af[2][2][NPL];  // [pipeline slot][pixel block][plane]
+  uint4 bq[3][2][NPL];   // [ring slot][channel block][plane]
+  if (c0 < c1) {
+    PATCH_LOAD2(c0);
+    const uint4* __restrict__ cb = Bw0 + (long)c0 * (9 * 4 * 64);
+    B_LOAD2(bq[0], cb, 0, 0);
+    B_LOAD2(bq[1], cb, 0, 1);
+    PATCH_STORE2(lds, 0, NPASS2);
+  }
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    const bool more = c + 1 < c1;
+    const __bf16* cur = lds + ((c - c0) & 1) * (NPL * PLANE);
+    __bf16* nxt = lds + (((c - c0) & 1) ^ 1) * (NPL * PLANE);
+    const uint4* __restrict__ cb = Bw0 + (long)((DBG & 16) ? 0 : c) * (9 * 4 * 64);
+    const uint4* __restrict__ nb = Bw0 + (long)((DBG & 16) ? 0 : (c + 1 < nchunk ? c + 1 : c)) * (9 * 4 * 64);  // clamped: loads stay unconditional
+    if (more && !(DBG & 4)) PATCH_LOAD2(c + 1);  // in flight during the first taps
+    A_LOAD2(af[0], cur, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+      // ---- issue section: A fragments one k-step ahead, B fragments two k-steps ahead
+      if (q + 1 < 18 && !(DBG & 2)) {
+        switch (q + 1) {  // (tap, ks) must be compile-time constants for the LDS immediates
+#define CASE_A(Q) case Q: A_LOAD2(af[(Q) & 1], cur, (Q) >> 1, (Q) & 1); break;
+          CASE_A(1) CASE_A(2) CASE_A(3) CASE_A(4) CASE_A(5) CASE_A(6) CASE_A(7) CASE_A(8) CASE_A(9)
+          CASE_A(10) CASE_A(11) CASE_A(12) CASE_A(13) CASE_A(14) CASE_A(15) CASE_A(16) CASE_A(17)
+#undef CASE_A
+        }
+      }
+      if (!(DBG & 1)) {
+        const int q2 = (q + 2) % 18;
+        const uint4* __restrict__ base = (q + 2 < 18) ? cb : nb;
+        B_LOAD2(bq[(q + 2) % 3], base, q2 >> 1, q2 & 1);
+      }
+      if constexpr (SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+      // ---- MFMA section (the patch conversion of the next chunk rides under taps 4..6)
+      MFMA12(af[(DBG & 2) ? 0 : (q & 1)], bq[(DBG & 1) ? 0 : (q % 3)]);
+      if constexpr (SCHED == 0) {
+        if (more && !(DBG & 8)) {
+          if (q == 8) PATCH_STORE2(nxt, 0, 2);
+          if (q == 10) PATCH_STORE2(nxt, 2, 4);
+          if (q == 12) PATCH_STORE2(nxt, 4, NPASS2);
+        }
+      } else {
+        // unconditional (the last chunk rewrites the idle buffer with stale data): no branch inside the scheduling region
+        if (q == 6) PATCH_STORE2(nxt, 0, 1);
+        if (q == 7) PATCH_STORE2(nxt, 1, 2);
+        if (q == 8) PATCH_STORE2(nxt, 2, 3);
+        if (q == 9) PATCH_STORE2(nxt, 3, 4);
+        if (q == 10) PATCH_STORE2(nxt, 4, 5);
+        if (q == 11) PATCH_STORE2(nxt, 5, 6);
+        // fine-grained interleave inside this k-step: every MFMA is followed by one load of the next k-steps and a few
+        // VALU / LDS-write instructions of the patch conversion, so the wavefront's own MFMA queue never drains
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+          if (r % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          if (r % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                  // VALU
+          if (r % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+        }
+      }
+      if ((DBG & 8) && !(DBG & 4) && q == 12) {
+#pragma unroll
+        for (int j = 0; j < NPASS2; ++j) asm volatile("" ::"v"(pr[j]));  // keep the loads alive
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // patch c fully consumed, patch c+1 fully written
+  }
+#undef PATCH_LOAD2
+#undef PATCH_STORE2
+#undef A_LOAD2
+#undef B_LOAD2
+#undef MFMA12
+
+  // ---- epilogue.  D = W x X^T in the 32x32 C/D layout: column (lane & 31) = pixel, row = channel
+  //      (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5): accumulator quad g holds channels 8g + 4hh .. + 3 of the lane's pixel.
+  if (p.splitk > 1) {
+    float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cb0 = n0 + wn * 64 + j * 32;
+        if (cb0 < p.N) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(f32x4*)&ws[mrow[i] * p.N + cb0 + 8 * g + 4 * hh] =
+                f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cb0 = n0 + wn * 64 + j * 32;
+      if (cb0 >= p.N) continue;
+      f32x4 rv[4];
+      if (Rg) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rv[g] = *(const f32x4*)&Rg[mrow[i] * p.ldr + cb0 + 8 * g + 4 * hh];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = cb0 + 8 * g + 4 * hh;
+        f32x4 o = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} * p.alpha;
+        if (biasg) o += f32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
+        if (Rg) o += rv[g];
+        *(f32x4*)&Cg[mrow[i] * p.ldc + col] = o;
+      }
+    }
+}
+
 // w: torch conv weight [Co][Ci][3][3].  dgrad = 0: B[n=co][tap][k=ci] = w[co][ci][ky][kx];
 // dgrad = 1: B[n=ci][tap][k=co] = w[co][ci][2-ky][2-kx].  Output: fragment order, see header.
 __global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Co, int Ci, int dgrad) {
@@ -307,15 +567,22 @@ int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int 
   return 0;
 }
 
-bool cgd_hconv_supported(const GemmParams& p, int precision) {
-  if (!p.conv || !p.Bpk || precision == CGD_PREC_F32 || p.nbatch != 1) return false;
+bool cgd_hconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
+  if (!p.conv || !p.Bpk || ctx->precision == CGD_PREC_F32 || p.nbatch != 1) return false;
   if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
   if (p.H <= 0 || p.W <= 0) return false;
+  if (p.ups && ((p.H | p.W) & 1)) return false;
+  if (p.M % HB_M) return false;
+  if (ctx->hconv_var & 4) {  // hconv2: 16x16-pixel tiles, 16-byte epilogue accesses
+    if ((p.H & 15) || (p.W & 15)) return false;
+    if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
+    if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
+    return true;
+  }
   const long hw = (long)p.H * p.W;
   if (hw % HB_M) return false;
   if (p.W >= HB_M ? (p.W % HB_M) != 0 : (HB_M % p.W) != 0) return false;
-  if (p.ups && ((p.H | p.W) & 1)) return false;
-  return p.M % HB_M == 0;
+  return true;
 }
 
 int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
@@ -325,7 +592,20 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   dim3 grid((g.M / HB_M) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
 #define HC_LAUNCH(M_, V_) hipLaunchKernelGGL((hconv_kernel<M_, V_>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
-  if (ctx->precision == CGD_PREC_BF16X3) {
+#define HC2_LAUNCH(M_, D_, S_) hipLaunchKernelGGL((hconv2_kernel<M_, D_, S_>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
+  if (ctx->hconv_var & 4) {
+    if (ctx->precision == CGD_PREC_BF16X3) {
+      switch (ctx->hconv_var >> 3) {  // scheduling variants / timing experiments (DBG != 0: wrong results)
+        case 0: HC2_LAUNCH(1, 0, 0); break;
+        case 1: HC2_LAUNCH(1, 0, 1); break;
+        case 2: HC2_LAUNCH(1, 1, 1); break;
+        case 3: HC2_LAUNCH(1, 12, 1); break;
+        default: HC2_LAUNCH(1, 15, 0); break;
+      }
+    } else {
+      HC2_LAUNCH(2, 0, 0);
+    }
+  } else if (ctx->precision == CGD_PREC_BF16X3) {
     switch (ctx->hconv_var & 3) {
       case 0: HC_LAUNCH(1, 0); break;
       case 1: HC_LAUNCH(1, 1); break;
@@ -335,6 +615,7 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   } else {
     HC_LAUNCH(2, 0);
   }
+#undef HC2_LAUNCH
 #undef HC_LAUNCH
   return 0;
 }

@@ -137,6 +137,9 @@ class Context:
         if tiles:
             large, small = (int(v) for v in tiles.split(","))
             self.check(self.lib.cgd_set_tiles(self.h, large, small))
+        hv = os.environ.get("CGD_HCONV_VAR")  # tuning only: halo conv kernel variant (see cgd_set_hconv)
+        if hv:
+            self.check(self.lib.cgd_set_hconv(self.h, 1 + 16 * int(hv), 256))
 
     def check(self, rc):
         if rc != 0:

@@ -10,7 +10,7 @@ import torch as th  # noqa: E402
 import cgd_amd  # noqa: E402,F401
 from cgd_amd import lib, ops  # noqa: E402
 
-SHAPES = [  # (H=W, Cin, Cout, launches per step in config 2 (fwd+dgrad, approximate))
+SHAPES_ALL = [  # (H=W, Cin, Cout, launches per step in config 2 (fwd+dgrad, approximate))
     (256, 256, 256, 18), (256, 512, 256, 3), (256, 256, 512, 3),
     (128, 256, 256, 22), (128, 512, 256, 3), (128, 256, 512, 3),
     (64, 256, 512, 2), (64, 512, 512, 14), (64, 1024, 512, 3), (64, 512, 1024, 3), (64, 768, 512, 1),
@@ -18,7 +18,8 @@ SHAPES = [  # (H=W, Cin, Cout, launches per step in config 2 (fwd+dgrad, approxi
     (16, 512, 1024, 2), (16, 1024, 1024, 14), (16, 2048, 1024, 3), (16, 1024, 2048, 3), (16, 1536, 1024, 1),
     (8, 1024, 1024, 18), (8, 2048, 1024, 3), (8, 1024, 2048, 3),
 ]
-TILES = [128, 1256, 5120, 5121, 5122, 5123]  # 512x = halo-staged conv kernel, scheduling variant x
+SHAPES = [s for s in SHAPES_ALL if s[0] >= 64 and s[3] >= 3][:8]
+TILES = [5121, 5124] + [5124 + 8 * d for d in (1, 2, 3, 4)]  # 512x = halo-staged conv kernel, variant x (1: hconv_kernel, 4: hconv2_kernel)
 
 
 def main():
@@ -70,8 +71,9 @@ def main():
     # best-per-shape projection
     tot_best = sum(min([v for v in r["us"].values() if v] or [0]) * r["count"] for r in res)
     tot_cur = sum((r["us"].get("1256") or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
-    tot_h = sum((r["us"].get("5121") or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
-    print(f"halo conv kernel wherever supported: {tot_h / 1e3:.2f} ms")
+    for code in ("5121", "5124"):
+        tot_h = sum((r["us"].get(code) or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
+        print(f"halo conv kernel {code} wherever supported: {tot_h / 1e3:.2f} ms")
     print(f"projected conv time/step: default-ish {tot_cur / 1e3:.2f} ms, best-per-shape {tot_best / 1e3:.2f} ms")
 
 

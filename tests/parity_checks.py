@@ -83,28 +83,32 @@ def check_conv(precision):
             out.append(rec(f"conv3x3 dgrad[p{precision}] {Ci}<-{Co}", got.permute(0, 3, 1, 2), xr.grad.float()))
     # halo-staged conv kernel (tile code 512): fragment-packed bf16 weights, patch staging, split-K over channel chunks
     if precision != 0:
-        for (Bn, H, W, Ci, Co, ups, sk) in [(1, 256, 256, 32, 64, 0, 1), (2, 16, 16, 64, 160, 0, 1), (1, 32, 32, 128, 128, 0, 2),
-                                            (1, 64, 64, 64, 96, 1, 1), (1, 128, 128, 32, 32, 0, 1), (1, 16, 32, 64, 64, 0, 1),
-                                            (1, 256, 512, 32, 32, 0, 1)]:
-            Hs, Ws = (H // 2, W // 2) if ups else (H, W)
-            x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
-            w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)
-            b = th.randn(Co, generator=g(7))
-            r = th.randn(Bn, H, W, Co, generator=g(17))
-            xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
-            ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).float() + r.permute(0, 3, 1, 2)
-            wf, wd = ops.pack_conv3x3(w)
-            wfrag = ops.pack_conv3x3_frag(ctx, w.to(DEV), dgrad=False)
-            got = ops.conv3x3(ctx, x.permute(0, 2, 3, 1).contiguous().to(DEV), wf.to(DEV), b.to(DEV), R=r.to(DEV), upsample_input=bool(ups),
-                              force_tile=512, splitk=sk, w_frag=wfrag)
-            out.append(rec(f"hconv[p{precision}] B{Bn} {H}x{W} {Ci}->{Co} ups{ups} sk{sk}", got.permute(0, 3, 1, 2), ref))
-            if not ups:
-                dy = th.randn(Bn, Co, H, W, generator=g(8))
-                xr = x.double().requires_grad_()
-                (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
-                wdfrag = ops.pack_conv3x3_frag(ctx, w.to(DEV), dgrad=True)
-                got = ops.conv3x3(ctx, dy.permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None, force_tile=512, splitk=sk, w_frag=wdfrag)
-                out.append(rec(f"hconv dgrad[p{precision}] {H}x{W} {Ci}<-{Co} sk{sk}", got.permute(0, 3, 1, 2), xr.grad.float()))
+        # 1: hconv_kernel (row-segment tiles); 4 / 12: hconv2_kernel (16x16 tiles, double-buffered; sectioned / interleaved issue)
+        for var in (1, 4, 12):
+            ctx.check(ctx.lib.cgd_set_hconv(ctx.h, 1 + 16 * var, 256))
+            for (Bn, H, W, Ci, Co, ups, sk) in [(1, 256, 256, 32, 64, 0, 1), (2, 16, 16, 64, 160, 0, 1), (1, 32, 32, 128, 128, 0, 2),
+                                                (1, 64, 64, 64, 96, 1, 1), (1, 128, 128, 32, 32, 0, 1), (1, 16, 32, 64, 64, 0, 1),
+                                                (1, 256, 512, 32, 32, 0, 1), (2, 48, 32, 32, 64, 0, 1), (1, 32, 32, 256, 64, 0, 3)]:
+                Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+                x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
+                w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)
+                b = th.randn(Co, generator=g(7))
+                r = th.randn(Bn, H, W, Co, generator=g(17))
+                xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+                ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).float() + r.permute(0, 3, 1, 2)
+                wf, wd = ops.pack_conv3x3(w)
+                wfrag = ops.pack_conv3x3_frag(ctx, w.to(DEV), dgrad=False)
+                got = ops.conv3x3(ctx, x.permute(0, 2, 3, 1).contiguous().to(DEV), wf.to(DEV), b.to(DEV), R=r.to(DEV), upsample_input=bool(ups),
+                                  force_tile=512, splitk=sk, w_frag=wfrag)
+                out.append(rec(f"hconv v{var}[p{precision}] B{Bn} {H}x{W} {Ci}->{Co} ups{ups} sk{sk}", got.permute(0, 3, 1, 2), ref))
+                if not ups:
+                    dy = th.randn(Bn, Co, H, W, generator=g(8))
+                    xr = x.double().requires_grad_()
+                    (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
+                    wdfrag = ops.pack_conv3x3_frag(ctx, w.to(DEV), dgrad=True)
+                    got = ops.conv3x3(ctx, dy.permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None, force_tile=512, splitk=sk, w_frag=wdfrag)
+                    out.append(rec(f"hconv v{var} dgrad[p{precision}] {H}x{W} {Ci}<-{Co} sk{sk}", got.permute(0, 3, 1, 2), xr.grad.float()))
+        ctx.check(ctx.lib.cgd_set_hconv(ctx.h, 1 + 16 * 12, 256))  # back to the default variant
     # thin ends
     x = th.randn(2, 3, 16, 24, generator=g(9))
     w = th.randn(64, 3, 3, 3, generator=g(10)) / math.sqrt(27)
