@@ -176,6 +176,269 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
   }
 }
 
+
+// ---- fused attention for the UNet's 16x16 / 32x32 levels (T = 256 / 1024, d = 64) -----------------------------------
+// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) on LDS tiles; no transposes, no batched GEMM launches, P is written once.
+//   forward : one workgroup per (32 query rows, head): pass 1 = row max / sum over all key blocks, pass 2 = P = softmax
+//             (written to global for the backward) and O += P V.  O is also copied into bufs.qkvT for the backward.
+//   backward: dq kernel per (32 query rows, head): D = rowsum(dO * O), dP = dO V^T, dS = P (dP - D) (written to global),
+//             dQ += dS K;   dkv kernel per (32 keys, head): dV = P^T dO, dK = dS^T Q.
+// MFMA operand k-mapping: step e of group m contracts k = 8m + e (lanes 0-31) and k = 8m + 4 + e (lanes 32-63), so an
+// operand that is k-contiguous in LDS is fetched with one ds_read_b128 per 4 MFMAs; an operand that is contiguous along
+// the lane index is fetched with ds_read_b32 (row pitch = 8 mod 16 floats keeps the two half-waves on different banks).
+typedef float am_f32x16 __attribute__((ext_vector_type(16)));
+typedef float am_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int AM_P68 = 68, AM_P72 = 72, AM_PS = 132, AM_P40 = 40;
+
+// acc[32x32] += sum_{k<64} A[row][k] * B[col][k]   (both k-contiguous; As/Bs = this lane's row base)
+__device__ __forceinline__ void am_mma_nt64(am_f32x16& acc, const float* As, const float* Bs, int hh) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const am_f32x4 a = *(const am_f32x4*)(As + 8 * m + 4 * hh);
+    const am_f32x4 b = *(const am_f32x4*)(Bs + 8 * m + 4 * hh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+  }
+}
+// acc += sum_{k<8*NM} A[row][k] * B[k][col]   (A k-contiguous: As = row base; B lane-contiguous: Bs = &B[0][col])
+template <int NM>
+__device__ __forceinline__ void am_mma_nn(am_f32x16& acc, const float* As, const float* Bs, int pitchB, int hh) {
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const am_f32x4 a = *(const am_f32x4*)(As + 8 * m + 4 * hh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], Bs[(8 * m + 4 * hh + e) * pitchB], acc, 0, 0, 0);
+  }
+}
+// acc += sum_{k<8*NM} A[k][row] * B[k][col]   (both lane-contiguous: As = &A[0][row], Bs = &B[0][col])
+template <int NM>
+__device__ __forceinline__ void am_mma_tn(am_f32x16& acc, const float* As, int pitchA, const float* Bs, int pitchB, int hh) {
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 8 * m + 4 * hh + e;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * pitchA], Bs[k * pitchB], acc, 0, 0, 0);
+    }
+}
+// stage ROWS x 64 floats (row stride ld in global) into LDS with the given pitch
+template <int ROWS>
+__device__ __forceinline__ void am_stage64(float* dst, int pitch, const float* src, long ld, int tid) {
+#pragma unroll
+  for (int e = tid; e < ROWS * 16; e += 256) {
+    const int r = e >> 4, u = e & 15;
+    *(am_f32x4*)&dst[r * pitch + 4 * u] = *(const am_f32x4*)(src + (long)r * ld + 4 * u);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo,
+                                                           float* __restrict__ Ocopy, float* __restrict__ P, int T, int H, long qo,
+                                                           long ko, long vo, long step, float alpha) {
+  __shared__ __attribute__((aligned(16))) float Qs[32 * AM_P68], Ks[128 * AM_P68], Vs[128 * AM_P72], Ss[32 * AM_PS];
+  __shared__ float mrow[32], lrow[32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  const float* base = qkv + (long)n * T * ldq + h * step;
+  am_stage64<32>(Qs, AM_P68, base + (long)qb * 32 * ldq + qo, ldq, tid);
+  const int nkb = T >> 7;
+  const int srow = tid >> 3, seg = tid & 7;
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int j = 0; j < nkb; ++j) {
+    __syncthreads();
+    am_stage64<128>(Ks, AM_P68, base + (long)j * 128 * ldq + ko, ldq, tid);
+    __syncthreads();
+    am_f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    am_mma_nt64(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ss[((r & 3) + 8 * (r >> 2) + 4 * hh) * AM_PS + 32 * w + l31] = sacc[r] * alpha;
+    __syncthreads();
+    float v[16], bm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i] = Ss[srow * AM_PS + seg * 16 + i];
+      bm = fmaxf(bm, v[i]);
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 1, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 2, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 4, 64));
+    const float mn = fmaxf(m_run, bm);
+    float bs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bs += __expf(v[i] - mn);
+    bs += __shfl_xor(bs, 1, 64);
+    bs += __shfl_xor(bs, 2, 64);
+    bs += __shfl_xor(bs, 4, 64);
+    l_run = l_run * __expf(m_run - mn) + bs;
+    m_run = mn;
+  }
+  if (seg == 0) {
+    mrow[srow] = m_run;
+    lrow[srow] = 1.f / l_run;
+  }
+  __syncthreads();
+  float mr[16], il[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    mr[r] = mrow[row];
+    il[r] = lrow[row];
+  }
+  const int fh = w & 1, kh = w >> 1;
+  am_f32x16 oacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+  float* Pg = P + (((long)n * H + h) * T + (long)qb * 32) * T + 32 * w + l31;
+  for (int j = 0; j < nkb; ++j) {
+    __syncthreads();
+    am_stage64<128>(Ks, AM_P68, base + (long)j * 128 * ldq + ko, ldq, tid);
+    am_stage64<128>(Vs, AM_P72, base + (long)j * 128 * ldq + vo, ldq, tid);
+    __syncthreads();
+    am_f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    am_mma_nt64(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float p = __expf(sacc[r] * alpha - mr[r]) * il[r];
+      Ss[row * AM_PS + 32 * w + l31] = p;
+      Pg[(long)row * T + j * 128] = p;
+    }
+    __syncthreads();
+    am_mma_nn<8>(oacc, &Ss[l31 * AM_PS + 64 * kh], &Vs[(64 * kh) * AM_P72 + 32 * fh + l31], AM_P72, hh);
+  }
+  __syncthreads();
+  float* red = Ks;  // [2][32][33]
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(fh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + l31] = oacc[r];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float v = oacc[r] + red[(fh * 32 + row) * 33 + l31];
+      const long t = (long)n * T + qb * 32 + row;
+      out[t * ldo + h * 64 + 32 * fh + l31] = v;
+      Ocopy[t * ((long)H * 64) + h * 64 + 32 * fh + l31] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout,
+                                                              int lddo, const float* __restrict__ Ocopy, const float* __restrict__ P,
+                                                              float* __restrict__ dS, float* __restrict__ dqkv, int lddq, int T, int H,
+                                                              long qo, long ko, long vo, long step, float alpha) {
+  __shared__ __attribute__((aligned(16))) float dOs[32 * AM_P68], Vs[128 * AM_P68], Ks[128 * AM_P72], Ss[32 * AM_PS];
+  __shared__ float Dr[32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  const float* base = qkv + (long)n * T * ldq + h * step;
+  const float* dob = dout + ((long)n * T + qb * 32) * lddo + h * 64;
+  am_stage64<32>(dOs, AM_P68, dob, lddo, tid);
+  {
+    const int srow = tid >> 3, seg = tid & 7;
+    const float* o = Ocopy + ((long)n * T + qb * 32 + srow) * ((long)H * 64) + h * 64 + seg * 8;
+    const float* g = dob + (long)srow * lddo + seg * 8;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a += o[i] * g[i];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 4, 64);
+    if (seg == 0) Dr[srow] = a;
+  }
+  __syncthreads();
+  float dr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dr[r] = Dr[(r & 3) + 8 * (r >> 2) + 4 * hh];
+  const int fh = w & 1, kh = w >> 1, nkb = T >> 7;
+  am_f32x16 qacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) qacc[e] = 0.f;
+  const long pbase = (((long)n * H + h) * T + (long)qb * 32) * T + 32 * w + l31;
+  for (int j = 0; j < nkb; ++j) {
+    __syncthreads();
+    am_stage64<128>(Vs, AM_P68, base + (long)j * 128 * ldq + vo, ldq, tid);
+    am_stage64<128>(Ks, AM_P72, base + (long)j * 128 * ldq + ko, ldq, tid);
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pv[r] = P[pbase + (long)((r & 3) + 8 * (r >> 2) + 4 * hh) * T + j * 128];
+    __syncthreads();
+    am_f32x16 dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+    am_mma_nt64(dp, &dOs[l31 * AM_P68], &Vs[(32 * w + l31) * AM_P68], hh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float ds = pv[r] * (dp[r] - dr[r]);
+      Ss[row * AM_PS + 32 * w + l31] = ds;
+      dS[pbase + (long)row * T + j * 128] = ds;
+    }
+    __syncthreads();
+    am_mma_nn<8>(qacc, &Ss[l31 * AM_PS + 64 * kh], &Ks[(64 * kh) * AM_P72 + 32 * fh + l31], AM_P72, hh);
+  }
+  __syncthreads();
+  float* red = Vs;  // [2][32][33]
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(fh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + l31] = qacc[r];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      dqkv[((long)n * T + qb * 32 + row) * lddq + h * step + qo + 32 * fh + l31] = (qacc[r] + red[(fh * 32 + row) * 33 + l31]) * alpha;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_mid_bwd_dkv_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout,
+                                                               int lddo, const float* __restrict__ P, const float* __restrict__ dS,
+                                                               float* __restrict__ dqkv, int lddq, int T, int H, long qo, long ko,
+                                                               long vo, long step, float alpha) {
+  __shared__ __attribute__((aligned(16))) float Pt[128 * AM_P40], St[128 * AM_P40], dOs[128 * AM_P72], Qs[128 * AM_P72];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int kb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  const float* base = qkv + (long)n * T * ldq + h * step;
+  const long prow0 = ((long)n * H + h) * T;
+  am_f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int tb = 0; tb < (T >> 7); ++tb) {
+    __syncthreads();
+#pragma unroll
+    for (int e = tid; e < 128 * 8; e += 256) {
+      const int r = e >> 3, u = e & 7;
+      const long g = (prow0 + tb * 128 + r) * T + kb * 32 + 4 * u;
+      *(am_f32x4*)&Pt[r * AM_P40 + 4 * u] = *(const am_f32x4*)(P + g);
+      *(am_f32x4*)&St[r * AM_P40 + 4 * u] = *(const am_f32x4*)(dS + g);
+    }
+    am_stage64<128>(dOs, AM_P72, dout + ((long)n * T + tb * 128) * lddo + h * 64, lddo, tid);
+    am_stage64<128>(Qs, AM_P72, base + (long)tb * 128 * ldq + qo, ldq, tid);
+    __syncthreads();
+    if (w < 2)
+      am_mma_tn<16>(acc, &Pt[l31], AM_P40, &dOs[32 * w + l31], AM_P72, hh);
+    else
+      am_mma_tn<16>(acc, &St[l31], AM_P40, &Qs[32 * (w - 2) + l31], AM_P72, hh);
+  }
+  const long off = h * step + (w < 2 ? vo : ko) + 32 * (w & 1) + l31;
+  const float sc = w < 2 ? 1.f : alpha;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    dqkv[((long)n * T + key) * lddq + off] = acc[r] * sc;
+  }
+}
+
+// the fused MFMA path: d = 64, T a multiple of 128, 16-byte aligned rows
+bool attn_mid_ok(const AttnShape& sh, int ldq, int ldo) { return sh.d == 64 && sh.T > AS_T && sh.T % 128 == 0 && !(ldq & 3) && !(ldo & 3); }
+
 }  // namespace
 
 int cgd_launch_softmax_rows(cgd_ctx* ctx, float* S, long rows, int T, int ld, hipStream_t s) {
@@ -197,6 +460,12 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   if (T <= AS_T && d == AS_D) {
     hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v,
                        ho.step, 1.f / sqrtf((float)d));
+    CGD_HIP(ctx, hipGetLastError());
+    return 0;
+  }
+  if (attn_mid_ok(sh, ldq, ldo)) {
+    hipLaunchKernelGGL(attn_mid_fwd_kernel, dim3(T / 32, H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, H, ho.q, ho.k,
+                       ho.v, ho.step, 1.f / sqrtf((float)d));
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
@@ -238,6 +507,14 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   if (T <= AS_T && d == AS_D) {
     hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q,
                        ho.k, ho.v, ho.step, alpha);
+    CGD_HIP(ctx, hipGetLastError());
+    return 0;
+  }
+  if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3)) {
+    hipLaunchKernelGGL(attn_mid_bwd_dq_kernel, dim3(T / 32, H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP, dqkv,
+                       lddq, T, H, ho.q, ho.k, ho.v, ho.step, alpha);
+    hipLaunchKernelGGL(attn_mid_bwd_dkv_kernel, dim3(T / 32, H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq, T,
+                       H, ho.q, ho.k, ho.v, ho.step, alpha);
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }

@@ -18,8 +18,8 @@ SHAPES_ALL = [  # (H=W, Cin, Cout, launches per step in config 2 (fwd+dgrad, app
     (16, 512, 1024, 2), (16, 1024, 1024, 14), (16, 2048, 1024, 3), (16, 1024, 2048, 3), (16, 1536, 1024, 1),
     (8, 1024, 1024, 18), (8, 2048, 1024, 3), (8, 1024, 2048, 3),
 ]
-SHAPES = [s for s in SHAPES_ALL if s[0] >= 64 and s[3] >= 3][:8]
-TILES = [5121, 5124] + [5124 + 8 * d for d in (1, 2, 3, 4)]  # 512x = halo-staged conv kernel, variant x (1: hconv_kernel, 4: hconv2_kernel)
+SHAPES = SHAPES_ALL
+TILES = [128, 5121, 5124, 5132]  # igemm 128x128 | hconv_kernel | hconv2 sectioned | hconv2 interleaved  # 512x = halo-staged conv kernel, variant x (1: hconv_kernel, 4: hconv2_kernel)
 
 
 def main():
@@ -71,7 +71,7 @@ def main():
     # best-per-shape projection
     tot_best = sum(min([v for v in r["us"].values() if v] or [0]) * r["count"] for r in res)
     tot_cur = sum((r["us"].get("1256") or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
-    for code in ("5121", "5124"):
+    for code in ("5121", "5132"):
         tot_h = sum((r["us"].get(code) or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
         print(f"halo conv kernel {code} wherever supported: {tot_h / 1e3:.2f} ms")
     print(f"projected conv time/step: default-ish {tot_cur / 1e3:.2f} ms, best-per-shape {tot_best / 1e3:.2f} ms")
