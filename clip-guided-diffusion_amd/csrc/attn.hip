@@ -64,118 +64,7 @@ HeadOff head_off(const AttnShape& sh) {
   return h;
 }
 
-// ---- fused attention for short sequences (T <= 64, d = 64): CLIP ViT-B/32 (T = 50) and the UNet's 8x8 level (T = 64) -----
-// One workgroup per (sequence, head): q, k, v (and dO) live in LDS, scores / softmax / PV in exact fp32 FMAs.  Replaces
-// 4 launches (transpose, QK^T, softmax, PV) forward and 8 backward; these sizes are launch-bound, not FLOP-bound.
-constexpr int AS_T = 64, AS_D = 64, AS_P = AS_D + 1;
-
-__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo,
-                                                             float* __restrict__ P, int T, int Tp, int H, long qo, long ko, long vo, long step,
-                                                             float alpha) {
-  __shared__ float q[AS_T][AS_P], k[AS_T][AS_P], v[AS_T][AS_P], sc[AS_T][AS_T + 1];
-  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const float* base = qkv + (long)n * T * ldq + h * step;
-  for (int e = tid; e < T * AS_D; e += 256) {
-    const int t = e >> 6, c = e & 63;
-    const float* r = base + (long)t * ldq + c;
-    q[t][c] = r[qo];
-    k[t][c] = r[ko];
-    v[t][c] = r[vo];
-  }
-  __syncthreads();
-  for (int e = tid; e < T * T; e += 256) {
-    const int t = e / T, s = e - t * T;
-    float a = 0.f;
-#pragma unroll 16
-    for (int c = 0; c < AS_D; ++c) a += q[t][c] * k[s][c];
-    sc[t][s] = a * alpha;
-  }
-  __syncthreads();
-  if (tid < T) {
-    float mx = -INFINITY;
-    for (int s = 0; s < T; ++s) mx = fmaxf(mx, sc[tid][s]);
-    float sum = 0.f;
-    for (int s = 0; s < T; ++s) {
-      const float e = __expf(sc[tid][s] - mx);
-      sc[tid][s] = e;
-      sum += e;
-    }
-    const float inv = 1.f / sum;
-    for (int s = 0; s < T; ++s) sc[tid][s] *= inv;
-  }
-  __syncthreads();
-  float* Pz = P + ((long)n * H + h) * T * Tp;
-  for (int e = tid; e < T * Tp; e += 256) {
-    const int t = e / Tp, s = e - t * Tp;
-    Pz[e] = s < T ? sc[t][s] : 0.f;
-  }
-  float* ob = out + (long)n * T * ldo + h * AS_D;
-  for (int e = tid; e < T * AS_D; e += 256) {
-    const int t = e >> 6, c = e & 63;
-    float a = 0.f;
-    for (int s = 0; s < T; ++s) a += sc[t][s] * v[s][c];
-    ob[(long)t * ldo + c] = a;
-  }
-}
-
-__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout, int lddo,
-                                                             float* __restrict__ dqkv, int lddq, const float* __restrict__ P, int T, int Tp,
-                                                             int H, long qo, long ko, long vo, long step, float alpha) {
-  __shared__ float q[AS_T][AS_P], k[AS_T][AS_P], v[AS_T][AS_P], go[AS_T][AS_P], pr[AS_T][AS_T + 1], ds[AS_T][AS_T + 1];
-  __shared__ float rs[AS_T];
-  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const float* base = qkv + (long)n * T * ldq + h * step;
-  const float* gob = dout + (long)n * T * lddo + h * AS_D;
-  const float* Pz = P + ((long)n * H + h) * T * Tp;
-  for (int e = tid; e < T * AS_D; e += 256) {
-    const int t = e >> 6, c = e & 63;
-    const float* r = base + (long)t * ldq + c;
-    q[t][c] = r[qo];
-    k[t][c] = r[ko];
-    v[t][c] = r[vo];
-    go[t][c] = gob[(long)t * lddo + c];
-  }
-  for (int e = tid; e < T * T; e += 256) {
-    const int t = e / T, s = e - t * T;
-    pr[t][s] = Pz[(long)t * Tp + s];
-  }
-  __syncthreads();
-  // dP = dO v^T
-  for (int e = tid; e < T * T; e += 256) {
-    const int t = e / T, s = e - t * T;
-    float a = 0.f;
-#pragma unroll 16
-    for (int c = 0; c < AS_D; ++c) a += go[t][c] * v[s][c];
-    ds[t][s] = a;
-  }
-  __syncthreads();
-  if (tid < T) {
-    float a = 0.f;
-    for (int s = 0; s < T; ++s) a += ds[tid][s] * pr[tid][s];
-    rs[tid] = a;
-  }
-  __syncthreads();
-  for (int e = tid; e < T * T; e += 256) {
-    const int t = e / T, s = e - t * T;
-    ds[t][s] = pr[t][s] * (ds[t][s] - rs[t]);
-  }
-  __syncthreads();
-  float* ob = dqkv + (long)n * T * lddq + h * step;
-  for (int e = tid; e < T * AS_D; e += 256) {
-    const int t = e >> 6, c = e & 63;  // t plays the role of the output row (t for dQ, s for dK / dV)
-    float dq = 0.f, dk = 0.f, dv = 0.f;
-    for (int s = 0; s < T; ++s) {
-      dq += ds[t][s] * k[s][c];
-      dk += ds[s][t] * q[s][c];
-      dv += pr[s][t] * go[s][c];
-    }
-    float* r = ob + (long)t * lddq + c;
-    r[qo] = dq * alpha;
-    r[ko] = dk * alpha;
-    r[vo] = dv;
-  }
-}
-
+constexpr int AS_T = 64, AS_D = 64;  // short-sequence fused kernels (attn_s64_*)
 
 // ---- fused attention for the UNet's 16x16 / 32x32 levels (T = 256 / 1024, d = 64) -----------------------------------
 // Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) on LDS tiles; no transposes, no batched GEMM launches, P is written once.
@@ -231,6 +120,24 @@ __device__ __forceinline__ void am_stage64(float* dst, int pitch, const float* s
   }
 }
 
+// register-staged variant: issue the global loads of the next tile before computing on the current one
+template <int ROWS>
+__device__ __forceinline__ void am_gload(am_f32x4 (&rg)[ROWS / 16], const float* src, long ld, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) {
+    const int e = tid + 256 * i, r = e >> 4, u = e & 15;
+    rg[i] = *(const am_f32x4*)(src + (long)r * ld + 4 * u);
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void am_sstore(float* dst, int pitch, const am_f32x4 (&rg)[ROWS / 16], int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) {
+    const int e = tid + 256 * i, r = e >> 4, u = e & 15;
+    *(am_f32x4*)&dst[r * pitch + 4 * u] = rg[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo,
                                                            float* __restrict__ Ocopy, float* __restrict__ P, int T, int H, long qo,
                                                            long ko, long vo, long step, float alpha) {
@@ -243,10 +150,13 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
   const int nkb = T >> 7;
   const int srow = tid >> 3, seg = tid & 7;
   float m_run = -INFINITY, l_run = 0.f;
+  am_f32x4 kr[8], vr[8];
+  am_gload<128>(kr, base + ko, ldq, tid);
   for (int j = 0; j < nkb; ++j) {
     __syncthreads();
-    am_stage64<128>(Ks, AM_P68, base + (long)j * 128 * ldq + ko, ldq, tid);
+    am_sstore<128>(Ks, AM_P68, kr, tid);
     __syncthreads();
+    am_gload<128>(kr, base + (long)(j + 1 < nkb ? j + 1 : 0) * 128 * ldq + ko, ldq, tid);  // next block (wraps to pass 2's first)
     am_f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
@@ -290,11 +200,16 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
 #pragma unroll
   for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
   float* Pg = P + (((long)n * H + h) * T + (long)qb * 32) * T + 32 * w + l31;
+  am_gload<128>(vr, base + vo, ldq, tid);
   for (int j = 0; j < nkb; ++j) {
     __syncthreads();
-    am_stage64<128>(Ks, AM_P68, base + (long)j * 128 * ldq + ko, ldq, tid);
-    am_stage64<128>(Vs, AM_P72, base + (long)j * 128 * ldq + vo, ldq, tid);
+    am_sstore<128>(Ks, AM_P68, kr, tid);
+    am_sstore<128>(Vs, AM_P72, vr, tid);
     __syncthreads();
+    if (j + 1 < nkb) {
+      am_gload<128>(kr, base + (long)(j + 1) * 128 * ldq + ko, ldq, tid);
+      am_gload<128>(vr, base + (long)(j + 1) * 128 * ldq + vo, ldq, tid);
+    }
     am_f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
@@ -360,14 +275,21 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
 #pragma unroll
   for (int e = 0; e < 16; ++e) qacc[e] = 0.f;
   const long pbase = (((long)n * H + h) * T + (long)qb * 32) * T + 32 * w + l31;
+  am_f32x4 kr[8], vr[8];
+  am_gload<128>(vr, base + vo, ldq, tid);
+  am_gload<128>(kr, base + ko, ldq, tid);
   for (int j = 0; j < nkb; ++j) {
     __syncthreads();
-    am_stage64<128>(Vs, AM_P68, base + (long)j * 128 * ldq + vo, ldq, tid);
-    am_stage64<128>(Ks, AM_P72, base + (long)j * 128 * ldq + ko, ldq, tid);
+    am_sstore<128>(Vs, AM_P68, vr, tid);
+    am_sstore<128>(Ks, AM_P72, kr, tid);
     float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) pv[r] = P[pbase + (long)((r & 3) + 8 * (r >> 2) + 4 * hh) * T + j * 128];
     __syncthreads();
+    if (j + 1 < nkb) {
+      am_gload<128>(vr, base + (long)(j + 1) * 128 * ldq + vo, ldq, tid);
+      am_gload<128>(kr, base + (long)(j + 1) * 128 * ldq + ko, ldq, tid);
+    }
     am_f32x16 dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dp[e] = 0.f;
@@ -410,29 +332,194 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dkv_kernel(const float* __re
   am_f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  for (int tb = 0; tb < (T >> 7); ++tb) {
+  am_f32x4 pr4[4], sr4[4], gr[8], qr[8];
+  const int ntb = T >> 7;
+#define DKV_LOAD(TB)                                                                              \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      const int e = tid + 256 * i, r = e >> 3, u = e & 7;                                         \
+      const long g = (prow0 + (TB) * 128 + r) * T + kb * 32 + 4 * u;                              \
+      pr4[i] = *(const am_f32x4*)(P + g);                                                         \
+      sr4[i] = *(const am_f32x4*)(dS + g);                                                        \
+    }                                                                                             \
+    am_gload<128>(gr, dout + ((long)n * T + (TB) * 128) * lddo + h * 64, lddo, tid);              \
+    am_gload<128>(qr, base + (long)(TB) * 128 * ldq + qo, ldq, tid);                              \
+  }
+  DKV_LOAD(0);
+  for (int tb = 0; tb < ntb; ++tb) {
     __syncthreads();
 #pragma unroll
-    for (int e = tid; e < 128 * 8; e += 256) {
-      const int r = e >> 3, u = e & 7;
-      const long g = (prow0 + tb * 128 + r) * T + kb * 32 + 4 * u;
-      *(am_f32x4*)&Pt[r * AM_P40 + 4 * u] = *(const am_f32x4*)(P + g);
-      *(am_f32x4*)&St[r * AM_P40 + 4 * u] = *(const am_f32x4*)(dS + g);
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, r = e >> 3, u = e & 7;
+      *(am_f32x4*)&Pt[r * AM_P40 + 4 * u] = pr4[i];
+      *(am_f32x4*)&St[r * AM_P40 + 4 * u] = sr4[i];
     }
-    am_stage64<128>(dOs, AM_P72, dout + ((long)n * T + tb * 128) * lddo + h * 64, lddo, tid);
-    am_stage64<128>(Qs, AM_P72, base + (long)tb * 128 * ldq + qo, ldq, tid);
+    am_sstore<128>(dOs, AM_P72, gr, tid);
+    am_sstore<128>(Qs, AM_P72, qr, tid);
     __syncthreads();
+    if (tb + 1 < ntb) DKV_LOAD(tb + 1);
     if (w < 2)
       am_mma_tn<16>(acc, &Pt[l31], AM_P40, &dOs[32 * w + l31], AM_P72, hh);
     else
       am_mma_tn<16>(acc, &St[l31], AM_P40, &Qs[32 * (w - 2) + l31], AM_P72, hh);
   }
+#undef DKV_LOAD
   const long off = h * step + (w < 2 ? vo : ko) + 32 * (w & 1) + l31;
   const float sc = w < 2 ? 1.f : alpha;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
     dqkv[((long)n * T + key) * lddq + off] = acc[r] * sc;
+  }
+}
+
+// ---- short sequences (T <= 64, d = 64) on the same exact-fp32 MFMA blocks: CLIP ViT-B/32 (T = 50), UNet 8x8 level (T = 64) --
+// One workgroup (4 wavefronts) per (sequence, head); rows/keys beyond T are zero-filled / masked.
+template <int ROWS>
+__device__ __forceinline__ void am_stage_rows(float* dst, int pitch, const float* src, long ld, int T, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) {
+    const int e = tid + 256 * i, r = e >> 4, u = e & 15;
+    am_f32x4 v = am_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < T) v = *(const am_f32x4*)(src + (long)r * ld + 4 * u);
+    *(am_f32x4*)&dst[r * pitch + 4 * u] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_s64_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo,
+                                                           float* __restrict__ P, int T, int Tp, int H, long qo, long ko, long vo, long step,
+                                                           float alpha) {
+  __shared__ __attribute__((aligned(16))) float Qs[64 * AM_P68], Ks[64 * AM_P68], Vs[64 * AM_P72], Ss[64 * AM_P68];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int h = blockIdx.x, n = blockIdx.y;
+  const float* base = qkv + (long)n * T * ldq + h * step;
+  am_stage_rows<64>(Qs, AM_P68, base + qo, ldq, T, tid);
+  am_stage_rows<64>(Ks, AM_P68, base + ko, ldq, T, tid);
+  am_stage_rows<64>(Vs, AM_P72, base + vo, ldq, T, tid);
+  __syncthreads();
+  const int ri = w >> 1, ci = w & 1;
+  am_f32x16 sacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+  am_mma_nt64(sacc, &Qs[(32 * ri + l31) * AM_P68], &Ks[(32 * ci + l31) * AM_P68], hh);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Ss[(32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh) * AM_P68 + 32 * ci + l31] = sacc[r] * alpha;
+  __syncthreads();
+  {
+    const int row = tid >> 2, seg = tid & 3;
+    float v[16], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int sidx = seg * 16 + i;
+      v[i] = sidx < T ? Ss[row * AM_P68 + sidx] : -INFINITY;
+      mx = fmaxf(mx, v[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i] = __expf(v[i] - mx);  // exp(-inf) = 0 for masked keys
+      sum += v[i];
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float inv = 1.f / sum;
+    float* Pz = P + (((long)n * H + h) * T + row) * Tp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int sidx = seg * 16 + i;
+      const float p = v[i] * inv;
+      Ss[row * AM_P68 + sidx] = p;
+      if (row < T && sidx < Tp) Pz[sidx] = p;
+    }
+  }
+  __syncthreads();
+  const int fh = ci;
+  am_f32x16 oacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+  am_mma_nn<8>(oacc, &Ss[(32 * ri + l31) * AM_P68], &Vs[32 * fh + l31], AM_P72, hh);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    if (row < T) out[((long)n * T + row) * ldo + h * 64 + 32 * fh + l31] = oacc[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_s64_bwd_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout, int lddo,
+                                                           float* __restrict__ dqkv, int lddq, const float* __restrict__ P, int T, int Tp,
+                                                           int H, long qo, long ko, long vo, long step, float alpha) {
+  __shared__ __attribute__((aligned(16))) float Qs[64 * AM_P72], Ks[64 * AM_P72], Vs[64 * AM_P68], Gs[64 * AM_P68], Ps[64 * AM_P68],
+      Ds[64 * AM_P68];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int h = blockIdx.x, n = blockIdx.y;
+  const float* base = qkv + (long)n * T * ldq + h * step;
+  am_stage_rows<64>(Qs, AM_P72, base + qo, ldq, T, tid);
+  am_stage_rows<64>(Ks, AM_P72, base + ko, ldq, T, tid);
+  am_stage_rows<64>(Vs, AM_P68, base + vo, ldq, T, tid);
+  am_stage_rows<64>(Gs, AM_P68, dout + (long)n * T * lddo + h * 64, lddo, T, tid);
+  {
+    const float* Pz = P + ((long)n * H + h) * T * Tp;
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int t = e >> 6, sidx = e & 63;
+      Ps[t * AM_P68 + sidx] = (t < T && sidx < T) ? Pz[(long)t * Tp + sidx] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int ri = w >> 1, ci = w & 1;
+  {  // dP = dO V^T
+    am_f32x16 dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+    am_mma_nt64(dp, &Gs[(32 * ri + l31) * AM_P68], &Vs[(32 * ci + l31) * AM_P68], hh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ds[(32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh) * AM_P68 + 32 * ci + l31] = dp[r];
+  }
+  __syncthreads();
+  {  // dS = P (dP - rowsum(dP P))
+    const int row = tid >> 2, seg = tid & 3;
+    float d[16], p[16], a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      d[i] = Ds[row * AM_P68 + seg * 16 + i];
+      p[i] = Ps[row * AM_P68 + seg * 16 + i];
+      a += d[i] * p[i];
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ds[row * AM_P68 + seg * 16 + i] = p[i] * (d[i] - a);
+  }
+  __syncthreads();
+  float* ob = dqkv + (long)n * T * lddq + h * step;
+  am_f32x16 acc;
+  // dQ[t][c] = alpha * sum_s dS[t][s] K[s][c]
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  am_mma_nn<8>(acc, &Ds[(32 * ri + l31) * AM_P68], &Ks[32 * ci + l31], AM_P72, hh);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    if (row < T) ob[(long)row * lddq + qo + 32 * ci + l31] = acc[r] * alpha;
+  }
+  // dK[s][c] = alpha * sum_t dS[t][s] Q[t][c]
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  am_mma_tn<8>(acc, &Ds[32 * ri + l31], AM_P68, &Qs[32 * ci + l31], AM_P72, hh);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    if (row < T) ob[(long)row * lddq + ko + 32 * ci + l31] = acc[r] * alpha;
+  }
+  // dV[s][c] = sum_t P[t][s] dO[t][c]
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  am_mma_tn<8>(acc, &Ps[32 * ri + l31], AM_P68, &Gs[32 * ci + l31], AM_P68, hh);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    if (row < T) ob[(long)row * lddq + vo + 32 * ci + l31] = acc[r];
   }
 }
 
@@ -457,9 +544,9 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
   const HeadOff ho = head_off(sh);
-  if (T <= AS_T && d == AS_D) {
-    hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v,
-                       ho.step, 1.f / sqrtf((float)d));
+  if (T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3)) {
+    hipLaunchKernelGGL(attn_s64_fwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
+                       1.f / sqrtf((float)d));
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
@@ -504,9 +591,9 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   const HeadOff ho = head_off(sh);
   const float alpha = 1.f / sqrtf((float)d);
   const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
-  if (T <= AS_T && d == AS_D) {
-    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q,
-                       ho.k, ho.v, ho.step, alpha);
+  if (T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3)) {
+    hipLaunchKernelGGL(attn_s64_bwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
+                       ho.v, ho.step, alpha);
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
