@@ -82,6 +82,7 @@ struct GemmParams {
   float alpha = 1.f;
   int conv = 0, H = 0, W = 0, Cin = 0, ups = 0;
   int splitk = 1;
+  int no_split = 0;  // 1: never split K automatically (the caller keeps data of its own in the workspace)
   float* ws = nullptr;
   int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip

@@ -103,6 +103,79 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(const float* __restr
   }
 }
 
+// ---- MFMA route for the thin ends (default): the 3/6-channel side becomes a K- or N-padded GEMM operand -----------------
+//   conv_in  (CIN -> Cout): im2col of the thin NCHW input [pix][KP] (KP = 32 / 64 >= 9*CIN), then C = A W^T on the MFMA GEMM.
+//   thin_out (Cin -> COUT): T[pix][tap*COUT + co] = sum_ci x[pix][ci] w[co][tap][ci] on the MFMA GEMM (x is read ONCE instead
+//                           of 9 times), then a 9-neighbour gather of T into the NCHW output.
+typedef float ct_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN, int KP>
+__global__ __launch_bounds__(256) void thin_im2col_kernel(const float* __restrict__ x, float* __restrict__ out, int Bn, int H, int W) {
+  constexpr int Q = KP / 4;
+  const long total = (long)Bn * H * W * Q;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const long pix = t / Q;
+    const int k4 = (int)(t - pix * Q);
+    const int b = (int)(pix / ((long)H * W));
+    const int rem = (int)(pix - (long)b * H * W);
+    const int yy = rem / W, xx = rem - yy * W;
+    ct_f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * k4 + e;
+      float val = 0.f;
+      if (k < 9 * CIN) {
+        const int tap = k / CIN, ci = k - tap * CIN;
+        const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) val = x[(((long)b * CIN + ci) * H + sy) * W + sx];
+      }
+      v[e] = val;
+    }
+    *(ct_f32x4*)(out + pix * KP + 4 * k4) = v;
+  }
+}
+
+// [N][K] -> [N][KP] zero padded
+__global__ __launch_bounds__(256) void thin_padw_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int K, int KP) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * KP) return;
+  const int n = t / KP, k = t - n * KP;
+  out[t] = k < K ? w[(long)n * K + k] : 0.f;
+}
+// w [COUT][9*Cin] (k = tap*Cin + ci) -> [NP][Cin], row = tap*COUT + co, zero rows beyond 9*COUT
+__global__ __launch_bounds__(256) void thin_tapw_kernel(const float* __restrict__ w, float* __restrict__ out, int COUT, int Cin, int NP) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= NP * Cin) return;
+  const int row = t / Cin, ci = t - row * Cin;
+  const int tap = row / COUT, co = row - tap * COUT;
+  out[t] = row < 9 * COUT ? w[(long)co * 9 * Cin + tap * Cin + ci] : 0.f;
+}
+
+template <int COUT, int NP>
+__global__ __launch_bounds__(256) void thin_gather_kernel(const float* __restrict__ T, const float* __restrict__ bias, float* __restrict__ y,
+                                                          int Bn, int H, int W) {
+  const long npix = (long)Bn * H * W;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= npix) return;
+  const int b = (int)(pix / ((long)H * W));
+  const int rem = (int)(pix - (long)b * H * W);
+  const int yy = rem / W, xx = rem - yy * W;
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+    if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+      const float* tp = T + (((long)b * H + sy) * W + sx) * NP + tap * COUT;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[co] += tp[co];
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) y[(((long)b * COUT + co) * H + yy) * W + xx] = acc[co];
+}
+
 }  // namespace
 
 int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int Bn, int H, int W, int Cin,
@@ -110,6 +183,32 @@ int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float
   if (Cout % 4 || Cout / 4 > 256) CGD_FAIL(ctx, "conv_in: Cout must be a multiple of 4 and <= 1024");
   const int ppb = 64;
   const long npix = (long)Bn * H * W;
+  if (Cin != 3 && Cin != 6) CGD_FAIL(ctx, "conv_in: Cin must be 3 or 6");
+  {
+    // MFMA route: scratch (im2col + padded weights) lives in the split-K workspace, so the GEMM must not split
+    const int KP = Cin == 3 ? 32 : 64;
+    const size_t a_floats = (size_t)npix * KP, w_floats = (size_t)Cout * KP;
+    if ((a_floats + w_floats) * sizeof(float) <= ctx->ws_bytes) {
+      float* a = ctx->ws;
+      float* wp = ctx->ws + a_floats;
+      const int g1 = (int)std::min<long>(cdiv(npix * (KP / 4), 256), 8192);
+      if (Cin == 3)
+        hipLaunchKernelGGL((thin_im2col_kernel<3, 32>), dim3(g1), dim3(256), 0, s, x, a, Bn, H, W);
+      else
+        hipLaunchKernelGGL((thin_im2col_kernel<6, 64>), dim3(g1), dim3(256), 0, s, x, a, Bn, H, W);
+      hipLaunchKernelGGL(thin_padw_kernel, dim3(cdiv((long)Cout * KP, 256)), dim3(256), 0, s, w, wp, Cout, 9 * Cin, KP);
+      GemmParams g;
+      g.A = a; g.lda = KP;
+      g.B = wp; g.ldb = KP;
+      g.C = y; g.ldc = Cout;
+      g.bias = bias;
+      g.M = (int)npix; g.N = Cout; g.K = KP;
+      g.no_split = 1;
+      CGD_TRY(cgd_launch_gemm(ctx, g, s));
+      CGD_HIP(ctx, hipGetLastError());
+      return 0;
+    }
+  }
   const size_t sh = (size_t)9 * Cin * Cout * sizeof(float);
   dim3 grid(cdiv(npix, ppb));
   if (Cin == 3)
@@ -126,6 +225,29 @@ int cgd_launch_conv_thin_out(cgd_ctx* ctx, const float* x, int ldx, const float*
                              int W, int Cin, int Cout, hipStream_t s) {
   const int ppb = 64;
   const long npix = (long)Bn * H * W;
+  if (Cout != 3 && Cout != 6) CGD_FAIL(ctx, "conv_thin_out: Cout must be 3 or 6");
+  if (!(Cin & 3) && !(ldx & 3) && !((uintptr_t)x & 15)) {
+    const int NP = Cout == 3 ? 32 : 64;
+    const size_t t_floats = (size_t)npix * NP, w_floats = (size_t)NP * Cin;
+    if ((t_floats + w_floats) * sizeof(float) <= ctx->ws_bytes) {
+      float* T = ctx->ws;
+      float* wt = ctx->ws + t_floats;
+      hipLaunchKernelGGL(thin_tapw_kernel, dim3(cdiv((long)NP * Cin, 256)), dim3(256), 0, s, w, wt, Cout, Cin, NP);
+      GemmParams g;
+      g.A = x; g.lda = ldx;
+      g.B = wt; g.ldb = Cin;
+      g.C = T; g.ldc = NP;
+      g.M = (int)npix; g.N = NP; g.K = Cin;
+      g.no_split = 1;
+      CGD_TRY(cgd_launch_gemm(ctx, g, s));
+      if (Cout == 3)
+        hipLaunchKernelGGL((thin_gather_kernel<3, 32>), dim3(cdiv(npix, 256)), dim3(256), 0, s, T, bias, y, Bn, H, W);
+      else
+        hipLaunchKernelGGL((thin_gather_kernel<6, 64>), dim3(cdiv(npix, 256)), dim3(256), 0, s, T, bias, y, Bn, H, W);
+      CGD_HIP(ctx, hipGetLastError());
+      return 0;
+    }
+  }
   const size_t sh = (size_t)9 * Cin * Cout * sizeof(float);
   if (sh > 160 * 1024) CGD_FAIL(ctx, "conv_thin_out: weights do not fit LDS");
   dim3 grid(cdiv(npix, ppb));

@@ -406,7 +406,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   const int nkt = cdiv(p.K, BK);
   if (p.splitk <= 0) p.splitk = 1;
   int tile = p.force_tile;
-  bool auto_split = p.splitk == 1 && p.nbatch == 1;
+  bool auto_split = p.splitk == 1 && p.nbatch == 1 && !p.no_split;
   // halo-staged conv kernel (hconv.hip): tile code 512
   bool use_h = false;
   if (cgd_hconv_supported(ctx, p)) use_h = tile == 512 || (!tile && ctx->hconv_mode && p.M >= ctx->hconv_min_m);
