@@ -107,28 +107,48 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __re
   }
 }
 
-// merge chunks -> stats[b][g] = (mean, rstd); one wavefront per (b, g)
-__global__ __launch_bounds__(64) void gn_stats_final_kernel(const float* __restrict__ part, int nchunk, int HW, int chunk, int cpg,
-                                                            float eps, float* __restrict__ stats /*[B][32][2]*/,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const float* __restrict__ film /*[B][ldfilm] scale|shift or null*/,
-                                                            int ldfilm, float* __restrict__ coef) {
+// block-wide sum of a double over 256 threads (4 wavefronts); every thread gets the result
+__device__ __forceinline__ double block_sum256(double v, double* red /*[4]*/) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();  // protects a previous use of red
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// merge chunks -> stats[b][g] = (mean, rstd); one 256-thread block per (b, g), chunk partials held in registers
+__global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __restrict__ part, int nchunk, int HW, int chunk, int cpg,
+                                                             float eps, float* __restrict__ stats /*[B][32][2]*/,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ film /*[B][ldfilm] scale|shift or null*/,
+                                                             int ldfilm, float* __restrict__ coef) {
+  __shared__ double red[4];
   const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  constexpr int MAXK = 8;  // nchunk <= 2048
+  float pm[MAXK], p2[MAXK];
+  int pn[MAXK];
   double wsum = 0.0;
-  for (int ck = lane; ck < nchunk; ck += 64) {
-    const int n = min(HW, (ck + 1) * chunk) - ck * chunk;
-    wsum += (double)n * part[(((long)b * nchunk + ck) * 32 + g) * 2];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    const int ck = lane + 256 * k;
+    pn[k] = 0;
+    pm[k] = p2[k] = 0.f;
+    if (ck < nchunk) {
+      const float2 v = *(const float2*)(part + (((long)b * nchunk + ck) * 32 + g) * 2);
+      pn[k] = min(HW, (ck + 1) * chunk) - ck * chunk;
+      pm[k] = v.x;
+      p2[k] = v.y;
+      wsum += (double)pn[k] * v.x;
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
-  const double mean = wsum / (double)HW;
+  const double mean = block_sum256(wsum, red) / (double)HW;
   double m2 = 0.0;
-  for (int ck = lane; ck < nchunk; ck += 64) {
-    const int n = min(HW, (ck + 1) * chunk) - ck * chunk;
-    const float* pp = part + (((long)b * nchunk + ck) * 32 + g) * 2;
-    const double d = (double)pp[0] - mean;
-    m2 += (double)pp[1] + (double)n * cpg * d * d;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    const double d = (double)pm[k] - mean;
+    m2 += (double)p2[k] + (double)pn[k] * cpg * d * d;
   }
-  for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+  m2 = block_sum256(m2, red);
   const double var = m2 / ((double)HW * cpg);
   const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
   if (lane == 0) {
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(64) void gn_stats_final_kernel(const float* __restr
   }
   // fold (mean, rstd, gamma, beta, film) into per-channel y = x*a + b; coef[b][c] = {a, b, gcoef = gamma*(1+scale), mean}
   const int C = cpg * 32;
-  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 256) {
     float gm = gamma[c], bt = beta[c];
     if (film) {
       const float sc = 1.f + film[(long)b * ldfilm + c], sh = film[(long)b * ldfilm + C + c];
@@ -277,25 +297,24 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
 
 // bcoef[b][c] = {A1 = rstd*gcoef, A2 = rstd^3 * mean_g(dxhat*(x-mean)) , A3 = rstd * mean_g(dxhat), unused}
 // dx = du*A1 - (x-mean)*A2 - A3
-__global__ void gn_bwd_coef_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ stats,
-                                   const float* __restrict__ coef, int C, int HW, float* __restrict__ bcoef) {
-  // one wavefront per (b, group): reduce the chunk partials, then write the group's channels
+__global__ __launch_bounds__(256) void gn_bwd_coef_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ stats,
+                                                          const float* __restrict__ coef, int C, int HW, float* __restrict__ bcoef) {
+  // one 256-thread block per (b, group): reduce the chunk partials, then write the group's channels
+  __shared__ double red[4];
   const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
   const int cpg = C / 32;
   double p1 = 0.0, p2 = 0.0;
-  for (int ck = lane; ck < nchunk; ck += 64) {
-    const float* pp = part + (((long)b * nchunk + ck) * 32 + g) * 2;
-    p1 += pp[0];
-    p2 += pp[1];
+  for (int ck = lane; ck < nchunk; ck += 256) {
+    const float2 v = *(const float2*)(part + (((long)b * nchunk + ck) * 32 + g) * 2);
+    p1 += v.x;
+    p2 += v.y;
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    p1 += __shfl_xor(p1, o, 64);
-    p2 += __shfl_xor(p2, o, 64);
-  }
+  p1 = block_sum256(p1, red);
+  p2 = block_sum256(p2, red);
   const double N = (double)HW * cpg;
   const float rstd = stats[((long)b * 32 + g) * 2 + 1];
   const float a2 = (float)((double)rstd * rstd * rstd * p2 / N), a3 = (float)((double)rstd * p1 / N);
-  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 256) {
     float* o = bcoef + ((long)b * C + c) * 4;
     o[0] = rstd * coef[((long)b * C + c) * 4 + 2];
     o[1] = a2;
@@ -361,7 +380,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 }
 
 // ---- LayerNorm: one wavefront per row -------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int rows,
+// generic versions (any C): three passes over an L1-resident row
+__global__ __launch_bounds__(256) void ln_fwd_generic_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int rows,
                                                      int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float* __restrict__ stats /*[rows][2]*/) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -387,7 +407,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = rstd*(dy*g - mean(dy*g) - xhat*mean(dy*g*xhat)) (+ add)
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+__global__ __launch_bounds__(256) void ln_bwd_generic_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                      float* __restrict__ dx, int lddx, const float* __restrict__ add, int ldadd,
                                                      int rows, int C, const float* __restrict__ gamma,
                                                      const float* __restrict__ stats) {
@@ -415,6 +435,93 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     float o = rstd * (dr[c] * gamma[c] - s1 - xh * s2);
     if (ar) o += ar[c];
     orow[c] = o;
+  }
+}
+
+// register-resident versions for C = 256 * NV (ViT widths 768 / 1024): the row is read once as NV float4 per lane
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int rows,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                     float* __restrict__ stats /*[rows][2]*/) {
+  constexpr int C = 256 * NV;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *(const float4*)(xr + 256 * i + 4 * lane);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / C + eps);
+  float* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 g = *(const float4*)(gamma + 256 * i + 4 * lane), bt = *(const float4*)(beta + 256 * i + 4 * lane);
+    float4 o;
+    o.x = v[i].x * rstd * g.x + bt.x;
+    o.y = v[i].y * rstd * g.y + bt.y;
+    o.z = v[i].z * rstd * g.z + bt.z;
+    o.w = v[i].w * rstd * g.w + bt.w;
+    *(float4*)(yr + 256 * i + 4 * lane) = o;
+  }
+  if (lane == 0 && stats) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                     float* __restrict__ dx, int lddx, const float* __restrict__ add, int ldadd, int rows,
+                                                     const float* __restrict__ gamma, const float* __restrict__ stats) {
+  constexpr int C = 256 * NV;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  const float* dr = dy + (long)row * lddy;
+  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  float4 xh[NV], gd[NV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 xv = *(const float4*)(xr + 256 * i + 4 * lane), dv = *(const float4*)(dr + 256 * i + 4 * lane);
+    const float4 g = *(const float4*)(gamma + 256 * i + 4 * lane);
+    xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
+    gd[i].x = dv.x * g.x; gd[i].y = dv.y * g.y; gd[i].z = dv.z * g.z; gd[i].w = dv.w * g.w;
+    s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+    s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  s1 /= C;
+  s2 /= C;
+  float* orow = dx + (long)row * lddx;
+  const float* ar = add ? add + (long)row * ldadd : nullptr;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float4 o;
+    o.x = rstd * (gd[i].x - s1 - xh[i].x * s2);
+    o.y = rstd * (gd[i].y - s1 - xh[i].y * s2);
+    o.z = rstd * (gd[i].z - s1 - xh[i].z * s2);
+    o.w = rstd * (gd[i].w - s1 - xh[i].w * s2);
+    if (ar) {
+      const float4 a = *(const float4*)(ar + 256 * i + 4 * lane);
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    *(float4*)(orow + 256 * i + 4 * lane) = o;
   }
 }
 
@@ -677,6 +784,7 @@ int pick_chunk(int HW, int B) {
   int chunk = HW * B / 1024;
   if (chunk < 8) chunk = 8;
   if (chunk > 256) chunk = 256;
+  if ((HW + chunk - 1) / chunk > 2048) chunk = (HW + 2047) / 2048;  // gn_stats_final_kernel keeps <= 8 partials per thread
   if (chunk > HW) chunk = HW;
   return chunk;
 }
@@ -716,7 +824,7 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
     return 0;
   }
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ldx, HW, C, chunk, part);
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(64), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats, gamma, beta, film,
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats, gamma, beta, film,
                      ldfilm, coef);
   if (act)
     hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
@@ -744,7 +852,7 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
   } else {
     hipLaunchKernelGGL((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, HW, C, chunk, coef, part);
   }
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(32, B), dim3(64), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
   if (act) {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C,
                        chunk, coef, bcoef);
@@ -758,15 +866,37 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
 
 int cgd_launch_ln_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int rows, int C, const float* gamma,
                       const float* beta, float eps, float* stats, hipStream_t s) {
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps, stats);
+  const bool vec = C % 256 == 0 && C <= 1024 && !(ldx & 3) && !(ldy & 3) && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15);
+  const dim3 grid(cdiv(rows, 4)), blk(256);
+  if (!vec) {
+    hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, blk, 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps, stats);
+  } else {
+    switch (C / 256) {
+      case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, blk, 0, s, x, ldx, y, ldy, rows, gamma, beta, eps, stats); break;
+      case 2: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, blk, 0, s, x, ldx, y, ldy, rows, gamma, beta, eps, stats); break;
+      case 3: hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, blk, 0, s, x, ldx, y, ldy, rows, gamma, beta, eps, stats); break;
+      default: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, blk, 0, s, x, ldx, y, ldy, rows, gamma, beta, eps, stats); break;
+    }
+  }
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 
 int cgd_launch_ln_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, const float* add,
                       int ldadd, int rows, int C, const float* gamma, const float* stats, hipStream_t s) {
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, C, gamma,
-                     stats);
+  const bool vec = C % 256 == 0 && C <= 1024 && !(ldx & 3) && !(lddy & 3) && !(lddx & 3) && !(ldadd & 3) &&
+                   !(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)add | (uintptr_t)gamma) & 15);
+  const dim3 grid(cdiv(rows, 4)), blk(256);
+  if (!vec) {
+    hipLaunchKernelGGL(ln_bwd_generic_kernel, grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, C, gamma, stats);
+  } else {
+    switch (C / 256) {
+      case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats); break;
+      case 2: hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats); break;
+      case 3: hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats); break;
+      default: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats); break;
+    }
+  }
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
