@@ -39,6 +39,8 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
 void cgd_ctx_destroy(cgd_ctx* ctx) {
   if (!ctx) return;
   if (ctx->ws) (void)hipFree(ctx->ws);
+  cgd_frag_cache_clear(ctx);
+  if (ctx->frag_tmp) (void)hipFree(ctx->frag_tmp);
   delete ctx;
 }
 
@@ -55,6 +57,13 @@ int cgd_set_tiles(cgd_ctx* ctx, int large, int small) {
   ctx->tile_huge = large >= 1000000 ? large / 1000000 : ctx->tile_huge;  // optional: huge*1e6 + large
   ctx->tile_large = large % 1000000;
   ctx->tile_small = small;
+  return 0;
+}
+
+int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks) {
+  ctx->hgemm_mode = mode;
+  if (min_m > 0) ctx->hgemm_min_m = min_m;
+  if (min_chunks > 0) ctx->hgemm_min_chunks = min_chunks;
   return 0;
 }
 

@@ -19,6 +19,12 @@ struct ProfRec {
   int kind;  // 0: igemm_kernel (+ its split-K reduce), 1: hconv_kernel alone (the dominant kernel of the step)
 };
 
+struct FragEntry {  // fragment-order copy of a persistent weight (hgemm.hip)
+  const float* w;
+  int N, K, ldw;
+  void* packed;
+};
+
 struct cgd_ctx {
   int device = 0;
   int precision = CGD_PREC_BF16X3;
@@ -30,6 +36,11 @@ struct cgd_ctx {
   int hconv_var = 12;  // halo conv variant (default: hconv2, interleaved issue; ops_r1u: -6..-15% vs hconv_kernel): bit 2 = hconv2_kernel (16x16 tiles, pipelined; bits 3+ = its scheduling variant); else hconv_kernel with bit 0 = sched_barrier
                       // after the fragment prefetch (ops_r1o: +3..10%), bit 1 = setprio
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int hgemm_mode = 1, hgemm_min_m = 2048, hgemm_min_chunks = 3;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it the
+                                                                 // launch is latency-bound and igemm's finer tiles win, gemm_r1ae), chunks per split-K slice
+  std::vector<FragEntry> frag_cache;                           // packed weights, keyed by pointer; cleared by finalize / set_param / destroy
+  void* frag_tmp = nullptr;                                    // packed copy of a non-persistent B operand (forced hgemm, tests)
+  size_t frag_tmp_bytes = 0;
   // optional HIP-event timing of every MFMA GEMM/conv launch (bench.py roofline leg)
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
@@ -84,7 +95,8 @@ struct GemmParams {
   int splitk = 1;
   int no_split = 0;  // 1: never split K automatically (the caller keeps data of its own in the workspace)
   float* ws = nullptr;
-  int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel
+  int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel
+  int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
 };
 
@@ -93,6 +105,13 @@ size_t cgd_hconv_packed_floats(int Co, int Ci);
 int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w /*[Co][Ci][3][3]*/, float* out, int Co, int Ci, int dgrad, hipStream_t s);
 bool cgd_hconv_supported(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
+
+// ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------
+bool cgd_hgemm_supported(const cgd_ctx* ctx, const GemmParams& p);
+int cgd_hgemm_tiles(const GemmParams& p);
+int cgd_hgemm_chunks(const GemmParams& p);
+int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
+void cgd_frag_cache_clear(cgd_ctx* ctx);
 
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s);
 

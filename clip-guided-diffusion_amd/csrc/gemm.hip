@@ -422,6 +422,22 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     }
     auto_split = false;
   }
+  // weight GEMM kernel (hgemm.hip): tile code 513; automatic for persistent weights with M >= hgemm_min_m
+  bool use_g = false;
+  if (!use_h && cgd_hgemm_supported(ctx, p))
+    use_g = tile == 513 || (!tile && p.weight && ctx->hgemm_mode && p.M >= ctx->hgemm_min_m);
+  if (tile == 513 && !use_g) CGD_FAIL(ctx, "cgd_launch_gemm: weight GEMM kernel does not support this problem");
+  if (use_g) {
+    tile = 513;
+    const long tiles = cgd_hgemm_tiles(p);
+    const int nch = cgd_hgemm_chunks(p);
+    if (auto_split && tiles < ctx->num_cu) {
+      long want = std::min<long>(cdiv(2L * ctx->num_cu, tiles), nch / ctx->hgemm_min_chunks);
+      while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
+      if (want >= 2) p.splitk = (int)want;
+    }
+    auto_split = false;
+  }
   if (!tile) {
     // largest tile that still fills the chip (>= 2 workgroups per CU), using split-K for the deficit
     const long want_wg = 2L * ctx->num_cu;
@@ -436,7 +452,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
       tile = ctx->tile_small;
   }
   int bm = 256, bn = 128;
-  if (!use_h) tile_dims(tile, &bm, &bn);
+  if (!use_h && !use_g) tile_dims(tile, &bm, &bn);
   const long ntiles = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
   if (auto_split && ntiles < 2L * ctx->num_cu) {
     long want = cdiv(2L * ctx->num_cu, ntiles);
@@ -472,6 +488,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (use_h) {
     CGD_TRY(cgd_launch_hconv(ctx, p, s));
     if (ctx->prof_on) CGD_HIP(ctx, hipEventRecord(pr.b, s));  // the halo conv kernel alone, without its split-K reduce
+  } else if (use_g) {
+    CGD_TRY(cgd_launch_hgemm(ctx, p, s));
   } else {
     switch (ctx->precision) {
       case CGD_PREC_F32: CGD_TRY(launch_mode<0>(ctx, p, tile, s)); break;

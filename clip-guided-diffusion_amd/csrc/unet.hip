@@ -158,7 +158,8 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
     GemmParams sk;
     sk.A = skip_src; sk.lda = skip_ld; sk.B = skw; sk.ldb = cin; sk.C = out.p; sk.ldc = cout; sk.bias = skb;
     sk.M = (int)npo; sk.N = cout; sk.K = cin;
-    CGD_TRY(cgd_launch_gemm(ctx, sk, s));
+    sk.weight = 1;
+  CGD_TRY(cgd_launch_gemm(ctx, sk, s));
     R = out.p;
     ldr = cout;
   }
@@ -212,7 +213,8 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
     GemmParams sk;
     sk.A = dout.p; sk.lda = dout.ld; sk.B = skwT; sk.ldb = cout; sk.C = dx.p; sk.ldc = cin;
     sk.M = (int)npo; sk.N = cin; sk.K = cout;
-    CGD_TRY(cgd_launch_gemm(ctx, sk, s));
+    sk.weight = 1;
+  CGD_TRY(cgd_launch_gemm(ctx, sk, s));
     add = dx.p; ldadd = cin;
   } else {
     add = dout.p; ldadd = dout.ld;
@@ -238,6 +240,7 @@ int AttnBlock::fwd(UNet& u, TV xin, int Bn, int& H, int& W, TV* o, hipStream_t s
   CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, n.p, C, B, T, C, g, b, nullptr, 0, 0, 1e-5f, sc.p, s));
   GemmParams q;
   q.A = n.p; q.lda = C; q.B = qkvw; q.ldb = C; q.C = qkv.p; q.ldc = 3 * C; q.bias = qkvb; q.M = (int)rows; q.N = 3 * C; q.K = C;
+  q.weight = 1;
   CGD_TRY(cgd_launch_gemm(ctx, q, s));
   AttnShape sh{B, heads, T, d, C, legacy};
   AttnBufs bf{qkvT.p, P.p, nullptr, nullptr, nullptr};
@@ -245,6 +248,7 @@ int AttnBlock::fwd(UNet& u, TV xin, int Bn, int& H, int& W, TV* o, hipStream_t s
   GemmParams p;
   p.A = a.p; p.lda = C; p.B = pw; p.ldb = C; p.C = out.p; p.ldc = C; p.bias = pb; p.R = x.p; p.ldr = x.ld; p.M = (int)rows; p.N = C;
   p.K = C;
+  p.weight = 1;
   CGD_TRY(cgd_launch_gemm(ctx, p, s));
   *o = TV{out.p, C, C};
   return 0;
@@ -263,12 +267,14 @@ int AttnBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   CGD_TRY(u.ensure(dAt, (size_t)B * C * Tp));
   GemmParams p;
   p.A = dout.p; p.lda = dout.ld; p.B = pwT; p.ldb = C; p.C = da.p; p.ldc = C; p.M = (int)rows; p.N = C; p.K = C;
+  p.weight = 1;
   CGD_TRY(cgd_launch_gemm(ctx, p, s));
   AttnShape sh{B, heads, T, d, C, legacy};
   AttnBufs bf{qkvT.p, P.p, Pt.p, dP.p, dAt.p};
   CGD_TRY(cgd_attn_bwd(ctx, sh, qkv.p, 3 * C, da.p, C, dqkv.p, 3 * C, bf, s));
   GemmParams q;
   q.A = dqkv.p; q.lda = 3 * C; q.B = qkvwT; q.ldb = 3 * C; q.C = dn.p; q.ldc = C; q.M = (int)rows; q.N = C; q.K = 3 * C;
+  q.weight = 1;
   CGD_TRY(cgd_launch_gemm(ctx, q, s));
   CGD_TRY(cgd_launch_gn_bwd(ctx, x.p, x.ld, dn.p, C, dx.p, C, dout.p, dout.ld, B, T, C, 0, sc.p, s));
   *din = TV{dx.p, C, C};
@@ -588,7 +594,10 @@ int cgd_unet_create(cgd_ctx* ctx, const cgd_unet_config* cfg, cgd_unet** out) {
   *out = u;
   return 0;
 }
-void cgd_unet_destroy(cgd_unet* u) { delete u; }
+void cgd_unet_destroy(cgd_unet* u) {
+  if (u) cgd_frag_cache_clear(u->net.ctx);  // packed copies are keyed by weight pointers that die with the net
+  delete u;
+}
 int cgd_unet_num_params(cgd_unet* u) { return (int)u->net.params.size(); }
 int cgd_unet_param_info(cgd_unet* u, int i, char* buf, int len, int64_t* numel) {
   if (i < 0 || i >= (int)u->net.params.size()) return -1;
@@ -596,8 +605,14 @@ int cgd_unet_param_info(cgd_unet* u, int i, char* buf, int len, int64_t* numel) 
   if (numel) *numel = u->net.params[i].numel;
   return 0;
 }
-int cgd_unet_set_param(cgd_unet* u, const char* name, const float* data, int64_t numel) { return u->net.set_param(name, data, numel); }
-int cgd_unet_finalize(cgd_unet* u) { return u->net.finalize(nullptr); }
+int cgd_unet_set_param(cgd_unet* u, const char* name, const float* data, int64_t numel) {
+  cgd_frag_cache_clear(u->net.ctx);
+  return u->net.set_param(name, data, numel);
+}
+int cgd_unet_finalize(cgd_unet* u) {
+  cgd_frag_cache_clear(u->net.ctx);
+  return u->net.finalize(nullptr);
+}
 int cgd_unet_forward(cgd_unet* u, const float* x, const float* t, const int64_t* y, float* out, int B, int H, int W, void* stream) {
   return u->net.forward(x, t, y, out, B, H, W, (hipStream_t)stream);
 }

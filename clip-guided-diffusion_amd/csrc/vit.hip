@@ -105,6 +105,7 @@ static GemmParams lin(const float* A, int lda, const float* Wt, int K, float* C,
                       long M, int Nn) {
   GemmParams p;
   p.A = A; p.lda = lda; p.B = Wt; p.ldb = K; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldr;
+  p.weight = 1;  // every B operand of the tower is a persistent (packed-at-load) weight
   p.M = (int)M; p.N = Nn; p.K = K;
   return p;
 }
@@ -223,7 +224,10 @@ int cgd_vit_create(cgd_ctx* ctx, const cgd_vit_config* cfg, cgd_vit** out) {
   *out = v;
   return 0;
 }
-void cgd_vit_destroy(cgd_vit* v) { delete v; }
+void cgd_vit_destroy(cgd_vit* v) {
+  if (v) cgd_frag_cache_clear(v->net.ctx);
+  delete v;
+}
 int cgd_vit_num_params(cgd_vit* v) { return (int)v->net.params.size(); }
 int cgd_vit_param_info(cgd_vit* v, int i, char* buf, int len, int64_t* numel) {
   if (i < 0 || i >= (int)v->net.params.size()) return -1;
@@ -231,8 +235,14 @@ int cgd_vit_param_info(cgd_vit* v, int i, char* buf, int len, int64_t* numel) {
   if (numel) *numel = v->net.params[i].numel;
   return 0;
 }
-int cgd_vit_set_param(cgd_vit* v, const char* name, const float* data, int64_t numel) { return v->net.set_param(name, data, numel); }
-int cgd_vit_finalize(cgd_vit* v) { return v->net.finalize(nullptr); }
+int cgd_vit_set_param(cgd_vit* v, const char* name, const float* data, int64_t numel) {
+  cgd_frag_cache_clear(v->net.ctx);
+  return v->net.set_param(name, data, numel);
+}
+int cgd_vit_finalize(cgd_vit* v) {
+  cgd_frag_cache_clear(v->net.ctx);
+  return v->net.finalize(nullptr);
+}
 int cgd_vit_forward(cgd_vit* v, const float* img, int layout, int N, float* emb, void* stream) {
   return v->net.forward(img, layout, N, emb, (hipStream_t)stream);
 }

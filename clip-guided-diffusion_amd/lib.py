@@ -45,6 +45,7 @@ _SIGS = {
     "cgd_set_precision": (i32, [vp, i32]),
     "cgd_get_precision": (i32, [vp]),
     "cgd_set_tiles": (i32, [vp, i32, i32]),
+    "cgd_set_hgemm": (i32, [vp, i32, i32, i32]),
     "cgd_profile": (i32, [vp, i32]),
     "cgd_profile_read": (i32, [vp, C.POINTER(C.c_double)]),
     "cgd_unet_create": (i32, [vp, C.POINTER(UNetConfig), C.POINTER(vp)]),
@@ -137,6 +138,9 @@ class Context:
         if tiles:
             large, small = (int(v) for v in tiles.split(","))
             self.check(self.lib.cgd_set_tiles(self.h, large, small))
+        hg = os.environ.get("CGD_HGEMM")  # tuning only: "<mode>,<min_m>,<min_chunks>" of the weight GEMM kernel
+        if hg:
+            self.check(self.lib.cgd_set_hgemm(self.h, *(int(v) for v in hg.split(","))))
         hv = os.environ.get("CGD_HCONV_VAR")  # tuning only: halo conv kernel variant (see cgd_set_hconv)
         if hv:
             self.check(self.lib.cgd_set_hconv(self.h, 1 + 16 * int(hv), 256))

@@ -48,6 +48,9 @@ def check_gemm(precision):
     out = []
     cases = [(300, 200, 128, 0, 1), (1, 1024, 256, 0, 1), (64, 1024, 4608, 0, 1), (800, 2304, 768, 0, 1), (130, 70, 52, 64, 1),
              (256, 256, 512, 128, 1), (256, 192, 1024, 64, 4), (4096, 256, 288, 0, 1)]
+    if precision != 0:  # weight GEMM kernel (hgemm.hip, tile code 513): ragged M, partial N tile, split-K, single chunk
+        cases += [(800, 768, 768, 513, 1), (200, 96, 256, 513, 2), (128, 160, 64, 513, 1), (1000, 2304, 768, 513, 1),
+                  (70, 32, 3072, 513, 5), (784, 768, 3072, 513, 0)]
     for (M, N, K, tile, sk) in cases:
         A = th.randn(M, K, generator=g(1))
         B = th.randn(N, K, generator=g(2))
