@@ -1,5 +1,5 @@
 """Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV of bench.py (steady-state step = between the last two
-conv_in_kernel<6> launches).  Usage: python tests/trace_step.py <kernel_trace.csv> [top_n]"""
+sample_update_kernel launches).  Usage: python tests/trace_step.py <kernel_trace.csv> [top_n]"""
 import collections
 import csv
 import sys
@@ -13,7 +13,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "conv_in_kernel<6>" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "sample_update_kernel" in r["Kernel_Name"]]
     step = rows[idx[-2]:idx[-1]]
     wall = (int(rows[idx[-1]]["Start_Timestamp"]) - int(step[0]["Start_Timestamp"])) / 1e6
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step) / 1e6
