@@ -33,7 +33,9 @@ struct cgd_ctx {
   size_t ws_bytes = 0;
   int num_cu = 256;
   int tile_huge = 1256, tile_large = 128, tile_small = 64;  // GEMM tile codes of the automatic selection (gemm.hip)
-  int hconv_var = 12;  // halo conv variant (default: hconv2, interleaved issue; ops_r1u: -6..-15% vs hconv_kernel): bit 2 = hconv2_kernel (16x16 tiles, pipelined; bits 3+ = its scheduling variant); else hconv_kernel with bit 0 = sched_barrier
+  int hconv_var = 12;  // halo conv variant: bit 2 = hconv2_kernel (default; ops_r1u: -6..-15% vs hconv_kernel), with bit 3 = always its
+                       // 8x16-pixel / 4-wavefront tile (two workgroups per CU; default: +0.8 % on the step vs 16x16), bit 4 = that tile for M >= 16384 only;
+                       // else hconv_kernel with bit 0 = sched_barrier
                       // after the fragment prefetch (ops_r1o: +3..10%), bit 1 = setprio
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   int hgemm_mode = 1, hgemm_min_m = 2048, hgemm_min_chunks = 3;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it the
@@ -104,6 +106,7 @@ struct GemmParams {
 size_t cgd_hconv_packed_floats(int Co, int Ci);
 int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w /*[Co][Ci][3][3]*/, float* out, int Co, int Ci, int dgrad, hipStream_t s);
 bool cgd_hconv_supported(const cgd_ctx* ctx, const GemmParams& p);
+int cgd_hconv_tile_m(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------

@@ -413,10 +413,13 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (tile == 512 && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel does not support this problem");
   if (use_h) {
     tile = 512;
-    const long tiles = (long)(p.M / 256) * cdiv(p.N, 128);
+    const int tm = cgd_hconv_tile_m(ctx, p);
+    if (p.M % tm) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel needs M to be a multiple of its pixel tile");
+    const long tiles = (long)(p.M / tm) * cdiv(p.N, 128);
     const int nchunk = p.Cin / 32;
-    if (auto_split && tiles < ctx->num_cu) {
-      long want = std::min<long>(cdiv(ctx->num_cu, tiles), nchunk / 2);
+    const long slots = (long)ctx->num_cu * (tm == 128 ? 2 : 1);  // resident workgroups (the 128-pixel tile runs two per CU)
+    if (auto_split && tiles < slots) {
+      long want = std::min<long>(cdiv(slots, tiles), nchunk / 2);
       while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
       if (want >= 2) p.splitk = (int)want;
     }

@@ -269,26 +269,31 @@ __global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag
 
 // ---------------------------------------------------------------------------------------------------------------------
 // hconv2: same operands and packed weights, re-tiled and software-pipelined.
-//   * tile = 16 x 16 pixels (any H, W that are multiples of 16): the halo patch is 18 x 18 = 324 rows (1.27x the tile,
-//     against 3.0x for a 256-wide row segment), 6 staging passes instead of 13 -> 28 fewer registers, 51.8 KB per buffer;
-//   * the patch is DOUBLE-buffered in LDS (103,680 B): chunk c+1 is loaded at the start of chunk c, converted and written
-//     into the other buffer in the middle of chunk c's taps (VALU/LDS work hidden under MFMA), ONE barrier per chunk;
+//   * tile = TH x 16 pixels (TH = 16: 8 wavefronts / 512 threads; TH = 8: 4 wavefronts / 256 threads, two workgroups per CU,
+//     whose barrier and load stalls are uncorrelated); the halo patch is (TH+2) x 18 rows (1.27x / 1.41x the tile, against
+//     3.0x for a 256-wide row segment), 6 staging passes instead of 13;
+//   * the patch is DOUBLE-buffered in LDS (103,680 / 57,600 B): chunk c+1 is loaded at the start of chunk c, converted and
+//     written into the other buffer in the middle of chunk c's taps (VALU/LDS work hidden under MFMA), ONE barrier per chunk;
 //   * explicit register software pipeline over the 18 k-steps of a chunk: A fragments (ds_read_b128) one k-step ahead,
 //     B fragments (global -> registers) two k-steps ahead in a 3-deep ring (18 % 3 == 0, so the ring is chunk-periodic and
-//     runs across chunk boundaries without a drain); sched_barrier keeps "issue loads" and "MFMA" sections apart;
+//     runs across chunk boundaries without a drain; a 4-deep ring spills);
+//   * every MFMA is followed by one load of the coming k-steps and a few conversion VALU ops (sched_group_barrier
+//     pattern), so a wavefront's own MFMA queue never drains;
 //   * MFMA operands are swapped (D = W_frag x X_frag^T): a lane then owns 4 consecutive output CHANNELS of one pixel per
 //     accumulator quad, so residual loads and output stores are 16-byte accesses along the NHWC channel axis.
-constexpr int TS = 16, PW2 = TS + 2, NP2 = PW2 * PW2;  // 324 patch rows
-constexpr int NPASS2 = 6;                               // ceil(324 / 64)
+constexpr int PW2 = 18;     // patch width: 16 + 2
+constexpr int NPASS2 = 6;   // staging passes (both tile heights)
 
-// DBG (timing experiments only, results are wrong): 1 = no B-fragment loads in the loop, 2 = no A-fragment LDS reads,
-// 4 = no patch global loads, 8 = no patch convert + LDS store, 16 = B-fragment loads always from chunk 0 (L1 hits)
-template <int MODE, int DBG = 0, int SCHED = 0>
-__global__ __launch_bounds__(512) void hconv2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
-                                                     const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
-                                                     const HConvParams p) {
+template <int MODE, int TH>
+__global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+                                                         const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
+                                                         const HConvParams p) {
   constexpr int NPL = MODE == 1 ? 2 : 1;   // bf16 planes (hi, lo)
+  constexpr int NP2 = (TH + 2) * PW2;      // patch rows: 324 / 180
   constexpr int PLANE = NP2 * HPH;         // elements per plane
+  constexpr int NT = TH * 32;              // threads
+  constexpr int RPP = NT / 8;              // patch rows per staging pass
+  static_assert(NPASS2 * RPP >= NP2, "staging passes must cover the patch");
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -301,19 +306,19 @@ __global__ __launch_bounds__(512) void hconv2_kernel(const float* __restrict__ A
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int mt = bid / ntn, n0 = (bid % ntn) * HB_N;
-  const int tpr = p.W >> 4, tpi = (p.H >> 4) * tpr;
+  const int tpr = p.W >> 4, tpi = (p.H / TH) * tpr;
   const int img = mt / tpi, trem = mt - img * tpi;
-  const int y0 = (trem / tpr) << 4, x0 = (trem % tpr) << 4;
+  const int y0 = (trem / tpr) * TH, x0 = (trem % tpr) << 4;
   const int HW = p.H * p.W;
   const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
   const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
 
-  // per-thread patch staging slots: 64 patch rows per pass, 8 float4 per row
+  // per-thread patch staging slots: RPP patch rows per pass, 8 float4 per row
   const int c4 = tid & 7;
   int poff[NPASS2];
 #pragma unroll
   for (int j = 0; j < NPASS2; ++j) {
-    const int prow = (tid >> 3) + 64 * j;
+    const int prow = (tid >> 3) + RPP * j;
     poff[j] = -2;  // beyond the patch
     if (prow < NP2) {
       const int py = prow / PW2, px = prow - py * PW2;
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(512) void hconv2_kernel(const float* __restrict__ A
   {                                                                                                 \
     _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                               \
       if (j < NPASS2 - 1 || poff[j] != -2) { /* only the last pass has rows beyond the patch */     \
-        const int prow = (tid >> 3) + 64 * j;                                                       \
+        const int prow = (tid >> 3) + RPP * j;                                                      \
         const f32x4 v = poff[j] >= 0 ? pr[j] : z4;                                                  \
         const bf16x4 hi = to_bf16x4(v);                                                             \
         *(bf16x4*)&(DSTB)[prow * HPH + c4 * 4] = hi;                                                \
@@ -392,11 +397,11 @@ __global__ __launch_bounds__(512) void hconv2_kernel(const float* __restrict__ A
   // B fragments of k-step (TAP, KS) of the chunk whose block base is BASE: [channel block j][plane]
 #define B_LOAD2(DST, BASE, TAP, KS)                                                                 \
   {                                                                                                 \
-    const uint4* q_ = (BASE) + ((TAP) * 4 + (KS) * 2) * 64;                                         \
-    DST[0][0] = q_[0];                                                                              \
-    if constexpr (MODE == 1) DST[0][1] = q_[64];                                                    \
-    DST[1][0] = q_[bj1];                                                                            \
-    if constexpr (MODE == 1) DST[1][1] = q_[bj1 + 64];                                              \
+    const uint4* bp_ = (BASE) + ((TAP) * 4 + (KS) * 2) * 64;                                        \
+    DST[0][0] = bp_[0];                                                                             \
+    if constexpr (MODE == 1) DST[0][1] = bp_[64];                                                   \
+    DST[1][0] = bp_[bj1];                                                                           \
+    if constexpr (MODE == 1) DST[1][1] = bp_[bj1 + 64];                                             \
   }
   // 12 MFMAs of one k-step; product-major so that the same accumulator recurs only every 4th instruction
 #define MFMA12(AQ, BQ)                                                                              \
@@ -425,14 +430,14 @@ __global__ __launch_bounds__(512) void hconv2_kernel(const float* __restrict__ A
     const bool more = c + 1 < c1;
     const __bf16* cur = lds + ((c - c0) & 1) * (NPL * PLANE);
     __bf16* nxt = lds + (((c - c0) & 1) ^ 1) * (NPL * PLANE);
-    const uint4* __restrict__ cb = Bw0 + (long)((DBG & 16) ? 0 : c) * (9 * 4 * 64);
-    const uint4* __restrict__ nb = Bw0 + (long)((DBG & 16) ? 0 : (c + 1 < nchunk ? c + 1 : c)) * (9 * 4 * 64);  // clamped: loads stay unconditional
-    if (more && !(DBG & 4)) PATCH_LOAD2(c + 1);  // in flight during the first taps
+    const uint4* __restrict__ cb = Bw0 + (long)c * (9 * 4 * 64);
+    const uint4* __restrict__ nb = Bw0 + (long)(c + 1 < nchunk ? c + 1 : c) * (9 * 4 * 64);  // clamped: loads stay unconditional
+    if (more) PATCH_LOAD2(c + 1);  // in flight during the first taps
     A_LOAD2(af[0], cur, 0, 0);
 #pragma unroll
     for (int q = 0; q < 18; ++q) {
-      // ---- issue section: A fragments one k-step ahead, B fragments two k-steps ahead
-      if (q + 1 < 18 && !(DBG & 2)) {
+      // ---- issue: A fragments one k-step ahead, B fragments two k-steps ahead
+      if (q + 1 < 18) {
         switch (q + 1) {  // (tap, ks) must be compile-time constants for the LDS immediates
 #define CASE_A(Q) case Q: A_LOAD2(af[(Q) & 1], cur, (Q) >> 1, (Q) & 1); break;
           CASE_A(1) CASE_A(2) CASE_A(3) CASE_A(4) CASE_A(5) CASE_A(6) CASE_A(7) CASE_A(8) CASE_A(9)
@@ -440,42 +445,22 @@ __global__ __launch_bounds__(512) void hconv2_kernel(const float* __restrict__ A
 #undef CASE_A
         }
       }
-      if (!(DBG & 1)) {
+      {
         const int q2 = (q + 2) % 18;
         const uint4* __restrict__ base = (q + 2 < 18) ? cb : nb;
         B_LOAD2(bq[(q + 2) % 3], base, q2 >> 1, q2 & 1);
       }
-      if constexpr (SCHED == 0) __builtin_amdgcn_sched_barrier(0);
-      // ---- MFMA section (the patch conversion of the next chunk rides under taps 4..6)
-      MFMA12(af[(DBG & 2) ? 0 : (q & 1)], bq[(DBG & 1) ? 0 : (q % 3)]);
-      if constexpr (SCHED == 0) {
-        if (more && !(DBG & 8)) {
-          if (q == 8) PATCH_STORE2(nxt, 0, 2);
-          if (q == 10) PATCH_STORE2(nxt, 2, 4);
-          if (q == 12) PATCH_STORE2(nxt, 4, NPASS2);
-        }
-      } else {
-        // unconditional (the last chunk rewrites the idle buffer with stale data): no branch inside the scheduling region
-        if (q == 6) PATCH_STORE2(nxt, 0, 1);
-        if (q == 7) PATCH_STORE2(nxt, 1, 2);
-        if (q == 8) PATCH_STORE2(nxt, 2, 3);
-        if (q == 9) PATCH_STORE2(nxt, 3, 4);
-        if (q == 10) PATCH_STORE2(nxt, 4, 5);
-        if (q == 11) PATCH_STORE2(nxt, 5, 6);
-        // fine-grained interleave inside this k-step: every MFMA is followed by one load of the next k-steps and a few
-        // VALU / LDS-write instructions of the patch conversion, so the wavefront's own MFMA queue never drains
+      // ---- 12 MFMAs; the conversion of the next chunk's patch rides under k-steps 6..11 (unconditional: the last chunk
+      //      rewrites the idle buffer with stale data, so there is no branch inside the scheduling region)
+      MFMA12(af[q & 1], bq[q % 3]);
+      if (q >= 6 && q <= 11) PATCH_STORE2(nxt, q - 6, q - 5);
 #pragma unroll
-        for (int r = 0; r < 12; ++r) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
-          if (r % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-          if (r % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                  // VALU
-          if (r % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-        }
-      }
-      if ((DBG & 8) && !(DBG & 4) && q == 12) {
-#pragma unroll
-        for (int j = 0; j < NPASS2; ++j) asm volatile("" ::"v"(pr[j]));  // keep the loads alive
+      for (int r = 0; r < 12; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+        if (r % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        if (r % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                  // VALU
+        if (r % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -572,17 +557,27 @@ bool cgd_hconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
   if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
   if (p.H <= 0 || p.W <= 0) return false;
   if (p.ups && ((p.H | p.W) & 1)) return false;
-  if (p.M % HB_M) return false;
-  if (ctx->hconv_var & 4) {  // hconv2: 16x16-pixel tiles, 16-byte epilogue accesses
+  if (ctx->hconv_var & 4) {  // hconv2: TH x 16-pixel tiles, 16-byte epilogue accesses
     if ((p.H & 15) || (p.W & 15)) return false;
     if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
     if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
     return true;
   }
+  if (p.M % HB_M) return false;
   const long hw = (long)p.H * p.W;
   if (hw % HB_M) return false;
   if (p.W >= HB_M ? (p.W % HB_M) != 0 : (HB_M % p.W) != 0) return false;
   return true;
+}
+
+// pixels per workgroup tile of the variant that cgd_launch_hconv will use: hconv2's 8x16 tile (two workgroups per CU)
+// when forced (bit 3) or, in auto mode (bit 4), for the big maps where it wins (ops_r1aj: -10 % at 256^2, neutral at 128^2,
+// mixed below because the split-K factor changes)
+int cgd_hconv_tile_m(const cgd_ctx* ctx, const GemmParams& p) {
+  if (!(ctx->hconv_var & 4)) return HB_M;
+  if (ctx->hconv_var & 8) return 128;
+  if ((ctx->hconv_var & 16) && p.M >= 16384) return 128;
+  return HB_M;
 }
 
 int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
@@ -590,20 +585,21 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.A = g.A; p.Bp = (const uint4*)g.Bpk; p.C = g.C; p.bias = g.bias; p.R = g.R; p.ws = g.ws;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
-  dim3 grid((g.M / HB_M) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
+  const int tm = cgd_hconv_tile_m(ctx, g);
+  dim3 grid((g.M / tm) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
 #define HC_LAUNCH(M_, V_) hipLaunchKernelGGL((hconv_kernel<M_, V_>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
-#define HC2_LAUNCH(M_, D_, S_) hipLaunchKernelGGL((hconv2_kernel<M_, D_, S_>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
+#define HC2_LAUNCH(M_, TH_) hipLaunchKernelGGL((hconv2_kernel<M_, TH_>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
   if (ctx->hconv_var & 4) {
     if (ctx->precision == CGD_PREC_BF16X3) {
-      switch (ctx->hconv_var >> 3) {  // scheduling variants / timing experiments (DBG != 0: wrong results)
-        case 0: HC2_LAUNCH(1, 0, 0); break;
-        case 1: HC2_LAUNCH(1, 0, 1); break;
-        case 2: HC2_LAUNCH(1, 1, 1); break;
-        case 3: HC2_LAUNCH(1, 12, 1); break;
-        default: HC2_LAUNCH(1, 15, 0); break;
-      }
+      if (tm == 128)
+        HC2_LAUNCH(1, 8);
+      else
+        HC2_LAUNCH(1, 16);
     } else {
-      HC2_LAUNCH(2, 0, 0);
+      if (tm == 128)
+        HC2_LAUNCH(2, 8);
+      else
+        HC2_LAUNCH(2, 16);
     }
   } else if (ctx->precision == CGD_PREC_BF16X3) {
     switch (ctx->hconv_var & 3) {

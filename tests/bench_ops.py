@@ -19,7 +19,7 @@ SHAPES_ALL = [  # (H=W, Cin, Cout, launches per step in config 2 (fwd+dgrad, app
     (8, 1024, 1024, 18), (8, 2048, 1024, 3), (8, 1024, 2048, 3),
 ]
 SHAPES = SHAPES_ALL
-TILES = [128, 5121, 5124, 5132]  # igemm 128x128 | hconv_kernel | hconv2 sectioned | hconv2 interleaved  # 512x = halo-staged conv kernel, variant x (1: hconv_kernel, 4: hconv2_kernel)
+TILES = [5121, 5124, 5132]  # hconv_kernel | hconv2 16x16 tiles | hconv2 8x16 tiles (2 workgroups / CU)  # 512x = halo-staged conv kernel, variant x (1: hconv_kernel, 4: hconv2_kernel)
 
 
 def main():

@@ -86,7 +86,7 @@ def check_conv(precision):
             out.append(rec(f"conv3x3 dgrad[p{precision}] {Ci}<-{Co}", got.permute(0, 3, 1, 2), xr.grad.float()))
     # halo-staged conv kernel (tile code 512): fragment-packed bf16 weights, patch staging, split-K over channel chunks
     if precision != 0:
-        # 1: hconv_kernel (row-segment tiles); 4 / 12: hconv2_kernel (16x16 tiles, double-buffered; sectioned / interleaved issue)
+        # 1: hconv_kernel (row-segment tiles); 4 / 12: hconv2_kernel (16x16 / 8x16-pixel tiles, double-buffered patch, interleaved issue)
         for var in (1, 4, 12):
             ctx.check(ctx.lib.cgd_set_hconv(ctx.h, 1 + 16 * var, 256))
             for (Bn, H, W, Ci, Co, ups, sk) in [(1, 256, 256, 32, 64, 0, 1), (2, 16, 16, 64, 160, 0, 1), (1, 32, 32, 128, 128, 0, 2),
