@@ -73,10 +73,6 @@ def clip_guided_diffusion(
     if not use_magnitude and image_size == 64:
         use_magnitude = True
         tqdm.write("Enabling magnitude for 64x64 checkpoints.")
-    if init_image and init_scale != 0:
-        raise NotImplementedError("init_scale (LPIPS-VGG perceptual loss) is the next SURVEY.md 8(f) row; use init_image with "
-                                  "skip_timesteps and init_scale=0")
-
     Path(prefix_path).mkdir(parents=True, exist_ok=True)
     Path(checkpoints_dir).mkdir(parents=True, exist_ok=True)
     diffusion_path = script_util.download_guided_diffusion(image_size=image_size, checkpoints_dir=checkpoints_dir, class_cond=class_cond)
@@ -113,7 +109,7 @@ def clip_guided_diffusion(
         import numpy as np
         from PIL import Image
         pil = Image.open(script_util.fetch(init_image)).convert("RGB").resize((image_size, image_size))
-        init_tensor = th.from_numpy(np.asarray(pil)).float().div(255).permute(2, 0, 1).to(device).unsqueeze(0).mul(2).sub(1)
+        init_tensor = th.from_numpy(np.array(pil)).float().div(255).permute(2, 0, 1).to(device).unsqueeze(0).mul(2).sub(1)
 
     model_kwargs = {}
     if class_cond:
@@ -131,7 +127,10 @@ def clip_guided_diffusion(
     cond_fn = ClipGuidance(
         gd_model.ctx, gd_model, clip_model.tower, diffusion, target_embeds, weight_t, num_cutouts, cutout_power=cutout_power,
         clip_guidance_scale=clip_guidance_scale, tv_scale=tv_scale, range_scale=range_scale, sat_scale=sat_scale, use_magnitude=use_magnitude,
-        reduce_clip=reduce_clip, progressive_cutout=progressive_cutout, cached_cutouts=cached_cutouts, make_cutouts=make_cutouts)
+        reduce_clip=reduce_clip, progressive_cutout=progressive_cutout, cached_cutouts=cached_cutouts, make_cutouts=make_cutouts,
+        # "initialized lazily as it can use a bit of VRAM" (reference cgd.py:146-148): only with an init image and a non-zero scale
+        lpips=script_util.load_lpips(gd_model.ctx, checkpoints_dir, device) if (init_tensor is not None and init_scale != 0) else None,
+        init_tensor=init_tensor, init_scale=init_scale)
 
     loop = diffusion.ddim_sample_loop_progressive if timestep_respacing.startswith("ddim") else diffusion.p_sample_loop_progressive
     try:

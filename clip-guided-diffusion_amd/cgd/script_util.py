@@ -161,3 +161,19 @@ def load_guided_diffusion(checkpoint_path: str, image_size: int, class_cond: boo
                                                   timestep_respacing=cfg["timestep_respacing"] or "",
                                                   rescale_timesteps=cfg["rescale_timesteps"])
     return model, _sampler.GuidedSampler(ctx, tables)
+
+
+def load_lpips(ctx, checkpoints_dir: str = CACHE_PATH, device="cuda"):
+    """Device LPIPS-VGG16 (reference: `lpips.LPIPS(net='vgg')`, cgd.py:147-148).  Weights: `<checkpoints_dir>/lpips_vgg16.pt`, a
+    state dict with the package's keys (torchvision VGG16 trunk as `net.slice{k}.{idx}.weight|bias`, heads `lin{k}.model.1.weight`);
+    with CGD_SYNTHETIC_WEIGHTS=1 seeded synthetic weights are used (no network on the build / bench boxes)."""
+    from cgd_amd import nets, synthetic
+    net = nets.LpipsVGG(ctx)
+    path = os.path.join(checkpoints_dir, "lpips_vgg16.pt")
+    if os.path.isfile(path):
+        sd = th.load(path, map_location="cpu")
+        sd = {k: (v.reshape(-1) if k.startswith("lin") else v) for k, v in sd.items()}
+        return net.load_state_dict({k: v.to(device) for k, v in sd.items() if k.startswith(("net.slice", "lin"))})
+    if synthetic_weights_enabled():
+        return net.load_state_dict(synthetic.lpips_state_dict(device=device))
+    raise FileNotFoundError(f"{path} not found: export lpips.LPIPS(net='vgg').state_dict() there (or set CGD_SYNTHETIC_WEIGHTS=1)")

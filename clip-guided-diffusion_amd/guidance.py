@@ -96,7 +96,8 @@ def prompt_weight_matrix(weights, batch, device):
 class ClipGuidance:
     def __init__(self, ctx, unet, clip_tower, diffusion, target_embeds, weights, num_cutouts, cutout_power=1.0,
                  clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0, sat_scale=0.0, use_magnitude=False,
-                 reduce_clip=False, progressive_cutout=False, cached_cutouts=False, make_cutouts=None):
+                 reduce_clip=False, progressive_cutout=False, cached_cutouts=False, make_cutouts=None, lpips=None, init_tensor=None,
+                 init_scale=0.0):
         self.ctx, self.unet, self.clip, self.diffusion = ctx, unet, clip_tower, diffusion
         dev = target_embeds.device
         self.targets_n = F.normalize(target_embeds.float(), dim=-1).contiguous()
@@ -106,6 +107,12 @@ class ClipGuidance:
         self.use_magnitude = bool(use_magnitude)
         self.reduce_clip, self.progressive_cutout, self.cached_cutouts = reduce_clip, progressive_cutout, cached_cutouts
         self.make_cutouts = make_cutouts or MakeCutouts(clip_tower.input_resolution, num_cutouts, cutout_power, ctx=ctx)
+        # init-image perceptual term (cgd.py:147-148,220-224): `lpips` is a nets.LpipsVGG, its reference = the init image
+        self.lpips, self.init_scale, self.init_tensor = None, float(init_scale), None
+        if lpips is not None and init_tensor is not None and init_scale != 0:
+            self.lpips, self.init_tensor = lpips, init_tensor.float()
+        self._lpips_ref_batch = 0
+        self.lpips_loss = None
         self.current_timestep = None  # closure counter of cgd.py:149,265-267
         self.scalars = None
         self.coords_tape = None  # optional replay of cutout coordinates (tests)
@@ -170,7 +177,16 @@ class ClipGuidance:
                                          clip_part.data_ptr(), cutn, B, P, self.clip.out_dim, self.cgs, s))
         dpatches = self.clip.dgrad(demb, self._b("dpatches", tuple(patches.shape), dev))
         gclip = self._b("gclip", (B, 3, H, W), dev)
-        ctx.check(lib.cgd_cutouts_bwd(ctx.h, dpatches.data_ptr(), geo.data_ptr(), gclip.data_ptr(), B, H, W, cutn, cs, 1, patch, 0, s))
+        acc = 0
+        if self.lpips is not None:
+            if self._lpips_ref_batch != B:  # the reference broadcasts a (1,3,H,W) init image over the batch (cgd.py:221)
+                self.lpips.set_reference(self.init_tensor.to(dev).expand(B, -1, -1, -1).contiguous())
+                self._lpips_ref_batch = B
+            # d(init_scale * sum_b lpips(x_in_b, init_b)) / dx_in goes into the same buffer as the CLIP gradient w.r.t. x_in
+            self.lpips_loss, _ = self.lpips.loss_grad(x_in, grad_scale=self.init_scale, g=gclip, accumulate=False,
+                                                      loss=self._b("lpips_loss", (B,), dev))
+            acc = 1
+        ctx.check(lib.cgd_cutouts_bwd(ctx.h, dpatches.data_ptr(), geo.data_ptr(), gclip.data_ptr(), B, H, W, cutn, cs, 1, patch, acc, s))
         nblk = lib.cgd_guidance_part_blocks(B, H, W)
         gdir = self._b("gdir", (B, 3, H, W), dev)
         seed6 = self._b("seed6", (B, 6, H, W), dev)
@@ -195,6 +211,9 @@ class ClipGuidance:
         if self.sats != 0:
             out["Saturation Loss"] = v[3]
         out["Total Loss"] = v[4]
+        if self.lpips is not None:
+            out["Init VGG Loss"] = float(self.lpips_loss.sum().item()) * self.init_scale
+            out["Total Loss"] += out["Init VGG Loss"]
         if self.use_magnitude:
             out["Magnitude"] = v[5]
         out["Grad"] = v[6]

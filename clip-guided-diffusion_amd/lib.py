@@ -64,6 +64,14 @@ _SIGS = {
     "cgd_vit_finalize": (i32, [vp]),
     "cgd_vit_forward": (i32, [vp, vp, i32, i32, vp, vp]),
     "cgd_vit_dgrad": (i32, [vp, vp, vp, vp]),
+    "cgd_lpips_create": (i32, [vp, C.POINTER(vp)]),
+    "cgd_lpips_destroy": (None, [vp]),
+    "cgd_lpips_num_params": (i32, [vp]),
+    "cgd_lpips_param_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64)]),
+    "cgd_lpips_set_param": (i32, [vp, C.c_char_p, vp, i64]),
+    "cgd_lpips_finalize": (i32, [vp]),
+    "cgd_lpips_set_reference": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cgd_lpips_loss_grad": (i32, [vp, vp, f32, vp, vp, i32, vp]),
     "cgd_cutouts_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cgd_cutouts_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cgd_spherical_loss": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),

@@ -157,3 +157,37 @@ class ClipImageTower(_Net):
         self.ctx.check(self.ctx.lib.cgd_vit_dgrad(self.h, d_emb.data_ptr(), d_img.data_ptr(), L.stream_ptr()))
         self._keep_g = d_emb
         return d_img
+
+
+class LpipsVGG(_Net):
+    """`lpips.LPIPS(net='vgg')` against a fixed reference image (/root/reference/cgd/cgd.py:147-148,220-224): value per sample and
+    gradient w.r.t. the first argument.  `load_state_dict` takes the package's keys (`net.slice{k}.{idx}.*`, `lin{k}.model.1.weight`)."""
+    _prefix = "lpips"
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.cgd_lpips_create(ctx.h, C.byref(h)))
+        self.h = h
+        self._ref = None
+
+    def set_reference(self, ref):
+        """ref (B,3,H,W) in [-1,1] (the init image); H, W multiples of 16."""
+        ref = ref.contiguous().float()
+        B, _, H, W = ref.shape
+        self.ctx.check(self.ctx.lib.cgd_lpips_set_reference(self.h, ref.data_ptr(), B, H, W, L.stream_ptr()))
+        self._ref = ref
+        return self
+
+    def loss_grad(self, x, grad_scale=1.0, g=None, accumulate=False, loss=None):
+        """Returns (loss (B,), g (B,3,H,W)) with g (+)= grad_scale * d(sum loss)/dx."""
+        x = x.contiguous().float()
+        assert self._ref is not None and tuple(x.shape) == tuple(self._ref.shape), "set_reference first (same shape)"
+        if g is None:
+            g = th.zeros_like(x) if accumulate else th.empty_like(x)
+        if loss is None:
+            loss = th.empty(x.shape[0], device=x.device, dtype=th.float32)
+        self.ctx.check(self.ctx.lib.cgd_lpips_loss_grad(self.h, x.data_ptr(), float(grad_scale), loss.data_ptr(), g.data_ptr(),
+                                                       int(bool(accumulate)), L.stream_ptr()))
+        self._keep = x
+        return loss, g

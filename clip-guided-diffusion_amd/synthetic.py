@@ -37,3 +37,18 @@ def flat_unpack(flat, specs):
         out[name] = flat[off:off + numel]
         off += numel
     return out
+
+
+def lpips_state_dict(seed=777, device="cpu"):
+    """Seeded stand-in for the LPIPS-VGG16 weights with the package's key names: fan-in scaled 3x3 convolutions, small biases and
+    non-negative 1x1 heads (the released heads are clamped to >= 0).  Same recipe as the test oracle, generated independently."""
+    spec = [(1, 0, 3, 64), (1, 2, 64, 64), (2, 5, 64, 128), (2, 7, 128, 128), (3, 10, 128, 256), (3, 12, 256, 256), (3, 14, 256, 256),
+            (4, 17, 256, 512), (4, 19, 512, 512), (4, 21, 512, 512), (5, 24, 512, 512), (5, 26, 512, 512), (5, 28, 512, 512)]
+    g = th.Generator().manual_seed(seed)
+    sd = {}
+    for (sl, idx, ci, co) in spec:
+        sd[f"net.slice{sl}.{idx}.weight"] = (th.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5).to(device)
+        sd[f"net.slice{sl}.{idx}.bias"] = (th.randn(co, generator=g) * 0.05).to(device)
+    for k, c in enumerate((64, 128, 256, 512, 512)):
+        sd[f"lin{k}.model.1.weight"] = (th.rand(1, c, 1, 1, generator=g) * 0.2).to(device)
+    return sd

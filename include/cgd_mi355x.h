@@ -93,6 +93,21 @@ int cgd_vit_finalize(cgd_vit* v);
 int cgd_vit_forward(cgd_vit* v, const float* img, int layout, int N, float* emb /* (N,out_dim) */, void* stream);
 int cgd_vit_dgrad(cgd_vit* v, const float* d_emb, float* d_img /* same layout as the forward input */, void* stream);
 
+/* ---- LPIPS-VGG16 init loss: replaces lpips.LPIPS(net='vgg') (cgd/cgd.py:147-148) and `lpips_vgg(x_in, init_tensor)` with its
+ *      backward to x_in (cgd.py:220-224,228).  Parameters use the package's names (net.slice{k}.{idx}.weight|bias,
+ *      lin{k}.model.1.weight).  set_reference: the fixed second argument (init image, (B,3,H,W) NCHW in [-1,1], H and W
+ *      multiples of 16).  loss_grad: loss[b] = lpips(x_b, ref_b);  g (B,3,H,W) (+)= grad_scale * d(sum_b loss_b)/dx. ---- */
+typedef struct cgd_lpips cgd_lpips;
+int cgd_lpips_create(cgd_ctx* ctx, cgd_lpips** out);
+void cgd_lpips_destroy(cgd_lpips* v);
+int cgd_lpips_num_params(cgd_lpips* v);
+int cgd_lpips_param_info(cgd_lpips* v, int index, char* name_buf, int buf_len, int64_t* numel);
+int cgd_lpips_set_param(cgd_lpips* v, const char* name, const float* data, int64_t numel);
+int cgd_lpips_finalize(cgd_lpips* v);
+int cgd_lpips_set_reference(cgd_lpips* v, const float* ref_nchw, int B, int H, int W, void* stream);
+int cgd_lpips_loss_grad(cgd_lpips* v, const float* x_nchw, float grad_scale, float* loss /* [B] */, float* g_nchw, int accumulate,
+                        void* stream);
+
 /* ---- cutouts: replaces MakeCutouts.forward (cgd/modules.py:50-66) + x.add(1).div(2) (cgd.py:190) + CLIP_NORMALIZE
  *      (clip_util.py:45).  coords: device int32 [cutn][4] = (oy, ox, h, w) of each (possibly truncated) crop. ---- */
 int cgd_cutouts_fwd(cgd_ctx* ctx, const float* x_in, const int32_t* coords, float* out, int B, int H, int W, int cutn, int cut_size,

@@ -83,7 +83,7 @@ class MakeCutouts(th.nn.Module):
 def make_cond_fn(*, diffusion, clip_model, make_cutouts, target_embeds, weights, num_cutouts,
                  clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0, sat_scale=0.0,
                  use_magnitude=False, reduce_clip=False, progressive_cutout=False, cached_cutouts=False,
-                 state=None, coords_tape=None):
+                 state=None, coords_tape=None, lpips_model=None, init_tensor=None, init_scale=0.0):
     """Returns (cond_fn, state).  `state['current_timestep']` plays the role of the reference's closure
     variable (cgd.py:149,265,267): the caller sets it to num_timesteps-1 before iterating and decrements
     it after every yielded sample.  `coords_tape` (optional list of per-call coordinate lists) replays
@@ -124,6 +124,10 @@ def make_cond_fn(*, diffusion, clip_model, make_cutouts, target_embeds, weights,
             sat_l = th.abs(x_in - x_in.clamp(min=-1, max=1)).mean().sum() * sat_scale
             log["Saturation Loss"] = sat_l.item()
             loss = loss + sat_l
+        if init_tensor is not None and init_scale != 0:  # cgd.py:220-224
+            init_l = lpips_model(x_in, init_tensor).sum() * init_scale
+            log["Init VGG Loss"] = init_l.item()
+            loss = loss + init_l
         log["Total Loss"] = loss.item()
         g = -th.autograd.grad(loss, x)[0]
         if use_magnitude:

@@ -353,6 +353,31 @@ def build_vit_pair(ctx, name="ViT-B/32", seed=4321):
     return ref, dev
 
 
+def check_lpips(precision):
+    """LPIPS-VGG16 init loss: per-sample value and gradient w.r.t. x against the CPU oracle (autograd)."""
+    from cgd_amd import nets
+    from oracle import lpips_vgg as olp
+    ctx = _ctx(precision)
+    out = []
+    orc = olp.synthetic_init_(olp.LpipsVGG()).double().eval()
+    dev_net = nets.LpipsVGG(ctx)
+    dev_net.load_state_dict({k: v.float().to(DEV) for k, v in orc.lpips_state_dict().items()})
+    for (B, H, W) in [(2, 64, 64), (1, 96, 128)]:
+        ref = (th.rand(B, 3, H, W, generator=g(70)) * 2 - 1)
+        x = (ref + 0.3 * th.randn(B, 3, H, W, generator=g(71))).clamp(-1.2, 1.2)
+        xr = x.double().requires_grad_()
+        val = orc(xr, ref.double()).flatten()
+        (val.sum() * 7.0).backward()
+        dev_net.set_reference(ref.to(DEV))
+        loss, gx = dev_net.loss_grad(x.to(DEV), grad_scale=7.0)
+        out.append(rec(f"lpips loss[p{precision}] B{B} {H}x{W}", loss, val.float()))
+        out.append(rec(f"lpips grad[p{precision}] B{B} {H}x{W}", gx, xr.grad.float()))
+        base = th.randn(B, 3, H, W, generator=g(72))
+        _, gacc = dev_net.loss_grad(x.to(DEV), grad_scale=7.0, g=base.to(DEV).clone(), accumulate=True)
+        out.append(rec(f"lpips grad accumulate[p{precision}] B{B} {H}x{W}", gacc, xr.grad.float() + base))
+    return out
+
+
 def check_vit(name, precision, N=3):
     ctx = _ctx(precision)
     ref, dev = build_vit_pair(ctx, name)

@@ -20,7 +20,7 @@ def make_tape(B, H, W, nsteps, num_classes, cutn, cut_size, cut_pow=1.0, seed=0)
 
 def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_cfg=(64, 16, 128, 2, 2, 64), P=1, hw=None,
                respacing="50", schedule="linear", use_magnitude=False, sat_scale=0.0, scales=(1000.0, 150.0, 50.0), skip=0,
-               weights=None):
+               weights=None, init_scale=0.0):
     from cgd_amd import diffusion as dd
     from cgd_amd import guidance as dg
     from cgd_amd import lib, nets, sampler
@@ -55,11 +55,22 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
     w = w / w.sum().abs()
     cgs, tvs, rs = scales
 
+    # optional init image + LPIPS-VGG16 perceptual term (cgd.py:147-148,220-224); the init image is (1,3,H,W) and broadcasts
+    init_cpu, o_lp, d_lp = None, None, None
+    if init_scale:
+        from oracle import lpips_vgg as olp
+        init_cpu = th.tanh(th.randn(1, 3, H, W, generator=g(90)))
+        o_lp = olp.synthetic_init_(olp.LpipsVGG()).eval()
+        for p in o_lp.parameters():
+            p.requires_grad_(False)
+        d_lp = nets.LpipsVGG(ctx).load_state_dict({k: v.float().to(DEV) for k, v in o_lp.lpips_state_dict().items()})
+
     # ---- oracle ----
     mk = og.MakeCutouts(res, cutn)
     o_cond, o_state = og.make_cond_fn(diffusion=o_diff, clip_model=ref_clip, make_cutouts=mk, target_embeds=targets, weights=w,
                                       num_cutouts=cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs, sat_scale=sat_scale,
-                                      use_magnitude=use_magnitude, coords_tape=tape["coords"])
+                                      use_magnitude=use_magnitude, coords_tape=tape["coords"], lpips_model=o_lp, init_tensor=init_cpu,
+                                      init_scale=init_scale)
     mkw = {"y": th.zeros(B, dtype=th.long)} if kw.get("num_classes") else {}
     loop = o_diff.ddim_sample_loop_progressive if ddim else o_diff.p_sample_loop_progressive
     o_gen = loop(ref_unet, (B, 3, H, W), clip_denoised=False, cond_fn=o_cond, model_kwargs=dict(mkw), device="cpu",
@@ -74,7 +85,8 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
 
     # ---- device ----
     guid = dg.ClipGuidance(ctx, dev_unet, dev_clip, smp, targets.to(DEV), w, cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs,
-                           sat_scale=sat_scale, use_magnitude=use_magnitude)
+                           sat_scale=sat_scale, use_magnitude=use_magnitude, lpips=d_lp,
+                           init_tensor=None if init_cpu is None else init_cpu.to(DEV), init_scale=init_scale)
     guid.coords_tape = tape["coords"]
     smp.tape = tape
     dmkw = {"y": th.zeros(B, dtype=th.long, device=DEV)} if kw.get("num_classes") else {}
@@ -83,7 +95,7 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
                   randomize_class=bool(dmkw), cond_fn_with_grad=True)
     guid.current_timestep = N - 1
     recs = []
-    tag = f"step[{case} p{precision} {'ddim' if ddim else 'p'} B{B} {H}x{W} mag{int(use_magnitude)} sat{sat_scale}]"
+    tag = f"step[{case} p{precision} {'ddim' if ddim else 'p'} B{B} {H}x{W} mag{int(use_magnitude)} sat{sat_scale} init{init_scale}]"
     for k, out in enumerate(d_gen):
         guid.current_timestep -= 1
         th.cuda.synchronize()
@@ -91,6 +103,6 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
         recs.append(rec(f"{tag} step{k} sample", out["sample"], o_s))
         recs.append(rec(f"{tag} step{k} pred_xstart", out["pred_xstart"], o_x0))
         lg = guid.log()
-        for key in ("CLIP Loss", "TV Loss", "Range Loss", "Total Loss"):
+        for key in ("CLIP Loss", "TV Loss", "Range Loss", "Total Loss") + (("Init VGG Loss",) if init_scale else ()):
             recs.append(rec(f"{tag} step{k} {key}", th.tensor([lg[key]]), th.tensor([o_log[key]])))
     return recs

@@ -68,3 +68,8 @@ def test_unet_256_checkpoint_shape():
 @pytest.mark.parametrize("precision", [0, 1])
 def test_clip_vit_b32(precision):
     _assert_all(pc.check_vit("ViT-B/32", precision))
+
+
+def test_lpips_vgg16_loss_and_grad():
+    # the trunk always runs on the exact-fp32 MFMA path (discontinuous gradient: ReLU masks, pooling arg-max)
+    _assert_all(pc.check_lpips(1))

@@ -37,6 +37,13 @@ def test_cosine_nonsquare_weighted_prompts():
                               use_magnitude=True))
 
 
+def test_init_image_lpips_term():
+    # init image broadcast over the batch + LPIPS-VGG16 perceptual term (cgd.py:220-224).  init_scale 100: the LPIPS gradient is
+    # discontinuous (ReLU / max-pool masks), so two fp32 implementations differ by a few mask flips; at the reference's
+    # typical 1000 that puts 4e-4 absolute on the sample (diag_r1al), beyond atol 1e-4, while every loss scalar still agrees to 1e-6
+    _assert_all(sc.check_step("mini", 1, respacing="50", steps=2, B=2, init_scale=100.0))
+
+
 def test_dropin_generator_yields_batch_idx_path(tmp_path, monkeypatch):
     """reference test.py:159-168 (yield order for batch_size=2) and :139-143 (first item not None), on synthetic weights."""
     monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
@@ -51,6 +58,24 @@ def test_dropin_generator_yields_batch_idx_path(tmp_path, monkeypatch):
     for _, path in first_two:
         assert os.path.isfile(path) and path.endswith("0000.png")
     assert os.path.isfile(tmp_path / "current.png")
+
+
+def test_dropin_generator_with_init_image_and_lpips(tmp_path, monkeypatch):
+    """init_image + skip_timesteps + init_scale (config 4 of BASELINE.json, reference cgd.py:111-119,147-148,220-224) through the drop-in
+    generator: the LPIPS-VGG16 module is created lazily and its loss shows up in the scalar log."""
+    import numpy as np
+    from PIL import Image
+    monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 255, (80, 96, 3), dtype=np.uint8)).save(tmp_path / "init.png")
+    from cgd.cgd import clip_guided_diffusion
+    gen = clip_guided_diffusion(prompts=["Loose seal."], image_size=64, batch_size=1, num_cutouts=2, timestep_respacing="25",
+                                noise_schedule="cosine", prefix_path=str(tmp_path / "out"), checkpoints_dir=str(tmp_path / "ckpt"),
+                                save_frequency=1, progress=False, device="cuda", init_image=str(tmp_path / "init.png"), init_scale=500,
+                                skip_timesteps=20)
+    b, path = next(gen)
+    assert b == 0 and os.path.isfile(path)
 
 
 def test_user_cond_fn_through_autograd_functions():

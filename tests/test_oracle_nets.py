@@ -63,3 +63,30 @@ def test_schedule_identities():
     xt = d.q_sample(x0, t, eps)
     rec = diffusion._extract(d.sqrt_recip_alphas_cumprod, t, xt.shape) * xt - diffusion._extract(d.sqrt_recipm1_alphas_cumprod, t, xt.shape) * eps
     assert th.allclose(rec, x0, atol=2e-4)
+
+
+def test_lpips_oracle_structure_and_identities():
+    """LPIPS-VGG16 oracle: package key names / shapes (14.7 M trunk parameters + 1472 head weights), lpips(x, x) = 0,
+    non-negativity with non-negative heads, and the value equals the hand-written five-tap formula."""
+    import torch.nn.functional as F
+    from oracle import lpips_vgg as olp
+    m = olp.synthetic_init_(olp.LpipsVGG()).eval()
+    sd = m.lpips_state_dict()
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("net.")) == 14_714_688
+    assert [sd[f"lin{k}.model.1.weight"].shape[1] for k in range(5)] == [64, 128, 256, 512, 512]
+    assert "net.slice3.14.bias" in sd and "net.slice5.28.weight" in sd
+    g = th.Generator().manual_seed(3)
+    x = th.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    y = th.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    with th.no_grad():
+        assert float(m(x, x).abs().max()) == 0.0
+        v = m(x, y)
+        assert v.shape == (2, 1, 1, 1) and bool((v > 0).all())
+        fx, fy = m.features(x), m.features(y)
+        assert [f.shape[1] for f in fx] == [64, 128, 256, 512, 512] and [f.shape[2] for f in fx] == [32, 16, 8, 4, 2]
+        man = 0
+        for k in range(5):
+            nx = fx[k] / (fx[k].pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            ny = fy[k] / (fy[k].pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            man = man + (F.conv2d((nx - ny) ** 2, m.lins[k].weight)).mean((2, 3), keepdim=True)
+        assert th.allclose(man, v, rtol=1e-6, atol=1e-8)
