@@ -73,3 +73,9 @@ def test_clip_vit_b32(precision):
 def test_lpips_vgg16_loss_and_grad():
     # the trunk always runs on the exact-fp32 MFMA path (discontinuous gradient: ReLU masks, pooling arg-max)
     _assert_all(pc.check_lpips(1))
+
+
+@pytest.mark.parametrize("name", ["ViT-B/16", "ViT-L/14"])
+def test_clip_vit_other_towers(name):
+    # BASELINE configs 3 / 5: 197 / 257 tokens take the batched-GEMM attention path, patch 14 gives a K = 588 patch GEMM
+    _assert_all(pc.check_vit(name, 1, N=2))
