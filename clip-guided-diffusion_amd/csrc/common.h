@@ -33,10 +33,8 @@ struct cgd_ctx {
   size_t ws_bytes = 0;
   int num_cu = 256;
   int tile_huge = 1256, tile_large = 128, tile_small = 64;  // GEMM tile codes of the automatic selection (gemm.hip)
-  int hconv_var = 12;  // halo conv variant: bit 2 = hconv2_kernel (default; ops_r1u: -6..-15% vs hconv_kernel), with bit 3 = always its
-                       // 8x16-pixel / 4-wavefront tile (two workgroups per CU; default: +0.8 % on the step vs 16x16), bit 4 = that tile for M >= 16384 only;
-                       // else hconv_kernel with bit 0 = sched_barrier
-                      // after the fragment prefetch (ops_r1o: +3..10%), bit 1 = setprio
+  int hconv_var = 0;  // halo conv tile: 0 = 8x16 pixels / 4 wavefronts / two workgroups per CU (default, +0.8 % on the step),
+                      // bit 0 = 16x16 / 8 wavefronts everywhere, bit 1 = 16x16 below 16384 pixels
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   int hgemm_mode = 1, hgemm_min_m = 2048, hgemm_min_chunks = 3;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it the
                                                                  // launch is latency-bound and igemm's finer tiles win, gemm_r1ae), chunks per split-K slice

@@ -1,17 +1,18 @@
 // Halo-staged 3x3 convolution (implicit GEMM, bf16x3 / bf16 MFMA) for gfx950 — the UNet's dominant kernel.
 //
-// Differences to the generic igemm kernel (gemm.hip), both aimed at its measured bottleneck (staging traffic and
-// one barrier per 32-deep K tile, profiles/prof_r1d):
-//   * A operand: a workgroup owns 256 consecutive pixels (one 256-wide row segment, or 256/W full rows).  For each
-//     32-channel chunk the (rows+2) x (W+2) halo patch is loaded, split into bf16 hi/lo and written to LDS ONCE, then
-//     reused by all 9 taps: a tap is just a constant row offset into the patch (zero rows implement the padding).
-//     Staging work per MFMA drops ~6x, and the patch is read-only for 9 K tiles.
+// Differences to the generic igemm kernel (gemm.hip), aimed at its measured bottlenecks (staging traffic, one barrier per
+// 32-deep K tile, conversion of the weights in the loop):
+//   * A operand: a workgroup owns a TH x 16-pixel tile.  For each 32-channel chunk the (TH+2) x 18 halo patch is loaded,
+//     split into bf16 hi/lo and written to LDS ONCE, then reused by all 9 taps: a tap is just a constant row offset into
+//     the patch (zero rows implement the padding).
 //   * B operand (weights): pre-packed at load time in MFMA B-fragment order, bf16 hi/lo planes,
 //     [N/32][Cin/32][tap][kstep][plane][lane][8]: every wavefront fetches its fragments with fully coalesced 1 KiB
 //     loads straight from L2 into registers — no LDS round trip, no conversion, no weight-related barrier.
-//   => one barrier pair per chunk (9 K tiles) instead of one per K tile; wavefronts drift apart inside a chunk so
-//      MFMA, LDS reads and global loads of different wavefronts overlap.
-// 8 wavefronts (4 x 2), each 64 x 64 of the 256 x 128 output tile; 123,840 B LDS (1 workgroup / CU).
+//   * Pointers are passed as kernel arguments (not inside the by-value struct) so that the backend knows they are global
+//     and emits global_load / global_store: flat_* accesses tick lgkmcnt as well and would serialise every LDS wait with
+//     the weight-fragment loads that are meant to stay in flight.
+// (The first version of this kernel — 256-pixel row-segment tiles, 13 staging passes, sectioned issue — is in the history:
+//  profiles/r1_hconv_variants_microbench.json.)
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -20,9 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int HB_M = 256, HB_N = 128, HPH = 40;  // tile, LDS row pitch (bf16 elements)
-constexpr int MAX_NP = 774;                      // 3 x 258 patch rows (W >= 256)
-constexpr int NPASS = 13;                        // ceil(774 / 64) staging passes of 64 rows
+constexpr int HB_M = 256, HB_N = 128, HPH = 40;  // 16x16-pixel tile, channel tile, LDS row pitch (bf16 elements)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: value selects stay in registers
 
@@ -50,225 +49,9 @@ struct HConvParams {
   float alpha;
 };
 
-// Pointers are passed as kernel arguments (not inside the by-value struct) so that the backend knows they are global
-// and emits global_load / global_store: flat_* accesses tick lgkmcnt as well and would serialise every LDS wait with
-// the weight-fragment loads that are meant to stay in flight.
-// VAR: scheduling experiments (bit 0: sched_barrier after the fragment prefetch so the loads are issued a full tap ahead;
-// bit 1: s_setprio(1) around each MFMA cluster)
-template <int MODE, int VAR>
-__global__ __launch_bounds__(512) void hconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
-                                                    const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
-                                                    const HConvParams p) {
-  __shared__ __attribute__((aligned(16))) __bf16 ph[MAX_NP][HPH];
-  __shared__ __attribute__((aligned(16))) __bf16 pl[MODE == 1 ? MAX_NP : 1][HPH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, hh = lane >> 5;
-
-  const int ntn = (p.N + HB_N - 1) / HB_N;
-  int bid = blockIdx.x;
-  {
-    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = (bid / ntn) * HB_M, n0 = (bid % ntn) * HB_N;
-
-  // ---- tile geometry ---------------------------------------------------------------------------------
-  const int HW = p.H * p.W;
-  const int img = m0 / HW, rem = m0 - img * HW;
-  const int y0 = rem / p.W, x0 = rem - y0 * p.W;
-  const bool wide = p.W >= HB_M;
-  const int TW = wide ? HB_M : p.W;     // pixels per tile row
-  const int TR = wide ? 1 : HB_M / p.W; // tile rows
-  const int PW = TW + 2, NP = (TR + 2) * PW;
-  const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
-  const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
-
-  // per-thread patch staging slots: 64 patch rows per pass, 8 float4 per row
-  const int c4 = tid & 7;
-  int poff[NPASS];
-#pragma unroll
-  for (int j = 0; j < NPASS; ++j) {
-    const int prow = (tid >> 3) + 64 * j;
-    poff[j] = -2;  // beyond the patch
-    if (prow < NP) {
-      const int py = prow / PW, px = prow - py * PW;
-      int yy = y0 + py - 1, xx = x0 + px - 1;
-      const bool inb = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      if (p.ups) {
-        yy >>= 1;
-        xx >>= 1;
-      }
-      poff[j] = inb ? (yy * Ws + xx) * p.lda + c4 * 4 : -1;  // -1: zero padding
-    }
-  }
-  // A-fragment rows of this lane inside the patch (tap adds a constant)
-  int frow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pix = wm * 64 + i * 32 + l31;
-    const int ry = wide ? 0 : pix / p.W, x = wide ? pix : pix - ry * p.W;
-    frow[i] = ry * PW + x;
-  }
-
-  const int nchunk = p.Cin >> 5;
-  int c0 = 0, c1 = nchunk;
-  if (p.splitk > 1) {
-    const int per = (nchunk + p.splitk - 1) / p.splitk;
-    c0 = blockIdx.z * per;
-    c1 = min(nchunk, c0 + per);
-  }
-  // packed weights: block (nb, chunk, tap, ks, plane) = 64 uint4
-  const int nb0 = (n0 + wn * 64) >> 5;
-  const int nbN = p.N >> 5;
-  const long bstride_nb = (long)nchunk * 9 * 4 * 64;
-  const int nbc = nb0 < nbN ? nb0 : nbN - 1;  // clamped first block
-  const int bj[2] = {0, (nb0 + 1 < nbN) ? 1 : 0};
-  const uint4* __restrict__ Bw0 = Bg + (long)nbc * bstride_nb + lane;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  f32x4 pr[NPASS];
-  const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint4 zu = make_uint4(0u, 0u, 0u, 0u);
-
-#define PATCH_LOAD(CH)                                                                              \
-  {                                                                                                 \
-    const float* __restrict__ Ac = Aimg + (CH) * 32;                                                \
-    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                             \
-      /* unconditional load from a clamped (valid) address + value select: a `cond ? *p : 0` lets the compiler select   \
-         between the global pointer and a stack slot holding 0, which forces flat_load + scratch */                      \
-      pr[j] = *(const f32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4));  /* zeroed at store time: no early wait */ \
-    }                                                                                               \
-  }
-#define PATCH_STORE()                                                                               \
-  {                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                             \
-      if (poff[j] != -2) {                                                                          \
-        const int prow = (tid >> 3) + 64 * j;                                                       \
-        const f32x4 v = poff[j] >= 0 ? pr[j] : z4;                                                  \
-        const bf16x4 hi = to_bf16x4(v);                                                             \
-        *(bf16x4*)&ph[prow][c4 * 4] = hi;                                                           \
-        if constexpr (MODE == 1) *(bf16x4*)&pl[prow][c4 * 4] = to_bf16x4(residual4(v, hi));         \
-      }                                                                                             \
-    }                                                                                               \
-  }
-  // B fragments of one tap: [block j][kstep][plane]
-#define BFRAG_LOAD(DST, CH, TAP)                                                                    \
-  {                                                                                                 \
-    const long o = ((long)(CH) * 9 + (TAP)) * 4 * 64;                                               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
-      /* columns beyond N are never stored: read a valid (clamped) block instead of branching */   \
-      const uint4* q = Bw0 + bj[j] * bstride_nb + o + ks * 128;                                     \
-      DST[j][ks][0] = q[0];                                                                         \
-      if constexpr (MODE == 1) DST[j][ks][1] = q[64];                                               \
-    }                                                                                               \
-    if constexpr (VAR & 1) __builtin_amdgcn_sched_barrier(0);                                       \
-  }
-#define TAP_COMPUTE(BQ, TAP)                                                                        \
-  {                                                                                                 \
-    const int toff = ((TAP) / 3) * PW + ((TAP) % 3);                                                \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
-      bf16x8 ah[2], al[2];                                                                          \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                               \
-        ah[i] = *(const bf16x8*)&ph[frow[i] + toff][ks * 16 + hh * 8];                              \
-        if constexpr (MODE == 1) al[i] = *(const bf16x8*)&pl[frow[i] + toff][ks * 16 + hh * 8];     \
-      }                                                                                             \
-      if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);                                         \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) { \
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, BQ[j][ks][0]);                                 \
-        if constexpr (MODE == 1) {                                                                  \
-          const bf16x8 bl = __builtin_bit_cast(bf16x8, BQ[j][ks][1]);                               \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);       \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);       \
-        }                                                                                           \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);         \
-      }                                                                                             \
-      if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);                                         \
-    }                                                                                               \
-  }
-
-  uint4 b0[2][2][MODE == 1 ? 2 : 1], b1[2][2][MODE == 1 ? 2 : 1];
-  if (c0 < c1) {
-    PATCH_LOAD(c0);
-    BFRAG_LOAD(b0, c0, 0);
-    PATCH_STORE();
-  }
-  __syncthreads();
-  for (int c = c0; c < c1; ++c) {
-    const bool more = c + 1 < c1;
-    if (more) PATCH_LOAD(c + 1);  // stays in flight during the 9 taps
-    BFRAG_LOAD(b1, c, 1); TAP_COMPUTE(b0, 0);
-    BFRAG_LOAD(b0, c, 2); TAP_COMPUTE(b1, 1);
-    BFRAG_LOAD(b1, c, 3); TAP_COMPUTE(b0, 2);
-    BFRAG_LOAD(b0, c, 4); TAP_COMPUTE(b1, 3);
-    BFRAG_LOAD(b1, c, 5); TAP_COMPUTE(b0, 4);
-    BFRAG_LOAD(b0, c, 6); TAP_COMPUTE(b1, 5);
-    BFRAG_LOAD(b1, c, 7); TAP_COMPUTE(b0, 6);
-    BFRAG_LOAD(b0, c, 8); TAP_COMPUTE(b1, 7);
-    TAP_COMPUTE(b0, 8);
-    if (more) BFRAG_LOAD(b0, c + 1, 0);  // overlaps the chunk-boundary barriers and the patch store
-    __syncthreads();                     // every wavefront is done reading patch c
-    if (more) {
-      PATCH_STORE();
-      __syncthreads();
-    }
-  }
-#undef PATCH_LOAD
-#undef PATCH_STORE
-#undef BFRAG_LOAD
-#undef TAP_COMPUTE
-
-  // ---- epilogue (32x32 MFMA C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----------
-  if (p.splitk > 1) {
-    float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (col < p.N) ws[(long)row * p.N + col] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + l31;
-      float bv = 0.f;
-      if (biasg) bv = biasg[col < p.N ? col : p.N - 1];
-      float rv[16];  // residual block fetched up front (clamped column), one wait instead of 16
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-      if (Rg) {
-        const int colc = col < p.N ? col : p.N - 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          rv[r] = Rg[(long)row * p.ldr + colc];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (col < p.N) Cg[(long)row * p.ldc + col] = p.alpha * acc[i][j][r] + bv + rv[r];
-      }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
-// hconv2: same operands and packed weights, re-tiled and software-pipelined.
+// hconv2_kernel
 //   * tile = TH x 16 pixels (TH = 16: 8 wavefronts / 512 threads; TH = 8: 4 wavefronts / 256 threads, two workgroups per CU,
 //     whose barrier and load stalls are uncorrelated); the halo patch is (TH+2) x 18 rows (1.27x / 1.41x the tile, against
 //     3.0x for a 256-wide row segment), 6 staging passes instead of 13;
@@ -555,29 +338,19 @@ int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int 
 bool cgd_hconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
   if (!p.conv || !p.Bpk || ctx->precision == CGD_PREC_F32 || p.nbatch != 1) return false;
   if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
-  if (p.H <= 0 || p.W <= 0) return false;
+  if (p.H <= 0 || p.W <= 0 || (p.H & 15) || (p.W & 15)) return false;  // TH x 16-pixel tiles
   if (p.ups && ((p.H | p.W) & 1)) return false;
-  if (ctx->hconv_var & 4) {  // hconv2: TH x 16-pixel tiles, 16-byte epilogue accesses
-    if ((p.H & 15) || (p.W & 15)) return false;
-    if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
-    if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
-    return true;
-  }
-  if (p.M % HB_M) return false;
-  const long hw = (long)p.H * p.W;
-  if (hw % HB_M) return false;
-  if (p.W >= HB_M ? (p.W % HB_M) != 0 : (HB_M % p.W) != 0) return false;
+  if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;               // 16-byte epilogue accesses
+  if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
   return true;
 }
 
-// pixels per workgroup tile of the variant that cgd_launch_hconv will use: hconv2's 8x16 tile (two workgroups per CU)
-// when forced (bit 3) or, in auto mode (bit 4), for the big maps where it wins (ops_r1aj: -10 % at 256^2, neutral at 128^2,
-// mixed below because the split-K factor changes)
+// pixels per workgroup tile: the 8x16 tile (4 wavefronts, two workgroups per CU whose stalls are uncorrelated) unless
+// hconv_var bit 0 asks for 16x16 everywhere or bit 1 for 16x16 below 16384 pixels (ops_r1aj)
 int cgd_hconv_tile_m(const cgd_ctx* ctx, const GemmParams& p) {
-  if (!(ctx->hconv_var & 4)) return HB_M;
-  if (ctx->hconv_var & 8) return 128;
-  if ((ctx->hconv_var & 16) && p.M >= 16384) return 128;
-  return HB_M;
+  if (ctx->hconv_var & 1) return HB_M;
+  if ((ctx->hconv_var & 2) && p.M < 16384) return HB_M;
+  return 128;
 }
 
 int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
@@ -587,31 +360,18 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   const int tm = cgd_hconv_tile_m(ctx, g);
   dim3 grid((g.M / tm) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
-#define HC_LAUNCH(M_, V_) hipLaunchKernelGGL((hconv_kernel<M_, V_>), grid, dim3(512), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
 #define HC2_LAUNCH(M_, TH_) hipLaunchKernelGGL((hconv2_kernel<M_, TH_>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
-  if (ctx->hconv_var & 4) {
-    if (ctx->precision == CGD_PREC_BF16X3) {
-      if (tm == 128)
-        HC2_LAUNCH(1, 8);
-      else
-        HC2_LAUNCH(1, 16);
-    } else {
-      if (tm == 128)
-        HC2_LAUNCH(2, 8);
-      else
-        HC2_LAUNCH(2, 16);
-    }
-  } else if (ctx->precision == CGD_PREC_BF16X3) {
-    switch (ctx->hconv_var & 3) {
-      case 0: HC_LAUNCH(1, 0); break;
-      case 1: HC_LAUNCH(1, 1); break;
-      case 2: HC_LAUNCH(1, 2); break;
-      default: HC_LAUNCH(1, 3); break;
-    }
+  if (ctx->precision == CGD_PREC_BF16X3) {
+    if (tm == 128)
+      HC2_LAUNCH(1, 8);
+    else
+      HC2_LAUNCH(1, 16);
   } else {
-    HC_LAUNCH(2, 0);
+    if (tm == 128)
+      HC2_LAUNCH(2, 8);
+    else
+      HC2_LAUNCH(2, 16);
   }
 #undef HC2_LAUNCH
-#undef HC_LAUNCH
   return 0;
 }
