@@ -94,6 +94,15 @@ def _vit_config_from_state_dict(sd):
     return (patch * grid, patch, width, layers, width // 64, sd["visual.proj"].shape[1])
 
 
+def _rn_config_from_state_dict(sd):
+    """clip.model.build_model's shape inference for a ModifiedResNet tower."""
+    counts = [len({k.split(".")[2] for k in sd if k.startswith(f"visual.layer{b}")}) for b in (1, 2, 3, 4)]
+    width = sd["visual.layer1.0.conv1.weight"].shape[0]
+    grid = round((sd["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
+    out_dim = sd["visual.attnpool.c_proj.weight"].shape[0]
+    return (grid * 32, width, tuple(counts), out_dim, width * 32 // 64)
+
+
 @lru_cache(maxsize=1)
 def load_clip(model_name="ViT-B/32", device="cpu"):
     print(f"Loading clip model\t{model_name}\ton device\t{device}.")
@@ -107,9 +116,10 @@ def load_clip(model_name="ViT-B/32", device="cpu"):
             sd = jit.state_dict()
         except RuntimeError:
             sd = th.load(model_path, map_location="cpu")
-        if "visual.proj" not in sd:
-            raise NotImplementedError(f"{model_name}: ModifiedResNet towers are the next SURVEY.md 8(f) row; ViT towers only")
-        tower = _nets.ClipImageTower(ctx, config=_vit_config_from_state_dict(sd))
+        if "visual.proj" in sd:
+            tower = _nets.ClipImageTower(ctx, config=_vit_config_from_state_dict(sd))
+        else:
+            tower = _nets.ClipResNetTower(ctx, config=_rn_config_from_state_dict(sd))
         tower.load_clip_state_dict({k: v.float() for k, v in sd.items() if k.startswith("visual.")})
         text_model = None
         try:
@@ -119,10 +129,15 @@ def load_clip(model_name="ViT-B/32", device="cpu"):
             pass
         return ClipModel(tower, text_model, model_name), tower.input_resolution
     if script_util.synthetic_weights_enabled():
-        if model_name not in _nets.VIT_CONFIGS:
-            raise NotImplementedError(f"{model_name}: ViT towers only (ModifiedResNet is a next-row item)")
-        tower = _nets.ClipImageTower(ctx, model_name)
-        tower.load_state_dict(_synthetic.synthetic_state_dict(tower, seed=4321, device=f"cuda:{ctx.device}"))
+        if model_name in _nets.VIT_CONFIGS:
+            tower = _nets.ClipImageTower(ctx, model_name)
+            tower.load_state_dict(_synthetic.synthetic_state_dict(tower, seed=4321, device=f"cuda:{ctx.device}"))
+        elif model_name in _nets.RN_CONFIGS:
+            tower = _nets.ClipResNetTower(ctx, model_name)
+            tower.load_state_dict(_synthetic.resnet_state_dict(tower, seed=2468, device=f"cuda:{ctx.device}"))
+        else:
+            raise NotImplementedError(f"{model_name}: supported towers are {sorted(_nets.VIT_CONFIGS) + sorted(_nets.RN_CONFIGS)} "
+                                      "(RN50x4 / RN50x16 need 16-channel conv slices)")
         return ClipModel(tower, None, model_name), tower.input_resolution
     raise FileNotFoundError(f"{model_path} not found (set CGD_SYNTHETIC_WEIGHTS=1 for seeded random weights)")
 

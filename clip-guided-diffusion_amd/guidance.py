@@ -162,11 +162,16 @@ class ClipGuidance:
         cutn = len(coords)
         geo = th.tensor(crop_geometry(coords, H, W), dtype=th.int32).to(dev, non_blocking=True)
         cs, patch = self.clip.input_resolution, self.clip.patch
-        gsz = cs // patch
         N = cutn * B
-        patches = self._b("patches", (N * gsz * gsz, 3 * patch * patch), dev)
-        ctx.check(lib.cgd_cutouts_fwd(ctx.h, x_in.data_ptr(), geo.data_ptr(), patches.data_ptr(), B, H, W, cutn, cs, 1, patch, s))
-        emb = self.clip.encode_image(patches, layout=1, n=N, out=self._b("emb", (N, self.clip.out_dim), dev))
+        if patch:  # ViT towers: the cutout kernel writes the patch rows of the patch-embedding GEMM directly (layout 1)
+            gsz = cs // patch
+            clip_in = self._b("patches", (N * gsz * gsz, 3 * patch * patch), dev)
+            layout = 1
+        else:      # ModifiedResNet towers: plain (N,3,cs,cs) images (layout 0)
+            clip_in = self._b("cut_images", (N, 3, cs, cs), dev)
+            layout = 0
+        ctx.check(lib.cgd_cutouts_fwd(ctx.h, x_in.data_ptr(), geo.data_ptr(), clip_in.data_ptr(), B, H, W, cutn, cs, layout, patch, s))
+        emb = self.clip.encode_image(clip_in, layout=layout, n=N, out=self._b("emb", (N, self.clip.out_dim), dev))
         P = self.targets_n.shape[0]
         wm = self._wm.get(B)
         if wm is None:
@@ -175,7 +180,7 @@ class ClipGuidance:
         clip_part = self._b("clip_part", (N,), dev)
         ctx.check(lib.cgd_spherical_loss(ctx.h, emb.data_ptr(), self.targets_n.data_ptr(), wm.data_ptr(), demb.data_ptr(),
                                          clip_part.data_ptr(), cutn, B, P, self.clip.out_dim, self.cgs, s))
-        dpatches = self.clip.dgrad(demb, self._b("dpatches", tuple(patches.shape), dev))
+        dpatches = self.clip.dgrad(demb, self._b("dclip_in", tuple(clip_in.shape), dev))
         gclip = self._b("gclip", (B, 3, H, W), dev)
         acc = 0
         if self.lpips is not None:
@@ -186,7 +191,7 @@ class ClipGuidance:
             self.lpips_loss, _ = self.lpips.loss_grad(x_in, grad_scale=self.init_scale, g=gclip, accumulate=False,
                                                       loss=self._b("lpips_loss", (B,), dev))
             acc = 1
-        ctx.check(lib.cgd_cutouts_bwd(ctx.h, dpatches.data_ptr(), geo.data_ptr(), gclip.data_ptr(), B, H, W, cutn, cs, 1, patch, acc, s))
+        ctx.check(lib.cgd_cutouts_bwd(ctx.h, dpatches.data_ptr(), geo.data_ptr(), gclip.data_ptr(), B, H, W, cutn, cs, layout, patch, acc, s))
         nblk = lib.cgd_guidance_part_blocks(B, H, W)
         gdir = self._b("gdir", (B, 3, H, W), dev)
         seed6 = self._b("seed6", (B, 6, H, W), dev)

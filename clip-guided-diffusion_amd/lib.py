@@ -29,6 +29,10 @@ class ViTConfig(C.Structure):
     _fields_ = [("resolution", i32), ("patch", i32), ("width", i32), ("layers", i32), ("heads", i32), ("out_dim", i32)]
 
 
+class RNConfig(C.Structure):
+    _fields_ = [("resolution", i32), ("width", i32), ("layers", i32 * 4), ("out_dim", i32), ("heads", i32)]
+
+
 class StepCoef(C.Structure):
     _fields_ = [
         ("sqrt_recip", f32), ("sqrt_recipm1", f32), ("coef1", f32), ("coef2", f32), ("min_log", f32), ("max_log", f32),
@@ -64,6 +68,14 @@ _SIGS = {
     "cgd_vit_finalize": (i32, [vp]),
     "cgd_vit_forward": (i32, [vp, vp, i32, i32, vp, vp]),
     "cgd_vit_dgrad": (i32, [vp, vp, vp, vp]),
+    "cgd_rn_create": (i32, [vp, C.POINTER(RNConfig), C.POINTER(vp)]),
+    "cgd_rn_destroy": (None, [vp]),
+    "cgd_rn_num_params": (i32, [vp]),
+    "cgd_rn_param_info": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64)]),
+    "cgd_rn_set_param": (i32, [vp, C.c_char_p, vp, i64]),
+    "cgd_rn_finalize": (i32, [vp]),
+    "cgd_rn_forward": (i32, [vp, vp, i32, vp, vp]),
+    "cgd_rn_dgrad": (i32, [vp, vp, vp, vp]),
     "cgd_lpips_create": (i32, [vp, C.POINTER(vp)]),
     "cgd_lpips_destroy": (None, [vp]),
     "cgd_lpips_num_params": (i32, [vp]),

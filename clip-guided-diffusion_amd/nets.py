@@ -159,6 +159,55 @@ class ClipImageTower(_Net):
         return d_img
 
 
+RN_CONFIGS = {
+    # name: (resolution, width, layers, out_dim, heads)   (clip/model.py ModifiedResNet)
+    "RN50": (224, 64, (3, 4, 6, 3), 1024, 32),
+    "RN101": (224, 64, (3, 4, 23, 3), 512, 32),
+}
+
+
+class ClipResNetTower(_Net):
+    """CLIP ModifiedResNet image tower (RN50 / RN101): `encode_image` + `dgrad`, same role as `ClipImageTower`.  `patch` is 0:
+    the cutout kernel hands it plain (N,3,res,res) images (layout 0)."""
+    _prefix = "rn"
+    patch = 0
+
+    def __init__(self, ctx, name="RN50", config=None):
+        self.ctx = ctx
+        res, width, layers, out, heads = config or RN_CONFIGS[name]
+        cfg = L.RNConfig()
+        cfg.resolution, cfg.width, cfg.out_dim, cfg.heads = res, width, out, heads
+        for i, v in enumerate(layers):
+            cfg.layers[i] = v
+        self.cfg = cfg
+        self.input_resolution, self.out_dim = res, out
+        h = C.c_void_p()
+        ctx.check(ctx.lib.cgd_rn_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def load_clip_state_dict(self, sd):
+        prefix = "visual." if any(k.startswith("visual.") for k in sd) else ""
+        return self.load_state_dict(sd, prefix)
+
+    def encode_image(self, img, layout=0, n=None, out=None):
+        assert layout == 0, "the ResNet tower takes NCHW images"
+        img = img.contiguous().float()
+        N = img.shape[0]
+        if out is None:
+            out = th.empty((N, self.out_dim), device=img.device, dtype=th.float32)
+        self.ctx.check(self.ctx.lib.cgd_rn_forward(self.h, img.data_ptr(), N, out.data_ptr(), L.stream_ptr()))
+        self._keep = img
+        return out
+
+    def dgrad(self, d_emb, d_img=None):
+        d_emb = d_emb.contiguous().float()
+        if d_img is None:
+            d_img = th.empty_like(self._keep)
+        self.ctx.check(self.ctx.lib.cgd_rn_dgrad(self.h, d_emb.data_ptr(), d_img.data_ptr(), L.stream_ptr()))
+        self._keep_g = d_emb
+        return d_img
+
+
 class LpipsVGG(_Net):
     """`lpips.LPIPS(net='vgg')` against a fixed reference image (/root/reference/cgd/cgd.py:147-148,220-224): value per sample and
     gradient w.r.t. the first argument.  `load_state_dict` takes the package's keys (`net.slice{k}.{idx}.*`, `lin{k}.model.1.weight`)."""

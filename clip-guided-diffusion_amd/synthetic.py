@@ -52,3 +52,37 @@ def lpips_state_dict(seed=777, device="cpu"):
     for k, c in enumerate((64, 128, 256, 512, 512)):
         sd[f"lin{k}.model.1.weight"] = (th.rand(1, c, 1, 1, generator=g) * 0.2).to(device)
     return sd
+
+
+def resnet_state_dict(net, seed=2468, device="cuda"):
+    """Seeded synthetic weights + BatchNorm statistics for a ClipResNetTower (names from `param_specs`): He-scaled convolutions,
+    unit-ish BatchNorm gains (0.25 on the last BatchNorm of each residual branch), positive running variances."""
+    g = th.Generator(device=device).manual_seed(seed)
+    sd = {}
+    specs = dict(net.param_specs())
+    for name, numel in specs.items():
+        leaf = name.rsplit(".", 1)[-1]
+        is_bn = ".bn" in name or name.startswith("bn") or ".downsample.1." in name
+        if is_bn and leaf == "weight":
+            gain = 0.25 if (".bn3." in name and name.startswith("layer")) else 1.0
+            t = gain * (1.0 + 0.1 * th.randn(numel, device=device, generator=g))
+        elif is_bn and leaf == "bias":
+            t = 0.05 * th.randn(numel, device=device, generator=g)
+        elif leaf == "running_mean":
+            t = 0.1 * th.randn(numel, device=device, generator=g)
+        elif leaf == "running_var":
+            t = 0.5 + th.rand(numel, device=device, generator=g)
+        elif name.endswith("positional_embedding"):
+            t = (net.cfg.width * 32) ** -0.5 * th.randn(numel, device=device, generator=g)
+        elif leaf == "bias":
+            t = 0.02 * th.randn(numel, device=device, generator=g)
+        else:
+            cout = specs[name.replace(".weight", ".bias")] if name.replace(".weight", ".bias") in specs and "proj" in name else None
+            if "proj" in name:
+                fan_in = numel // cout
+            else:
+                bn = name.replace("conv", "bn").replace("downsample.0", "downsample.1")
+                fan_in = numel // specs[bn]
+            t = (2.0 / fan_in) ** 0.5 * th.randn(numel, device=device, generator=g)
+        sd[name] = t
+    return sd

@@ -93,6 +93,22 @@ int cgd_vit_finalize(cgd_vit* v);
 int cgd_vit_forward(cgd_vit* v, const float* img, int layout, int N, float* emb /* (N,out_dim) */, void* stream);
 int cgd_vit_dgrad(cgd_vit* v, const float* d_emb, float* d_img /* same layout as the forward input */, void* stream);
 
+/* ---- CLIP image tower, ModifiedResNet variant (RN50 / RN101; clip_util.py:17): same role as the ViT tower.  Parameters use
+ *      the OpenAI `visual.*` names including the BatchNorm running statistics (folded into the convolutions by finalize).
+ *      img: (N,3,res,res) NCHW, CLIP-normalised. ---- */
+typedef struct cgd_rn cgd_rn;
+typedef struct cgd_rn_config {
+  int resolution, width, layers[4], out_dim, heads;
+} cgd_rn_config;
+int cgd_rn_create(cgd_ctx* ctx, const cgd_rn_config* cfg, cgd_rn** out);
+void cgd_rn_destroy(cgd_rn* v);
+int cgd_rn_num_params(cgd_rn* v);
+int cgd_rn_param_info(cgd_rn* v, int index, char* name_buf, int buf_len, int64_t* numel);
+int cgd_rn_set_param(cgd_rn* v, const char* name, const float* data, int64_t numel);
+int cgd_rn_finalize(cgd_rn* v);
+int cgd_rn_forward(cgd_rn* v, const float* img, int N, float* emb /* (N,out_dim) */, void* stream);
+int cgd_rn_dgrad(cgd_rn* v, const float* d_emb, float* d_img /* (N,3,res,res) */, void* stream);
+
 /* ---- LPIPS-VGG16 init loss: replaces lpips.LPIPS(net='vgg') (cgd/cgd.py:147-148) and `lpips_vgg(x_in, init_tensor)` with its
  *      backward to x_in (cgd.py:220-224,228).  Parameters use the package's names (net.slice{k}.{idx}.weight|bias,
  *      lin{k}.model.1.weight).  set_reference: the fixed second argument (init image, (B,3,H,W) NCHW in [-1,1], H and W

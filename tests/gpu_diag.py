@@ -21,6 +21,10 @@ GROUPS = {
     "unet_small": [lambda: pc.check_unet("mini", 0), lambda: pc.check_unet("mini", 1), lambda: pc.check_unet("mini128", 0),
                    lambda: pc.check_unet("mini64", 0), lambda: pc.check_unet("mini", 0, B=2, hw=(32, 48))],
     "vit": [lambda: pc.check_vit("ViT-B/32", 0), lambda: pc.check_vit("ViT-B/32", 1)],
+    "resnet": [lambda: pc.check_resnet("tiny", 0, config=(64, 64, (1, 1, 1, 1), 128, 32)),
+               lambda: pc.check_resnet("tiny", 1, config=(64, 64, (1, 1, 1, 1), 128, 32)),
+               lambda: pc.check_resnet("RN50", 0), lambda: pc.check_resnet("RN50", 1),
+               lambda: _sc().check_step("mini", 0, respacing="50", steps=2, B=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32))],
     "lpips": [lambda: pc.check_lpips(0), lambda: pc.check_lpips(1),
               lambda: _sc().check_step("mini", 1, respacing="50", steps=2, B=2, init_scale=100.0)],
     "unet64": [lambda: pc.check_unet("cfg64", 0), lambda: pc.check_unet("cfg64", 1), lambda: pc.check_unet("cfg64", 2)],

@@ -20,7 +20,7 @@ def make_tape(B, H, W, nsteps, num_classes, cutn, cut_size, cut_pow=1.0, seed=0)
 
 def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_cfg=(64, 16, 128, 2, 2, 64), P=1, hw=None,
                respacing="50", schedule="linear", use_magnitude=False, sat_scale=0.0, scales=(1000.0, 150.0, 50.0), skip=0,
-               weights=None, init_scale=0.0):
+               weights=None, init_scale=0.0, rn_cfg=None):
     from cgd_amd import diffusion as dd
     from cgd_amd import guidance as dg
     from cgd_amd import lib, nets, sampler
@@ -33,15 +33,21 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
     H, W = hw or (kw["image_size"], kw["image_size"])
     ref_unet, dev_unet = pc.build_unet_pair(ctx, case)
     # small CLIP tower so that the oracle finishes in seconds; the full ViT-B/32 has its own check
-    res, patch, width, layers, heads, outd = vit_cfg
-    ref_clip = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
-    th.nn.Module.__init__(ref_clip)
-    ref_clip.visual = ocv.VisionTransformer(res, patch, width, layers, heads, outd)
-    ocv.synthetic_init_(ref_clip).eval()
+    if rn_cfg is None:
+        res, patch, width, layers, heads, outd = vit_cfg
+        ref_clip = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
+        th.nn.Module.__init__(ref_clip)
+        ref_clip.visual = ocv.VisionTransformer(res, patch, width, layers, heads, outd)
+        ocv.synthetic_init_(ref_clip).eval()
+        dev_clip = nets.ClipImageTower(ctx, config=vit_cfg)
+    else:  # ModifiedResNet tower (RN50-style): (resolution, width, layers, out_dim, heads)
+        from oracle import clip_resnet as ocr
+        res, outd = rn_cfg[0], rn_cfg[3]
+        ref_clip = ocr.synthetic_init_(ocr.ClipResNetImageModel(config=rn_cfg)).eval()
+        dev_clip = nets.ClipResNetTower(ctx, config=rn_cfg)
     for p in ref_clip.parameters():
         p.requires_grad_(False)
-    dev_clip = nets.ClipImageTower(ctx, config=vit_cfg)
-    dev_clip.load_clip_state_dict({k: v.to(DEV) for k, v in ref_clip.state_dict().items()})
+    dev_clip.load_clip_state_dict({k: v.to(DEV) for k, v in ref_clip.state_dict().items() if "num_batches_tracked" not in k})
 
     spec = ("ddim" + respacing) if ddim else respacing
     rescale = False

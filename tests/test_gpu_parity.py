@@ -79,3 +79,10 @@ def test_lpips_vgg16_loss_and_grad():
 def test_clip_vit_other_towers(name):
     # BASELINE configs 3 / 5: 197 / 257 tokens take the batched-GEMM attention path, patch 14 gives a K = 588 patch GEMM
     _assert_all(pc.check_vit(name, 1, N=2))
+
+
+@pytest.mark.parametrize("name,precision,config", [("tiny", 0, (64, 64, (1, 1, 1, 1), 128, 32)), ("tiny", 1, (64, 64, (1, 1, 1, 1), 128, 32)),
+                                                   ("RN50", 1, None)])
+def test_clip_modified_resnet(name, precision, config):
+    # forward at rtol 1e-3 / atol 1e-4; the gradient of a ReLU tower by relative L2 (parity_checks.rec_l2 explains why)
+    _assert_all(pc.check_resnet(name, precision, config=config))

@@ -44,6 +44,12 @@ def test_init_image_lpips_term():
     _assert_all(sc.check_step("mini", 1, respacing="50", steps=2, B=2, init_scale=100.0))
 
 
+def test_guided_steps_with_resnet_clip_tower():
+    # ModifiedResNet CLIP tower in the guidance loop (cutouts layout 0); exact-fp32 MFMA mode keeps ReLU-mask flips out of the
+    # sample tolerance
+    _assert_all(sc.check_step("mini", 0, respacing="50", steps=2, B=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32)))
+
+
 def test_dropin_generator_yields_batch_idx_path(tmp_path, monkeypatch):
     """reference test.py:159-168 (yield order for batch_size=2) and :139-143 (first item not None), on synthetic weights."""
     monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
@@ -76,6 +82,21 @@ def test_dropin_generator_with_init_image_and_lpips(tmp_path, monkeypatch):
                                 skip_timesteps=20)
     b, path = next(gen)
     assert b == 0 and os.path.isfile(path)
+
+
+def test_dropin_generator_with_rn50_tower(tmp_path, monkeypatch):
+    """clip_model_name='RN50' (reference clip_util.py:17) through the drop-in generator on synthetic weights."""
+    monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.chdir(tmp_path)
+    from cgd import clip_util
+    clip_util.load_clip.cache_clear()
+    from cgd.cgd import clip_guided_diffusion
+    gen = clip_guided_diffusion(prompts=["Loose seal."], image_size=64, batch_size=1, num_cutouts=2, timestep_respacing="25",
+                                noise_schedule="cosine", prefix_path=str(tmp_path / "out"), checkpoints_dir=str(tmp_path / "ckpt"),
+                                save_frequency=1, progress=False, device="cuda", clip_model_name="RN50")
+    b, path = next(gen)
+    assert b == 0 and os.path.isfile(path)
+    clip_util.load_clip.cache_clear()
 
 
 def test_user_cond_fn_through_autograd_functions():

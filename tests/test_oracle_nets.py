@@ -90,3 +90,20 @@ def test_lpips_oracle_structure_and_identities():
             ny = fy[k] / (fy[k].pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
             man = man + (F.conv2d((nx - ny) ** 2, m.lins[k].weight)).mean((2, 3), keepdim=True)
         assert th.allclose(man, v, rtol=1e-6, atol=1e-8)
+
+
+def test_clip_resnet_oracle_parameter_counts_and_shapes():
+    """ModifiedResNet oracle: the published tower sizes (RN50 38,316,896; RN101 56,259,936 parameters), OpenAI key names and
+    the output shape."""
+    from oracle import clip_resnet as ocr
+    for name, count in (("RN50", 38_316_896), ("RN101", 56_259_936)):
+        m = ocr.ClipResNetImageModel(name)
+        assert sum(p.numel() for p in m.parameters()) == count
+    m = ocr.synthetic_init_(ocr.ClipResNetImageModel(config=(64, 64, (1, 1, 1, 1), 128, 32))).eval()
+    keys = set(m.state_dict())
+    for k in ("visual.conv1.weight", "visual.bn3.running_var", "visual.layer1.0.downsample.0.weight", "visual.layer1.0.downsample.1.running_mean",
+              "visual.layer4.0.conv3.weight", "visual.attnpool.positional_embedding", "visual.attnpool.c_proj.bias"):
+        assert k in keys, k
+    with th.no_grad():
+        e = m.encode_image(th.randn(2, 3, 64, 64, generator=th.Generator().manual_seed(0)))
+    assert e.shape == (2, 128) and bool(th.isfinite(e).all())
