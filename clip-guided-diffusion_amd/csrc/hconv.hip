@@ -58,8 +58,9 @@ struct HConvParams {
 //   * the patch is DOUBLE-buffered in LDS (103,680 / 57,600 B): chunk c+1 is loaded at the start of chunk c, converted and
 //     written into the other buffer in the middle of chunk c's taps (VALU/LDS work hidden under MFMA), ONE barrier per chunk;
 //   * explicit register software pipeline over the 18 k-steps of a chunk: A fragments (ds_read_b128) one k-step ahead,
-//     B fragments (global -> registers) two k-steps ahead in a 3-deep ring (18 % 3 == 0, so the ring is chunk-periodic and
-//     runs across chunk boundaries without a drain; a 4-deep ring spills);
+//     B fragments (global -> registers) several k-steps ahead in a register ring whose depth divides 18 (chunk-periodic,
+//     runs across chunk boundaries without a drain): 6 slots / 5 k-steps ahead on the 4-wavefront tile, 3 / 2 on the
+//     8-wavefront tile (which would spill);
 //   * every MFMA is followed by one load of the coming k-steps and a few conversion VALU ops (sched_group_barrier
 //     pattern), so a wavefront's own MFMA queue never drains;
 //   * MFMA operands are swapped (D = W_frag x X_frag^T): a lane then owns 4 consecutive output CHANNELS of one pixel per
@@ -199,13 +200,18 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[j][0]), AQ[i][0], acc[i][j], 0, 0, 0); \
   }
 
-  bf16x8 af[2][2][NPL];  // [pipeline slot][pixel block][plane]
-  uint4 bq[3][2][NPL];   // [ring slot][channel block][plane]
+  // B-fragment ring: RING slots, loads DIST = RING - 1 k-steps ahead.  RING divides the 18 k-steps of a chunk, so the slot of
+  // a k-step is compile-time and the ring runs across chunk boundaries without a drain.  The 4-wavefront tile has the
+  // registers for 6 slots (5 k-steps ~ 2 us of slack: covers the patch loads queued in front of the B loads in the in-order
+  // vmcnt counter); the 8-wavefront tile spills beyond 3.
+  constexpr int RING = TH == 8 ? 6 : 3, DIST = RING - 1;
+  bf16x8 af[2][2][NPL];     // [pipeline slot][pixel block][plane]
+  uint4 bq[RING][2][NPL];   // [ring slot][channel block][plane]
   if (c0 < c1) {
     PATCH_LOAD2(c0);
     const uint4* __restrict__ cb = Bw0 + (long)c0 * (9 * 4 * 64);
-    B_LOAD2(bq[0], cb, 0, 0);
-    B_LOAD2(bq[1], cb, 0, 1);
+#pragma unroll
+    for (int q = 0; q < DIST; ++q) B_LOAD2(bq[q], cb, q >> 1, q & 1);
     PATCH_STORE2(lds, 0, NPASS2);
   }
   __syncthreads();
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     A_LOAD2(af[0], cur, 0, 0);
 #pragma unroll
     for (int q = 0; q < 18; ++q) {
-      // ---- issue: A fragments one k-step ahead, B fragments two k-steps ahead
+      // ---- issue: A fragments one k-step ahead, B fragments DIST k-steps ahead
       if (q + 1 < 18) {
         switch (q + 1) {  // (tap, ks) must be compile-time constants for the LDS immediates
 #define CASE_A(Q) case Q: A_LOAD2(af[(Q) & 1], cur, (Q) >> 1, (Q) & 1); break;
@@ -229,13 +235,13 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
         }
       }
       {
-        const int q2 = (q + 2) % 18;
-        const uint4* __restrict__ base = (q + 2 < 18) ? cb : nb;
-        B_LOAD2(bq[(q + 2) % 3], base, q2 >> 1, q2 & 1);
+        const int q2 = (q + DIST) % 18;
+        const uint4* __restrict__ base = (q + DIST < 18) ? cb : nb;
+        B_LOAD2(bq[(q + DIST) % RING], base, q2 >> 1, q2 & 1);
       }
       // ---- 12 MFMAs; the conversion of the next chunk's patch rides under k-steps 6..11 (unconditional: the last chunk
       //      rewrites the idle buffer with stale data, so there is no branch inside the scheduling region)
-      MFMA12(af[q & 1], bq[q % 3]);
+      MFMA12(af[q & 1], bq[q % RING]);
       if (q >= 6 && q <= 11) PATCH_STORE2(nxt, q - 6, q - 5);
 #pragma unroll
       for (int r = 0; r < 12; ++r) {
