@@ -563,7 +563,8 @@ __device__ __forceinline__ void vset(typename VecT<VEC>::T& v, int i, float x) {
   if constexpr (VEC == 1) v = x; else v[i] = x;
 }
 
-template <int ACT, int VEC>
+// CACHE: the group slab fits the block's registers (<= 8 vectors per thread): x is read ONCE, all loads are issued up front
+template <int ACT, int VEC, bool CACHE>
 __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int HW,
                                                              int C, int lg, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ film, int ldfilm, float eps,
@@ -578,7 +579,25 @@ __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __rest
   float* yg = y + (long)b * HW * ldy + g * cpg + q * VEC;
   const float k0 = x[(long)b * HW * ldx + g * cpg];
   float s = 0.f, ss = 0.f;
-  if (act_q) {
+  V vc[CACHE ? 8 : 1];
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int p = r + it * rows;
+      if (act_q && p < HW) vc[it] = *(const V*)(xg + (long)p * ldx);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      if (act_q && r + it * rows < HW) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = vget<VEC>(vc[it], e) - k0;
+          s += d;
+          ss += d * d;
+        }
+      }
+    }
+  } else if (act_q) {
     for (int p0 = r; p0 < HW; p0 += rows * GS_U) {
       V v[GS_U];
 #pragma unroll
@@ -630,6 +649,23 @@ __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __rest
     a[e] = ca[q * VEC + e];
     bb[e] = cb[q * VEC + e];
   }
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int p = r + it * rows;
+      if (p < HW) {
+        V o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float t = vget<VEC>(vc[it], e) * a[e] + bb[e];
+          if (ACT == 1) t = silu_f(t);
+          vset<VEC>(o, e, t);
+        }
+        *(V*)(yg + (long)p * ldy) = o;
+      }
+    }
+    return;
+  }
   for (int p0 = r; p0 < HW; p0 += rows * GS_U) {
     V v[GS_U];
 #pragma unroll
@@ -654,7 +690,7 @@ __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __rest
   }
 }
 
-template <int ACT, int VEC>
+template <int ACT, int VEC, bool CACHE>
 __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int lddz,
                                                              float* dx, int lddx, const float* add, int ldadd, int HW, int C, int lg,
                                                              const float* __restrict__ stats, const float* __restrict__ coef) {
@@ -678,6 +714,32 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
     gc[e] = o[2];
   }
   float p1 = 0.f, p2 = 0.f;
+  V xc[CACHE ? 4 : 1], dc[CACHE ? 4 : 1];  // CACHE (<= 4 vectors per thread): x and the activation-/gamma-scaled upstream gradient stay in registers
+  if constexpr (CACHE) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int p = r + it * rows;
+      if (act_q && p < HW) {
+        xc[it] = *(const V*)(xg + (long)p * ldx);
+        dc[it] = *(const V*)(dg + (long)p * lddz);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (act_q && r + it * rows < HW) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float xe = vget<VEC>(xc[it], e);
+          float du = vget<VEC>(dc[it], e);
+          if (ACT == 1) du *= dsilu_f(xe * a[e] + bb[e]);
+          du *= gc[e];
+          vset<VEC>(dc[it], e, du);
+          p1 += du;
+          p2 += du * (xe - mean);
+        }
+      }
+    }
+  } else
   if (act_q) {
     for (int p0 = r; p0 < HW; p0 += rows * GS_U) {
       V xv[GS_U], dv[GS_U];
@@ -707,6 +769,29 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
   p2 = block_sum(p2, red);
   if (!act_q) return;
   const float a2 = rstd * rstd * rstd * p2 / n, a3 = rstd * p1 / n;
+  if constexpr (CACHE) {
+    V av[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int p = r + it * rows;
+      if (ag && p < HW) av[it] = *(const V*)(ag + (long)p * ldadd);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int p = r + it * rows;
+      if (p < HW) {
+        V o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float t = vget<VEC>(dc[it], e) * rstd - (vget<VEC>(xc[it], e) - mean) * a2 - a3;
+          if (ag) t += vget<VEC>(av[it], e);
+          vset<VEC>(o, e, t);
+        }
+        *(V*)(og + (long)p * lddx) = o;
+      }
+    }
+    return;
+  }
   for (int p0 = r; p0 < HW; p0 += rows * GS_U) {
     V xv[GS_U], dv[GS_U], av[GS_U];
 #pragma unroll
@@ -744,12 +829,14 @@ void launch_gn_small_fwd(const float* x, int ldx, float* y, int ldy, int B, int 
   const int cq = v4 ? cpg / 4 : cpg;
   int lg = 0;
   while ((1 << lg) < cq) ++lg;
-  if (v4)
-    hipLaunchKernelGGL((gn_small_fwd_kernel<ACT, 4>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps,
-                       stats, coef);
-  else
-    hipLaunchKernelGGL((gn_small_fwd_kernel<ACT, 1>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps,
-                       stats, coef);
+  const bool cache = (long)HW <= 8L * (GS_NT >> lg) && !getenv("CGD_GN_NOCACHE");  // <= 8 vectors per thread: single read
+#define GN_SF(V_, C_) hipLaunchKernelGGL((gn_small_fwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps, stats, coef)
+  if (v4) {
+    if (cache) GN_SF(4, true); else GN_SF(4, false);
+  } else {
+    if (cache) GN_SF(1, true); else GN_SF(1, false);
+  }
+#undef GN_SF
 }
 
 template <int ACT>
@@ -760,12 +847,14 @@ void launch_gn_small_bwd(const float* x, int ldx, const float* dz, int lddz, flo
   const int cq = v4 ? cpg / 4 : cpg;
   int lg = 0;
   while ((1 << lg) < cq) ++lg;
-  if (v4)
-    hipLaunchKernelGGL((gn_small_bwd_kernel<ACT, 4>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C, lg, stats,
-                       coef);
-  else
-    hipLaunchKernelGGL((gn_small_bwd_kernel<ACT, 1>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C, lg, stats,
-                       coef);
+  const bool cache = (long)HW <= 4L * (GS_NT >> lg) && !getenv("CGD_GN_NOCACHE");  // <= 4 vectors of x and of dz per thread
+#define GN_SB(V_, C_) hipLaunchKernelGGL((gn_small_bwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C, lg, stats, coef)
+  if (v4) {
+    if (cache) GN_SB(4, true); else GN_SB(4, false);
+  } else {
+    if (cache) GN_SB(1, true); else GN_SB(1, false);
+  }
+#undef GN_SB
 }
 
 // <= 32x32 pixels: launch-bound sizes take the single-launch kernels (CGD_GN_SMALL_HW overrides, for tuning)
