@@ -110,23 +110,26 @@ __device__ __forceinline__ void am_mma_tn(am_f32x16& acc, const float* As, int p
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * pitchA], Bs[k * pitchB], acc, 0, 0, 0);
     }
 }
-// stage ROWS x 64 floats (row stride ld in global) into LDS with the given pitch
+// stage ROWS x 64 floats (row stride ld in global) into LDS with the given pitch; rows >= nvalid are zero
 template <int ROWS>
-__device__ __forceinline__ void am_stage64(float* dst, int pitch, const float* src, long ld, int tid) {
+__device__ __forceinline__ void am_stage64(float* dst, int pitch, const float* src, long ld, int tid, int nvalid) {
 #pragma unroll
   for (int e = tid; e < ROWS * 16; e += 256) {
     const int r = e >> 4, u = e & 15;
-    *(am_f32x4*)&dst[r * pitch + 4 * u] = *(const am_f32x4*)(src + (long)r * ld + 4 * u);
+    am_f32x4 v = *(const am_f32x4*)(src + (long)(r < nvalid ? r : 0) * ld + 4 * u);
+    if (r >= nvalid) v = am_f32x4{0.f, 0.f, 0.f, 0.f};
+    *(am_f32x4*)&dst[r * pitch + 4 * u] = v;
   }
 }
 
-// register-staged variant: issue the global loads of the next tile before computing on the current one
+// register-staged variant: issue the global loads of the next tile before computing on the current one (rows >= nvalid: 0)
 template <int ROWS>
-__device__ __forceinline__ void am_gload(am_f32x4 (&rg)[ROWS / 16], const float* src, long ld, int tid) {
+__device__ __forceinline__ void am_gload(am_f32x4 (&rg)[ROWS / 16], const float* src, long ld, int tid, int nvalid) {
 #pragma unroll
   for (int i = 0; i < ROWS / 16; ++i) {
     const int e = tid + 256 * i, r = e >> 4, u = e & 15;
-    rg[i] = *(const am_f32x4*)(src + (long)r * ld + 4 * u);
+    rg[i] = *(const am_f32x4*)(src + (long)(r < nvalid ? r : 0) * ld + 4 * u);
+    if (r >= nvalid) rg[i] = am_f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 template <int ROWS>
@@ -139,30 +142,34 @@ __device__ __forceinline__ void am_sstore(float* dst, int pitch, const am_f32x4 
 }
 
 __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo,
-                                                           float* __restrict__ Ocopy, float* __restrict__ P, int T, int H, long qo,
-                                                           long ko, long vo, long step, float alpha) {
+                                                           float* __restrict__ Ocopy, float* __restrict__ P, int T, int Tp, int H,
+                                                           long qo, long ko, long vo, long step, float alpha) {
   __shared__ __attribute__((aligned(16))) float Qs[32 * AM_P68], Ks[128 * AM_P68], Vs[128 * AM_P72], Ss[32 * AM_PS];
   __shared__ float mrow[32], lrow[32];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const float* base = qkv + (long)n * T * ldq + h * step;
-  am_stage64<32>(Qs, AM_P68, base + (long)qb * 32 * ldq + qo, ldq, tid);
-  const int nkb = T >> 7;
+  am_stage64<32>(Qs, AM_P68, base + (long)qb * 32 * ldq + qo, ldq, tid, T - qb * 32);
+  const int nkb = (T + 127) >> 7;  // key blocks; keys >= T are masked (score -inf, probability 0), query rows >= T not stored
   const int srow = tid >> 3, seg = tid & 7;
   float m_run = -INFINITY, l_run = 0.f;
   am_f32x4 kr[8], vr[8];
-  am_gload<128>(kr, base + ko, ldq, tid);
+  am_gload<128>(kr, base + ko, ldq, tid, T);
   for (int j = 0; j < nkb; ++j) {
     __syncthreads();
     am_sstore<128>(Ks, AM_P68, kr, tid);
     __syncthreads();
-    am_gload<128>(kr, base + (long)(j + 1 < nkb ? j + 1 : 0) * 128 * ldq + ko, ldq, tid);  // next block (wraps to pass 2's first)
+    {
+      const int jn = j + 1 < nkb ? j + 1 : 0;  // next block (wraps to pass 2's first)
+      am_gload<128>(kr, base + (long)jn * 128 * ldq + ko, ldq, tid, T - jn * 128);
+    }
     am_f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
     am_mma_nt64(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Ss[((r & 3) + 8 * (r >> 2) + 4 * hh) * AM_PS + 32 * w + l31] = sacc[r] * alpha;
+    for (int r = 0; r < 16; ++r)
+      Ss[((r & 3) + 8 * (r >> 2) + 4 * hh) * AM_PS + 32 * w + l31] = (j * 128 + 32 * w + l31 < T) ? sacc[r] * alpha : -INFINITY;
     __syncthreads();
     float v[16], bm = -INFINITY;
 #pragma unroll
@@ -199,27 +206,28 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
   am_f32x16 oacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
-  float* Pg = P + (((long)n * H + h) * T + (long)qb * 32) * T + 32 * w + l31;
-  am_gload<128>(vr, base + vo, ldq, tid);
+  float* Pg = P + (((long)n * H + h) * T + (long)qb * 32) * Tp + 32 * w + l31;
+  am_gload<128>(vr, base + vo, ldq, tid, T);
   for (int j = 0; j < nkb; ++j) {
     __syncthreads();
     am_sstore<128>(Ks, AM_P68, kr, tid);
     am_sstore<128>(Vs, AM_P72, vr, tid);
     __syncthreads();
     if (j + 1 < nkb) {
-      am_gload<128>(kr, base + (long)(j + 1) * 128 * ldq + ko, ldq, tid);
-      am_gload<128>(vr, base + (long)(j + 1) * 128 * ldq + vo, ldq, tid);
+      am_gload<128>(kr, base + (long)(j + 1) * 128 * ldq + ko, ldq, tid, T - (j + 1) * 128);
+      am_gload<128>(vr, base + (long)(j + 1) * 128 * ldq + vo, ldq, tid, T - (j + 1) * 128);
     }
     am_f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
     am_mma_nt64(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
+    const int key = j * 128 + 32 * w + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const float p = __expf(sacc[r] * alpha - mr[r]) * il[r];
+      const float p = key < T ? __expf(sacc[r] * alpha - mr[r]) * il[r] : 0.f;
       Ss[row * AM_PS + 32 * w + l31] = p;
-      Pg[(long)row * T + j * 128] = p;
+      if (qb * 32 + row < T && key < Tp) Pg[(long)row * Tp + j * 128] = p;
     }
     __syncthreads();
     am_mma_nn<8>(oacc, &Ss[l31 * AM_PS + 64 * kh], &Vs[(64 * kh) * AM_P72 + 32 * fh + l31], AM_P72, hh);
@@ -237,30 +245,34 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
       const float v = oacc[r] + red[(fh * 32 + row) * 33 + l31];
       const long t = (long)n * T + qb * 32 + row;
-      out[t * ldo + h * 64 + 32 * fh + l31] = v;
-      Ocopy[t * ((long)H * 64) + h * 64 + 32 * fh + l31] = v;
+      if (qb * 32 + row < T) {
+        out[t * ldo + h * 64 + 32 * fh + l31] = v;
+        Ocopy[t * ((long)H * 64) + h * 64 + 32 * fh + l31] = v;
+      }
     }
   }
 }
 
 __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout,
                                                               int lddo, const float* __restrict__ Ocopy, const float* __restrict__ P,
-                                                              float* __restrict__ dS, float* __restrict__ dqkv, int lddq, int T, int H,
-                                                              long qo, long ko, long vo, long step, float alpha) {
+                                                              float* __restrict__ dS, float* __restrict__ dqkv, int lddq, int T, int Tp,
+                                                              int H, long qo, long ko, long vo, long step, float alpha) {
   __shared__ __attribute__((aligned(16))) float dOs[32 * AM_P68], Vs[128 * AM_P68], Ks[128 * AM_P72], Ss[32 * AM_PS];
   __shared__ float Dr[32];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const float* base = qkv + (long)n * T * ldq + h * step;
   const float* dob = dout + ((long)n * T + qb * 32) * lddo + h * 64;
-  am_stage64<32>(dOs, AM_P68, dob, lddo, tid);
+  am_stage64<32>(dOs, AM_P68, dob, lddo, tid, T - qb * 32);
   {
     const int srow = tid >> 3, seg = tid & 7;
-    const float* o = Ocopy + ((long)n * T + qb * 32 + srow) * ((long)H * 64) + h * 64 + seg * 8;
-    const float* g = dob + (long)srow * lddo + seg * 8;
+    const bool rok = qb * 32 + srow < T;
+    const float* o = Ocopy + ((long)n * T + qb * 32 + (rok ? srow : 0)) * ((long)H * 64) + h * 64 + seg * 8;
+    const float* g = dob + (long)(rok ? srow : 0) * lddo + seg * 8;
     float a = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) a += o[i] * g[i];
+    if (!rok) a = 0.f;
     a += __shfl_xor(a, 1, 64);
     a += __shfl_xor(a, 2, 64);
     a += __shfl_xor(a, 4, 64);
@@ -270,25 +282,31 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
   float dr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) dr[r] = Dr[(r & 3) + 8 * (r >> 2) + 4 * hh];
-  const int fh = w & 1, kh = w >> 1, nkb = T >> 7;
+  const int fh = w & 1, kh = w >> 1, nkb = (T + 127) >> 7;
   am_f32x16 qacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) qacc[e] = 0.f;
-  const long pbase = (((long)n * H + h) * T + (long)qb * 32) * T + 32 * w + l31;
+  const long pbase = (((long)n * H + h) * T + (long)qb * 32) * Tp + 32 * w + l31;
   am_f32x4 kr[8], vr[8];
-  am_gload<128>(vr, base + vo, ldq, tid);
-  am_gload<128>(kr, base + ko, ldq, tid);
+  am_gload<128>(vr, base + vo, ldq, tid, T);
+  am_gload<128>(kr, base + ko, ldq, tid, T);
   for (int j = 0; j < nkb; ++j) {
     __syncthreads();
     am_sstore<128>(Vs, AM_P68, vr, tid);
     am_sstore<128>(Ks, AM_P72, kr, tid);
     float pv[16];
+    const int key = j * 128 + 32 * w + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pv[r] = P[pbase + (long)((r & 3) + 8 * (r >> 2) + 4 * hh) * T + j * 128];
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const bool ok = qb * 32 + row < T && key < T;
+      pv[r] = P[ok ? pbase + (long)row * Tp + j * 128 : 0L];
+      if (!ok) pv[r] = 0.f;
+    }
     __syncthreads();
     if (j + 1 < nkb) {
-      am_gload<128>(vr, base + (long)(j + 1) * 128 * ldq + vo, ldq, tid);
-      am_gload<128>(kr, base + (long)(j + 1) * 128 * ldq + ko, ldq, tid);
+      am_gload<128>(vr, base + (long)(j + 1) * 128 * ldq + vo, ldq, tid, T - (j + 1) * 128);
+      am_gload<128>(kr, base + (long)(j + 1) * 128 * ldq + ko, ldq, tid, T - (j + 1) * 128);
     }
     am_f32x16 dp;
 #pragma unroll
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
       const float ds = pv[r] * (dp[r] - dr[r]);
       Ss[row * AM_PS + 32 * w + l31] = ds;
-      dS[pbase + (long)row * T + j * 128] = ds;
+      if (qb * 32 + row < T && key < Tp) dS[pbase + (long)row * Tp + j * 128] = ds;
     }
     __syncthreads();
     am_mma_nn<8>(qacc, &Ss[l31 * AM_PS + 64 * kh], &Ks[(64 * kh) * AM_P72 + 32 * fh + l31], AM_P72, hh);
@@ -315,15 +333,16 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      dqkv[((long)n * T + qb * 32 + row) * lddq + h * step + qo + 32 * fh + l31] = (qacc[r] + red[(fh * 32 + row) * 33 + l31]) * alpha;
+      if (qb * 32 + row < T)
+        dqkv[((long)n * T + qb * 32 + row) * lddq + h * step + qo + 32 * fh + l31] = (qacc[r] + red[(fh * 32 + row) * 33 + l31]) * alpha;
     }
   }
 }
 
 __global__ __launch_bounds__(256) void attn_mid_bwd_dkv_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout,
                                                                int lddo, const float* __restrict__ P, const float* __restrict__ dS,
-                                                               float* __restrict__ dqkv, int lddq, int T, int H, long qo, long ko,
-                                                               long vo, long step, float alpha) {
+                                                               float* __restrict__ dqkv, int lddq, int T, int Tp, int H, long qo,
+                                                               long ko, long vo, long step, float alpha) {
   __shared__ __attribute__((aligned(16))) float Pt[128 * AM_P40], St[128 * AM_P40], dOs[128 * AM_P72], Qs[128 * AM_P72];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int kb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
@@ -333,17 +352,19 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dkv_kernel(const float* __re
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   am_f32x4 pr4[4], sr4[4], gr[8], qr[8];
-  const int ntb = T >> 7;
+  const int ntb = (T + 127) >> 7;  // query rows >= T and key columns >= Tp are zero-filled
 #define DKV_LOAD(TB)                                                                              \
   {                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
       const int e = tid + 256 * i, r = e >> 3, u = e & 7;                                         \
-      const long g = (prow0 + (TB) * 128 + r) * T + kb * 32 + 4 * u;                              \
+      const bool ok = (TB) * 128 + r < T && kb * 32 + 4 * u < Tp;                                 \
+      const long g = ok ? (prow0 + (TB) * 128 + r) * Tp + kb * 32 + 4 * u : 0L;                   \
       pr4[i] = *(const am_f32x4*)(P + g);                                                         \
       sr4[i] = *(const am_f32x4*)(dS + g);                                                        \
+      if (!ok) pr4[i] = sr4[i] = am_f32x4{0.f, 0.f, 0.f, 0.f};                                    \
     }                                                                                             \
-    am_gload<128>(gr, dout + ((long)n * T + (TB) * 128) * lddo + h * 64, lddo, tid);              \
-    am_gload<128>(qr, base + (long)(TB) * 128 * ldq + qo, ldq, tid);                              \
+    am_gload<128>(gr, dout + ((long)n * T + (TB) * 128) * lddo + h * 64, lddo, tid, T - (TB) * 128); \
+    am_gload<128>(qr, base + (long)(TB) * 128 * ldq + qo, ldq, tid, T - (TB) * 128);              \
   }
   DKV_LOAD(0);
   for (int tb = 0; tb < ntb; ++tb) {
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dkv_kernel(const float* __re
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    dqkv[((long)n * T + key) * lddq + off] = acc[r] * sc;
+    if (key < T) dqkv[((long)n * T + key) * lddq + off] = acc[r] * sc;
   }
 }
 
@@ -523,8 +544,8 @@ __global__ __launch_bounds__(256) void attn_s64_bwd_kernel(const float* __restri
   }
 }
 
-// the fused MFMA path: d = 64, T a multiple of 128, 16-byte aligned rows
-bool attn_mid_ok(const AttnShape& sh, int ldq, int ldo) { return sh.d == 64 && sh.T > AS_T && sh.T % 128 == 0 && !(ldq & 3) && !(ldo & 3); }
+// the fused MFMA path: d = 64, any T > 64 (keys / queries beyond T are masked), 16-byte aligned rows
+bool attn_mid_ok(const AttnShape& sh, int ldq, int ldo) { return sh.d == 64 && sh.T > AS_T && !(ldq & 3) && !(ldo & 3); }
 
 }  // namespace
 
@@ -551,7 +572,7 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
     return 0;
   }
   if (attn_mid_ok(sh, ldq, ldo)) {
-    hipLaunchKernelGGL(attn_mid_fwd_kernel, dim3(T / 32, H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, H, ho.q, ho.k,
+    hipLaunchKernelGGL(attn_mid_fwd_kernel, dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, 1.f / sqrtf((float)d));
     CGD_HIP(ctx, hipGetLastError());
     return 0;
@@ -598,10 +619,10 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
     return 0;
   }
   if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3)) {
-    hipLaunchKernelGGL(attn_mid_bwd_dq_kernel, dim3(T / 32, H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP, dqkv,
-                       lddq, T, H, ho.q, ho.k, ho.v, ho.step, alpha);
-    hipLaunchKernelGGL(attn_mid_bwd_dkv_kernel, dim3(T / 32, H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq, T,
-                       H, ho.q, ho.k, ho.v, ho.step, alpha);
+    hipLaunchKernelGGL(attn_mid_bwd_dq_kernel, dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
+                       dqkv, lddq, T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
+    hipLaunchKernelGGL(attn_mid_bwd_dkv_kernel, dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq,
+                       T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }

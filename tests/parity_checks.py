@@ -230,7 +230,7 @@ def check_attn(precision):
     ctx = _ctx(precision)
     out = []
     for (nb, heads, T, d, legacy) in [(2, 2, 64, 64, 1), (1, 4, 256, 64, 1), (3, 12, 50, 64, 0), (1, 3, 100, 64, 0), (1, 4, 64, 128, 1),
-                                      (2, 3, 256, 64, 0), (1, 2, 1024, 64, 1), (1, 2, 192, 64, 1)]:
+                                      (2, 3, 256, 64, 0), (1, 2, 1024, 64, 1), (1, 2, 192, 64, 1), (2, 12, 197, 64, 0), (1, 4, 257, 64, 0)]:
         Cc = heads * d
         qkv = th.randn(nb * T, 3 * Cc, generator=g(40))
         dout = th.randn(nb * T, Cc, generator=g(41))
