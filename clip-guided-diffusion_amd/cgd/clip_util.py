@@ -136,8 +136,7 @@ def load_clip(model_name="ViT-B/32", device="cpu"):
             tower = _nets.ClipResNetTower(ctx, model_name)
             tower.load_state_dict(_synthetic.resnet_state_dict(tower, seed=2468, device=f"cuda:{ctx.device}"))
         else:
-            raise NotImplementedError(f"{model_name}: supported towers are {sorted(_nets.VIT_CONFIGS) + sorted(_nets.RN_CONFIGS)} "
-                                      "(RN50x4 / RN50x16 need 16-channel conv slices)")
+            raise NotImplementedError(f"{model_name}: supported towers are {sorted(_nets.VIT_CONFIGS) + sorted(_nets.RN_CONFIGS)}")
         return ClipModel(tower, None, model_name), tower.input_resolution
     raise FileNotFoundError(f"{model_path} not found (set CGD_SYNTHETIC_WEIGHTS=1 for seeded random weights)")
 

@@ -1,4 +1,4 @@
-// CLIP image tower, ModifiedResNet variant (RN50 / RN101), forward and backward-to-input on MI355X.
+// CLIP image tower, ModifiedResNet variant (RN50 / RN101 / RN50x4 / RN50x16), forward and backward-to-input on MI355X.
 //
 // Replaces clip_model.encode_image(clip_in) (/root/reference/cgd/cgd.py:194) for the ResNet entries of
 // CLIP_MODEL_NAMES (/root/reference/cgd/clip_util.py:17) and their leg of th.autograd.grad(loss, x) (cgd.py:228).
@@ -21,17 +21,20 @@ typedef float rn_f32x4 __attribute__((ext_vector_type(4)));
 int rn_grid(long n) { return (int)std::min<long>((n + 255) / 256, 16384); }
 
 // ---- small kernels -------------------------------------------------------------------------------------------------------
-// w_out[co][:] = w[co][:] * gamma/sqrt(var+eps) ; b_out[co] = beta - mean * gamma/sqrt(var+eps)
+// w_out[co][ci][t] = w[co][ci][t] * gamma/sqrt(var+eps) into a zero-initialised, channel-padded layout [CoP][CiP][kk];
+// b_out[co] = beta - mean * gamma/sqrt(var+eps)
 __global__ __launch_bounds__(256) void rn_fold_bn_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ mean,
                                                          const float* __restrict__ var, float* __restrict__ w_out, float* __restrict__ b_out,
-                                                         int Co, long per) {
-  const long total = (long)Co * per;
+                                                         int Co, int Ci, int CiP, int kk) {
+  const long per = (long)Ci * kk, total = (long)Co * per;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int co = (int)(i / per);
+    const long rem = i - (long)co * per;
+    const int ci = (int)(rem / kk), t = (int)(rem - (long)ci * kk);
     const float sc = gamma[co] * rsqrtf(var[co] + 1e-5f);
-    w_out[i] = w[i] * sc;
-    if (i % per == 0) b_out[co] = beta[co] - mean[co] * sc;
+    w_out[((long)co * CiP + ci) * kk + t] = w[i] * sc;
+    if (rem == 0) b_out[co] = beta[co] - mean[co] * sc;
   }
 }
 // stem conv1 weight [Co][3][3][3] (co, ci, ky, kx) -> forward GEMM operand [Co][32] (k = tap*3 + ci, zero padded) and
@@ -209,16 +212,21 @@ __global__ __launch_bounds__(64) void rn_pool_attn_bwd_kernel(const float* __res
 }
 
 // ---- network ------------------------------------------------------------------------------------------------------------
+static int pad32(int c) { return (c + 31) & ~31; }
+
+// cin / cout: the checkpoint's channel counts; cinP / coutP: the device layout, padded to multiples of 32 with zero weights
+// (RN50x4: 40 -> 64, 80 -> 96; RN50x16: 48 -> 64).  Padded channels stay exactly zero forward (zero weight rows and bias,
+// ReLU) and backward (zero weight columns).
 struct ConvBN {
   std::string conv, bn;
-  int cin = 0, cout = 0, k = 1;
+  int cin = 0, cout = 0, k = 1, cinP = 0, coutP = 0;
   float *w = 0, *bias = 0;             // folded; 1x1: [cout][cin]; 3x3: torch layout before packing
   float *wT = 0;                        // 1x1: [cin][cout]
   float *wf = 0, *wd = 0, *wfp = 0, *wdp = 0;  // 3x3 packs
 };
 
 struct Block {
-  int inplanes = 0, planes = 0, stride = 1;
+  int inplanes = 0, planes = 0, c4 = 0, stride = 1;  // device (padded) widths: input, bottleneck, output
   bool has_ds = false;
   ConvBN c1, c2, c3, cd;
   int H = 0, W = 0;  // input map
@@ -253,7 +261,7 @@ struct ResNet : NetBase {
   }
   int conv3(const float* A, const ConvBN& c, bool dgrad_, float* C, int Bn, int H, int W, hipStream_t s) {
     GemmParams g;
-    const int ci = dgrad_ ? c.cout : c.cin, co = dgrad_ ? c.cin : c.cout;
+    const int ci = dgrad_ ? c.coutP : c.cinP, co = dgrad_ ? c.cinP : c.coutP;
     g.A = A; g.lda = ci; g.B = dgrad_ ? c.wd : c.wf; g.Bpk = dgrad_ ? c.wdp : c.wfp; g.ldb = 9 * ci; g.C = C; g.ldc = co;
     g.bias = dgrad_ ? nullptr : c.bias;
     g.M = Bn * H * W; g.N = co; g.conv = 1; g.H = H; g.W = W; g.Cin = ci;
@@ -267,6 +275,8 @@ struct ResNet : NetBase {
 
 void ResNet::add_convbn(ConvBN& c, const std::string& conv, const std::string& bn, int cin, int cout, int k) {
   c.conv = conv; c.bn = bn; c.cin = cin; c.cout = cout; c.k = k;
+  c.cinP = cin == 3 ? 3 : pad32(cin);
+  c.coutP = pad32(cout);
   add_param(conv + ".weight", (int64_t)cout * cin * k * k);
   add_param(bn + ".weight", cout);
   add_param(bn + ".bias", cout);
@@ -278,7 +288,7 @@ int ResNet::build() {
   const int w = cfg.width;
   R = cfg.resolution;
   if (R % 32) CGD_FAIL(ctx, "resnet: resolution must be a multiple of 32");
-  if (w % 64) CGD_FAIL(ctx, "resnet: width must be a multiple of 64 (RN50 / RN101); RN50x4 / RN50x16 need 16-channel conv slices");
+  if (w % 16) CGD_FAIL(ctx, "resnet: width must be a multiple of 16");
   E = w * 32;
   if (E != cfg.heads * 64) CGD_FAIL(ctx, "resnet: attention pool needs head dim 64");
   NPX = (R / 32) * (R / 32);
@@ -293,13 +303,14 @@ int ResNet::build() {
     for (int i = 0; i < cfg.layers[L]; ++i) {
       blocks.emplace_back();
       Block& b = blocks.back();
-      b.inplanes = inpl; b.planes = planes; b.stride = i == 0 ? stride : 1;
+      b.inplanes = pad32(inpl); b.planes = pad32(planes); b.stride = i == 0 ? stride : 1;  // device (padded) widths
       b.has_ds = i == 0 && (stride > 1 || inpl != planes * 4);
       const std::string p = "layer" + std::to_string(L + 1) + "." + std::to_string(i);
       add_convbn(b.c1, p + ".conv1", p + ".bn1", inpl, planes, 1);
       add_convbn(b.c2, p + ".conv2", p + ".bn2", planes, planes, 3);
       add_convbn(b.c3, p + ".conv3", p + ".bn3", planes, planes * 4, 1);
       if (b.has_ds) add_convbn(b.cd, p + ".downsample.0", p + ".downsample.1", inpl, planes * 4, 1);
+      b.c4 = b.c3.coutP;
       inpl = planes * 4;
     }
   }
@@ -314,26 +325,29 @@ int ResNet::build() {
 }
 
 int ResNet::fold(ConvBN& c, hipStream_t s) {
-  const long per = (long)c.cin * c.k * c.k;
+  const int kk = c.k * c.k;
+  const size_t nw = (size_t)c.coutP * c.cinP * kk;
   if (!c.w) {
-    CGD_TRY(alloc(&c.w, (size_t)c.cout * per));
-    CGD_TRY(alloc(&c.bias, (size_t)c.cout));
+    CGD_TRY(alloc(&c.w, nw));
+    CGD_TRY(alloc(&c.bias, (size_t)c.coutP));
   }
-  hipLaunchKernelGGL(rn_fold_bn_kernel, dim3(rn_grid((long)c.cout * per)), dim3(256), 0, s, P(c.conv + ".weight"), P(c.bn + ".weight"),
-                     P(c.bn + ".bias"), P(c.bn + ".running_mean"), P(c.bn + ".running_var"), c.w, c.bias, c.cout, per);
+  CGD_HIP(ctx, hipMemsetAsync(c.w, 0, nw * sizeof(float), s));
+  CGD_HIP(ctx, hipMemsetAsync(c.bias, 0, (size_t)c.coutP * sizeof(float), s));
+  hipLaunchKernelGGL(rn_fold_bn_kernel, dim3(rn_grid((long)c.cout * c.cin * kk)), dim3(256), 0, s, P(c.conv + ".weight"), P(c.bn + ".weight"),
+                     P(c.bn + ".bias"), P(c.bn + ".running_mean"), P(c.bn + ".running_var"), c.w, c.bias, c.cout, c.cin, c.cinP, kk);
   if (c.k == 1) {
-    if (!c.wT) CGD_TRY(alloc(&c.wT, (size_t)c.cout * c.cin));
-    CGD_TRY(cgd_launch_transpose(ctx, c.w, c.cin, 0, c.wT, c.cout, 0, c.cout, c.cin, 1, s));
+    if (!c.wT) CGD_TRY(alloc(&c.wT, nw));
+    CGD_TRY(cgd_launch_transpose(ctx, c.w, c.cinP, 0, c.wT, c.coutP, 0, c.coutP, c.cinP, 1, s));
   } else if (c.cin >= 32) {
     if (!c.wf) {
-      CGD_TRY(alloc(&c.wf, (size_t)c.cout * per));
-      CGD_TRY(alloc(&c.wd, (size_t)c.cout * per));
-      CGD_TRY(alloc(&c.wfp, cgd_hconv_packed_floats(c.cout, c.cin)));
-      CGD_TRY(alloc(&c.wdp, cgd_hconv_packed_floats(c.cout, c.cin)));
+      CGD_TRY(alloc(&c.wf, nw));
+      CGD_TRY(alloc(&c.wd, nw));
+      CGD_TRY(alloc(&c.wfp, cgd_hconv_packed_floats(c.coutP, c.cinP)));
+      CGD_TRY(alloc(&c.wdp, cgd_hconv_packed_floats(c.coutP, c.cinP)));
     }
-    CGD_TRY(cgd_pack_conv3x3(ctx, c.w, c.wf, c.wd, c.cout, c.cin, s));
-    CGD_TRY(cgd_pack_conv3x3_frag(ctx, c.w, c.wfp, c.cout, c.cin, 0, s));
-    CGD_TRY(cgd_pack_conv3x3_frag(ctx, c.w, c.wdp, c.cout, c.cin, 1, s));
+    CGD_TRY(cgd_pack_conv3x3(ctx, c.w, c.wf, c.wd, c.coutP, c.cinP, s));
+    CGD_TRY(cgd_pack_conv3x3_frag(ctx, c.w, c.wfp, c.coutP, c.cinP, 0, s));
+    CGD_TRY(cgd_pack_conv3x3_frag(ctx, c.w, c.wdp, c.coutP, c.cinP, 1, s));
   }
   return 0;
 }
@@ -344,10 +358,10 @@ int ResNet::finalize(hipStream_t s) {
   CGD_TRY(fold(s2, s));
   CGD_TRY(fold(s3, s));
   if (!s1f) {
-    CGD_TRY(alloc(&s1f, (size_t)s1.cout * 32));
-    CGD_TRY(alloc(&s1b, (size_t)32 * s1.cout));
+    CGD_TRY(alloc(&s1f, (size_t)s1.coutP * 32));
+    CGD_TRY(alloc(&s1b, (size_t)32 * s1.coutP));
   }
-  hipLaunchKernelGGL(rn_pack_stem_kernel, dim3((s1.cout * 32 + 255) / 256), dim3(256), 0, s, s1.w, s1f, s1b, s1.cout);
+  hipLaunchKernelGGL(rn_pack_stem_kernel, dim3((s1.coutP * 32 + 255) / 256), dim3(256), 0, s, s1.w, s1f, s1b, s1.coutP);
   for (Block& b : blocks) {
     CGD_TRY(fold(b.c1, s));
     CGD_TRY(fold(b.c2, s));
@@ -381,19 +395,19 @@ int ResNet::finalize(hipStream_t s) {
 int ResNet::forward(const float* img, int Nn, float* emb, hipStream_t s) {
   if (!finalized) CGD_FAIL(ctx, "resnet: weights not finalized");
   N = Nn;
-  const int w = cfg.width, R2 = R / 2, R4 = R / 4;
+  const int wh = s1.coutP, w = s3.coutP, R2 = R / 2, R4 = R / 4;  // device (padded) stem widths
   const long M2 = (long)N * R2 * R2, M4 = (long)N * R4 * R4;
   // stem
   CGD_TRY(ensure(col, (size_t)M2 * 32));
-  CGD_TRY(ensure(a1, (size_t)M2 * (w / 2)));
-  CGD_TRY(ensure(a2, (size_t)M2 * (w / 2)));
+  CGD_TRY(ensure(a1, (size_t)M2 * wh));
+  CGD_TRY(ensure(a2, (size_t)M2 * wh));
   CGD_TRY(ensure(a3, (size_t)M2 * w));
   CGD_TRY(ensure(a3p, (size_t)M4 * w));
   hipLaunchKernelGGL(rn_stem_im2col_kernel, dim3(rn_grid(M2 * 8)), dim3(256), 0, s, img, col.p, N, R, R2);
-  CGD_TRY(gemm(col.p, 32, s1f, 32, a1.p, w / 2, s1.bias, nullptr, 0, M2, w / 2, s));
-  relu(a1.p, M2 * (w / 2), s);
+  CGD_TRY(gemm(col.p, 32, s1f, 32, a1.p, wh, s1.bias, nullptr, 0, M2, wh, s));
+  relu(a1.p, M2 * wh, s);
   CGD_TRY(conv3(a1.p, s2, false, a2.p, N, R2, R2, s));
-  relu(a2.p, M2 * (w / 2), s);
+  relu(a2.p, M2 * wh, s);
   CGD_TRY(conv3(a2.p, s3, false, a3.p, N, R2, R2, s));
   relu(a3.p, M2 * w, s);
   CGD_TRY(cgd_launch_pool2x2(ctx, a3.p, w, a3p.p, w, nullptr, 0, N, R4, R4, w, 0.25f, s));
@@ -406,7 +420,7 @@ int ResNet::forward(const float* img, int Nn, float* emb, hipStream_t s) {
     const long Mi = (long)N * H * Wd, Mo = (long)N * Ho * Wo;
     CGD_TRY(ensure(b.o1, (size_t)Mi * b.planes));
     CGD_TRY(ensure(b.o2, (size_t)Mi * b.planes));
-    CGD_TRY(ensure(b.out, (size_t)Mo * b.planes * 4));
+    CGD_TRY(ensure(b.out, (size_t)Mo * b.c4));
     CGD_TRY(gemm(x, b.inplanes, b.c1.w, b.inplanes, b.o1.p, b.planes, b.c1.bias, nullptr, 0, Mi, b.planes, s));
     relu(b.o1.p, Mi * b.planes, s);
     CGD_TRY(conv3(b.o1.p, b.c2, false, b.o2.p, N, H, Wd, s));
@@ -423,12 +437,12 @@ int ResNet::forward(const float* img, int Nn, float* emb, hipStream_t s) {
     }
     const float* idp = x;
     if (b.has_ds) {
-      CGD_TRY(ensure(b.d_id, (size_t)Mo * b.planes * 4));  // also the forward shortcut buffer
-      CGD_TRY(gemm(xin, b.inplanes, b.cd.w, b.inplanes, b.d_id.p, b.planes * 4, b.cd.bias, nullptr, 0, Mo, b.planes * 4, s));
+      CGD_TRY(ensure(b.d_id, (size_t)Mo * b.c4));  // also the forward shortcut buffer
+      CGD_TRY(gemm(xin, b.inplanes, b.cd.w, b.inplanes, b.d_id.p, b.c4, b.cd.bias, nullptr, 0, Mo, b.c4, s));
       idp = b.d_id.p;
     }
-    CGD_TRY(gemm(o2in, b.planes, b.c3.w, b.planes, b.out.p, b.planes * 4, b.c3.bias, idp, b.planes * 4, Mo, b.planes * 4, s));
-    relu(b.out.p, Mo * b.planes * 4, s);
+    CGD_TRY(gemm(o2in, b.planes, b.c3.w, b.planes, b.out.p, b.c4, b.c3.bias, idp, b.c4, Mo, b.c4, s));
+    relu(b.out.p, Mo * b.c4, s);
     x = b.out.p;
     H = Ho; Wd = Wo;
   }
@@ -450,7 +464,7 @@ int ResNet::forward(const float* img, int Nn, float* emb, hipStream_t s) {
 
 int ResNet::dgrad(const float* demb, float* dimg, hipStream_t s) {
   if (!have_fwd) CGD_FAIL(ctx, "resnet: dgrad without a forward");
-  const int w = cfg.width, R2 = R / 2, R4 = R / 4;
+  const int wh = s1.coutP, w = s3.coutP, R2 = R / 2, R4 = R / 4;
   // attention pool backward
   CGD_TRY(ensure(d_o, (size_t)N * E));
   CGD_TRY(ensure(dq, (size_t)N * E));
@@ -473,7 +487,7 @@ int ResNet::dgrad(const float* demb, float* dimg, hipStream_t s) {
     Block& b = blocks[bi];
     const int H = b.H, Wd = b.W, Ho = H / b.stride, Wo = Wd / b.stride;
     const long Mi = (long)N * H * Wd, Mo = (long)N * Ho * Wo;
-    const int C4 = b.planes * 4;
+    const int C4 = b.c4;
     relu_bwd(b.out.p, dout, Mo * C4, s);  // dz: gradient of (conv3 out + shortcut)
     // main branch
     CGD_TRY(ensure(b.d_o2p, (size_t)Mo * b.planes));
@@ -511,14 +525,14 @@ int ResNet::dgrad(const float* demb, float* dimg, hipStream_t s) {
   CGD_TRY(ensure(d_a3, (size_t)M2 * w));
   CGD_TRY(cgd_launch_upsample2x(ctx, dout, w, d_a3.p, w, nullptr, 0, N, R2, R2, w, 0.25f, s));
   relu_bwd(a3.p, d_a3.p, M2 * w, s);
-  CGD_TRY(ensure(d_a2, (size_t)M2 * (w / 2)));
+  CGD_TRY(ensure(d_a2, (size_t)M2 * wh));
   CGD_TRY(conv3(d_a3.p, s3, true, d_a2.p, N, R2, R2, s));
-  relu_bwd(a2.p, d_a2.p, M2 * (w / 2), s);
-  CGD_TRY(ensure(d_a1, (size_t)M2 * (w / 2)));
+  relu_bwd(a2.p, d_a2.p, M2 * wh, s);
+  CGD_TRY(ensure(d_a1, (size_t)M2 * wh));
   CGD_TRY(conv3(d_a2.p, s2, true, d_a1.p, N, R2, R2, s));
-  relu_bwd(a1.p, d_a1.p, M2 * (w / 2), s);
+  relu_bwd(a1.p, d_a1.p, M2 * wh, s);
   CGD_TRY(ensure(Tst, (size_t)M2 * 32));
-  CGD_TRY(gemm(d_a1.p, w / 2, s1b, w / 2, Tst.p, 32, nullptr, nullptr, 0, M2, 32, s));
+  CGD_TRY(gemm(d_a1.p, wh, s1b, wh, Tst.p, 32, nullptr, nullptr, 0, M2, 32, s));
   hipLaunchKernelGGL(rn_stem_gather_kernel, dim3(rn_grid((long)N * 3 * R * R)), dim3(256), 0, s, Tst.p, dimg, N, R, R2);
   CGD_HIP(ctx, hipGetLastError());
   return 0;

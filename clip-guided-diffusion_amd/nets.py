@@ -163,6 +163,8 @@ RN_CONFIGS = {
     # name: (resolution, width, layers, out_dim, heads)   (clip/model.py ModifiedResNet)
     "RN50": (224, 64, (3, 4, 6, 3), 1024, 32),
     "RN101": (224, 64, (3, 4, 23, 3), 512, 32),
+    "RN50x4": (288, 80, (4, 6, 10, 6), 640, 40),    # widths 40 / 80 are zero-padded to 64 / 96 channels on the device
+    "RN50x16": (384, 96, (6, 8, 18, 8), 768, 48),
 }
 
 

@@ -1,4 +1,4 @@
-"""CPU oracle: CLIP image tower, ModifiedResNet variant (RN50 / RN101).  TEST INFRASTRUCTURE ONLY.
+"""CPU oracle: CLIP image tower, ModifiedResNet variant (RN50 / RN101 / RN50x4 / RN50x16).  TEST INFRASTRUCTURE ONLY.
 
 Restates `clip.model.ModifiedResNet`, `Bottleneck` and `AttentionPool2d` of the un-vendored dependency clip-anytorch 2.6.0
 (/root/reference/uv.lock:254-255; = OpenAI clip/model.py).  Reference call sites: /root/reference/cgd/clip_util.py:17
@@ -24,6 +24,8 @@ RN_CONFIGS = {
     # name: (resolution, width, layers, out_dim, heads)
     "RN50": (224, 64, (3, 4, 6, 3), 1024, 32),
     "RN101": (224, 64, (3, 4, 23, 3), 512, 32),
+    "RN50x4": (288, 80, (4, 6, 10, 6), 640, 40),
+    "RN50x16": (384, 96, (6, 8, 18, 8), 768, 48),
 }
 
 

@@ -24,6 +24,8 @@ GROUPS = {
     "resnet": [lambda: pc.check_resnet("tiny", 0, config=(64, 64, (1, 1, 1, 1), 128, 32)),
                lambda: pc.check_resnet("tiny", 1, config=(64, 64, (1, 1, 1, 1), 128, 32)),
                lambda: pc.check_resnet("RN50", 0), lambda: pc.check_resnet("RN50", 1),
+               lambda: pc.check_resnet("x4-tiny", 0, config=(96, 80, (1, 1, 1, 1), 64, 40)),
+               lambda: pc.check_resnet("x16-tiny", 1, config=(64, 96, (1, 1, 1, 1), 64, 48)),
                lambda: _sc().check_step("mini", 0, respacing="50", steps=2, B=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32))],
     "lpips": [lambda: pc.check_lpips(0), lambda: pc.check_lpips(1),
               lambda: _sc().check_step("mini", 1, respacing="50", steps=2, B=2, init_scale=100.0)],

@@ -82,7 +82,9 @@ def test_clip_vit_other_towers(name):
 
 
 @pytest.mark.parametrize("name,precision,config", [("tiny", 0, (64, 64, (1, 1, 1, 1), 128, 32)), ("tiny", 1, (64, 64, (1, 1, 1, 1), 128, 32)),
-                                                   ("RN50", 1, None)])
+                                                   ("RN50", 1, None), ("x4-tiny", 0, (96, 80, (1, 1, 1, 1), 64, 40)),
+                                                   ("x16-tiny", 1, (64, 96, (1, 1, 1, 1), 64, 48))])
 def test_clip_modified_resnet(name, precision, config):
-    # forward at rtol 1e-3 / atol 1e-4; the gradient of a ReLU tower by relative L2 (parity_checks.rec_l2 explains why)
+    # forward at rtol 1e-3 / atol 1e-4; the gradient of a ReLU tower by relative L2 (parity_checks.rec_l2 explains why);
+    # the x4 / x16 widths (80 / 96, stems 40 / 48) exercise the zero-padded channel layout
     _assert_all(pc.check_resnet(name, precision, config=config))

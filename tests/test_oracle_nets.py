@@ -96,7 +96,7 @@ def test_clip_resnet_oracle_parameter_counts_and_shapes():
     """ModifiedResNet oracle: the published tower sizes (RN50 38,316,896; RN101 56,259,936 parameters), OpenAI key names and
     the output shape."""
     from oracle import clip_resnet as ocr
-    for name, count in (("RN50", 38_316_896), ("RN101", 56_259_936)):
+    for name, count in (("RN50", 38_316_896), ("RN101", 56_259_936), ("RN50x4", 87_137_080)):
         m = ocr.ClipResNetImageModel(name)
         assert sum(p.numel() for p in m.parameters()) == count
     m = ocr.synthetic_init_(ocr.ClipResNetImageModel(config=(64, 64, (1, 1, 1, 1), 128, 32))).eval()
