@@ -77,21 +77,29 @@ def clip_guided_diffusion(
     Path(checkpoints_dir).mkdir(parents=True, exist_ok=True)
     diffusion_path = script_util.download_guided_diffusion(image_size=image_size, checkpoints_dir=checkpoints_dir, class_cond=class_cond)
 
-    # CLIP tower, prompt embeddings and weights
-    clip_model, clip_size = clip_util.load_clip(clip_model_name, device)
-    embeds, weights = [], []
+    # CLIP tower(s), prompt embeddings and weights.  "A+B" (e.g. "RN50+ViT-L/14", BASELINE config 5) sums the CLIP losses of
+    # several towers: a build extension, the reference takes a single name.
+    clip_names = [n.strip() for n in clip_model_name.split("+")]
+    clip_models, clip_size = [], None
+    for name in clip_names:
+        cm, size = clip_util.load_clip(name, device)
+        clip_models.append(cm)
+        clip_size = clip_size or size
+    clip_model = clip_models[0]
+    embeds_per_tower, weights = [[] for _ in clip_names], []
     for prompt in prompts:
         text, weight = script_util.parse_prompt(prompt)
-        embed, weight = clip_util.encode_text_prompt(text, weight, clip_model_name, device)
-        embeds.append(embed)
-        weights.append(weight)
+        for k, name in enumerate(clip_names):
+            embed, w_k = clip_util.encode_text_prompt(text, weight, name, device)
+            embeds_per_tower[k].append(embed)
+        weights.append(w_k)
     for image_prompt in image_prompts:
         img, weight = script_util.parse_prompt(image_prompt)
-        embed, batched = clip_util.encode_image_prompt(img, weight, image_size, num_cutouts=num_cutouts, clip_model_name=clip_model_name,
-                                                       device=device)
-        embeds.append(embed)
+        for k, name in enumerate(clip_names):
+            embed, batched = clip_util.encode_image_prompt(img, weight, image_size, num_cutouts=num_cutouts, clip_model_name=name, device=device)
+            embeds_per_tower[k].append(embed)
         weights.extend(batched)
-    target_embeds = th.cat(embeds)
+    target_embeds = [th.cat(e) for e in embeds_per_tower]
     weight_t = th.tensor(weights, device=device)
     if weight_t.sum().abs() < 1e-3:
         raise RuntimeError("The weights must not sum to 0.")
@@ -125,7 +133,7 @@ def clip_guided_diffusion(
             tqdm.write(f"Skipping first {skip_timesteps} timesteps (--reduce-clip optimization)")
 
     cond_fn = ClipGuidance(
-        gd_model.ctx, gd_model, clip_model.tower, diffusion, target_embeds, weight_t, num_cutouts, cutout_power=cutout_power,
+        gd_model.ctx, gd_model, [cm.tower for cm in clip_models], diffusion, target_embeds, weight_t, num_cutouts, cutout_power=cutout_power,
         clip_guidance_scale=clip_guidance_scale, tv_scale=tv_scale, range_scale=range_scale, sat_scale=sat_scale, use_magnitude=use_magnitude,
         reduce_clip=reduce_clip, progressive_cutout=progressive_cutout, cached_cutouts=cached_cutouts, make_cutouts=make_cutouts,
         # "initialized lazily as it can use a bit of VRAM" (reference cgd.py:146-148): only with an init image and a non-zero scale

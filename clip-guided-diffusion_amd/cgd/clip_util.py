@@ -103,7 +103,7 @@ def _rn_config_from_state_dict(sd):
     return (grid * 32, width, tuple(counts), out_dim, width * 32 // 64)
 
 
-@lru_cache(maxsize=1)
+@lru_cache(maxsize=4)  # the reference caches one model; "A+B" multi-CLIP runs keep several
 def load_clip(model_name="ViT-B/32", device="cpu"):
     print(f"Loading clip model\t{model_name}\ton device\t{device}.")
     if device == "cpu" or "cuda" not in device:

@@ -98,9 +98,16 @@ class ClipGuidance:
                  clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0, sat_scale=0.0, use_magnitude=False,
                  reduce_clip=False, progressive_cutout=False, cached_cutouts=False, make_cutouts=None, lpips=None, init_tensor=None,
                  init_scale=0.0):
-        self.ctx, self.unet, self.clip, self.diffusion = ctx, unet, clip_tower, diffusion
-        dev = target_embeds.device
-        self.targets_n = F.normalize(target_embeds.float(), dim=-1).contiguous()
+        # Multi-CLIP (BASELINE config 5, a build extension: the reference takes one clip_model_name): `clip_tower` / `target_embeds`
+        # may be lists; the CLIP losses of the towers are summed (same cutout boxes, prompt weights and guidance scale).
+        self.towers = list(clip_tower) if isinstance(clip_tower, (list, tuple)) else [clip_tower]
+        embeds = list(target_embeds) if isinstance(target_embeds, (list, tuple)) else [target_embeds]
+        assert len(embeds) == len(self.towers), "one target-embedding tensor per CLIP tower"
+        self.ctx, self.unet, self.clip, self.diffusion = ctx, unet, self.towers[0], diffusion
+        clip_tower = self.towers[0]
+        dev = embeds[0].device
+        self.targets_list = [F.normalize(e.float(), dim=-1).contiguous() for e in embeds]
+        self.targets_n = self.targets_list[0]
         self.weights = th.as_tensor(weights, dtype=th.float32, device=dev).flatten()
         self.num_cutouts = num_cutouts
         self.cgs, self.tvs, self.rs, self.sats = float(clip_guidance_scale), float(tv_scale), float(range_scale), float(sat_scale)
@@ -161,26 +168,10 @@ class ClipGuidance:
         self.make_cutouts.last_coords = coords
         cutn = len(coords)
         geo = th.tensor(crop_geometry(coords, H, W), dtype=th.int32).to(dev, non_blocking=True)
-        cs, patch = self.clip.input_resolution, self.clip.patch
         N = cutn * B
-        if patch:  # ViT towers: the cutout kernel writes the patch rows of the patch-embedding GEMM directly (layout 1)
-            gsz = cs // patch
-            clip_in = self._b("patches", (N * gsz * gsz, 3 * patch * patch), dev)
-            layout = 1
-        else:      # ModifiedResNet towers: plain (N,3,cs,cs) images (layout 0)
-            clip_in = self._b("cut_images", (N, 3, cs, cs), dev)
-            layout = 0
-        ctx.check(lib.cgd_cutouts_fwd(ctx.h, x_in.data_ptr(), geo.data_ptr(), clip_in.data_ptr(), B, H, W, cutn, cs, layout, patch, s))
-        emb = self.clip.encode_image(clip_in, layout=layout, n=N, out=self._b("emb", (N, self.clip.out_dim), dev))
-        P = self.targets_n.shape[0]
         wm = self._wm.get(B)
         if wm is None:
             wm = self._wm[B] = prompt_weight_matrix(self.weights.cpu(), B, dev)
-        demb = self._b("demb", (N, self.clip.out_dim), dev)
-        clip_part = self._b("clip_part", (N,), dev)
-        ctx.check(lib.cgd_spherical_loss(ctx.h, emb.data_ptr(), self.targets_n.data_ptr(), wm.data_ptr(), demb.data_ptr(),
-                                         clip_part.data_ptr(), cutn, B, P, self.clip.out_dim, self.cgs, s))
-        dpatches = self.clip.dgrad(demb, self._b("dclip_in", tuple(clip_in.shape), dev))
         gclip = self._b("gclip", (B, 3, H, W), dev)
         acc = 0
         if self.lpips is not None:
@@ -191,7 +182,26 @@ class ClipGuidance:
             self.lpips_loss, _ = self.lpips.loss_grad(x_in, grad_scale=self.init_scale, g=gclip, accumulate=False,
                                                       loss=self._b("lpips_loss", (B,), dev))
             acc = 1
-        ctx.check(lib.cgd_cutouts_bwd(ctx.h, dpatches.data_ptr(), geo.data_ptr(), gclip.data_ptr(), B, H, W, cutn, cs, layout, patch, acc, s))
+        clip_part = self._b("clip_part", (len(self.towers) * N,), dev)
+        for k, (tower, targets) in enumerate(zip(self.towers, self.targets_list)):
+            cs, patch = tower.input_resolution, tower.patch
+            if patch:  # ViT towers: the cutout kernel writes the patch rows of the patch-embedding GEMM directly (layout 1)
+                gsz = cs // patch
+                clip_in = self._b(f"patches{k}", (N * gsz * gsz, 3 * patch * patch), dev)
+                layout = 1
+            else:      # ModifiedResNet towers: plain (N,3,cs,cs) images (layout 0)
+                clip_in = self._b(f"cut_images{k}", (N, 3, cs, cs), dev)
+                layout = 0
+            ctx.check(lib.cgd_cutouts_fwd(ctx.h, x_in.data_ptr(), geo.data_ptr(), clip_in.data_ptr(), B, H, W, cutn, cs, layout, patch, s))
+            emb = tower.encode_image(clip_in, layout=layout, n=N, out=self._b(f"emb{k}", (N, tower.out_dim), dev))
+            demb = self._b(f"demb{k}", (N, tower.out_dim), dev)
+            ctx.check(lib.cgd_spherical_loss(ctx.h, emb.data_ptr(), targets.data_ptr(), wm.data_ptr(), demb.data_ptr(),
+                                             clip_part[k * N:].data_ptr(), cutn, B, targets.shape[0], tower.out_dim, self.cgs, s))
+            dclip_in = tower.dgrad(demb, self._b(f"dclip_in{k}", tuple(clip_in.shape), dev))
+            ctx.check(lib.cgd_cutouts_bwd(ctx.h, dclip_in.data_ptr(), geo.data_ptr(), gclip.data_ptr(), B, H, W, cutn, cs, layout, patch, acc, s))
+            acc = 1
+            if k == 0:
+                self.emb = emb
         nblk = lib.cgd_guidance_part_blocks(B, H, W)
         gdir = self._b("gdir", (B, 3, H, W), dev)
         seed6 = self._b("seed6", (B, 6, H, W), dev)
@@ -203,10 +213,9 @@ class ClipGuidance:
         gpart = self._b("gpart", (nblk, 2), dev)
         ctx.check(lib.cgd_grad_finish(ctx.h, gdir.data_ptr(), gunet.data_ptr(), g.data_ptr(), gpart.data_ptr(), B, H, W, s))
         self.scalars = self._b("scalars", (8,), dev)
-        ctx.check(lib.cgd_scalars(ctx.h, clip_part.data_ptr(), N, lpart.data_ptr(), gpart.data_ptr(), B, H, W, int(self.use_magnitude),
-                                  self.scalars.data_ptr(), s))
+        ctx.check(lib.cgd_scalars(ctx.h, clip_part.data_ptr(), len(self.towers) * N, lpart.data_ptr(), gpart.data_ptr(), B, H, W,
+                                  int(self.use_magnitude), self.scalars.data_ptr(), s))
         self._keep = geo
-        self.emb = emb
         return g
 
     def log(self):

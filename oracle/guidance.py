@@ -111,11 +111,24 @@ def make_cond_fn(*, diffusion, clip_model, make_cutouts, target_embeds, weights,
         if coords_tape is not None:
             coords = coords_tape[state["calls"]]
         state["calls"] += 1
-        cut = make_cutouts(x_in.add(1).div(2), use_cache=cached_cutouts, num_cutouts_override=cutn, coords=coords)
-        clip_in = clip_normalize(cut)
-        emb = clip_model.encode_image(clip_in).float().view([cutn, n, -1])
-        dists = spherical_dist_loss(emb.unsqueeze(0), target_embeds.unsqueeze(0)).view([cutn, n, -1])
-        clip_l = dists.mul(weights).sum(2).mean(0).sum() * clip_guidance_scale
+        # multi-CLIP (BASELINE config 5, a build extension): lists of models / target embeddings, CLIP losses summed; every
+        # tower crops the same boxes and pools them to its own input resolution
+        models = clip_model if isinstance(clip_model, (list, tuple)) else [clip_model]
+        targets = target_embeds if isinstance(target_embeds, (list, tuple)) else [target_embeds]
+        cutters = make_cutouts if isinstance(make_cutouts, (list, tuple)) else [make_cutouts] * len(models)
+        clip_l = 0
+        for ki, (cm, te, mk) in enumerate(zip(models, targets, cutters)):
+            if coords is None and ki > 0:
+                coords_k = cutters[0].last_coords
+            else:
+                coords_k = coords
+            cut = mk(x_in.add(1).div(2), use_cache=cached_cutouts, num_cutouts_override=cutn, coords=coords_k)
+            clip_in = clip_normalize(cut)
+            emb_k = cm.encode_image(clip_in).float().view([cutn, n, -1])
+            dists = spherical_dist_loss(emb_k.unsqueeze(0), te.unsqueeze(0)).view([cutn, n, -1])
+            clip_l = clip_l + dists.mul(weights).sum(2).mean(0).sum() * clip_guidance_scale
+            if ki == 0:
+                emb = emb_k
         range_l = range_loss(out["pred_xstart"]).sum() * range_scale
         tv_l = tv_loss(x_in).sum() * tv_scale
         log["CLIP Loss"], log["Range Loss"], log["TV Loss"] = clip_l.item(), range_l.item(), tv_l.item()

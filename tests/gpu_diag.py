@@ -27,6 +27,8 @@ GROUPS = {
                lambda: pc.check_resnet("x4-tiny", 0, config=(96, 80, (1, 1, 1, 1), 64, 40)),
                lambda: pc.check_resnet("x16-tiny", 1, config=(64, 96, (1, 1, 1, 1), 64, 48)),
                lambda: _sc().check_step("mini", 0, respacing="50", steps=2, B=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32))],
+    "dual": [lambda: _sc().check_step("mini", 1, respacing="50", steps=2, B=2, P=2, dual=True),
+             lambda: _sc().check_step("mini", 0, respacing="50", steps=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32), dual=True)],
     "lpips": [lambda: pc.check_lpips(0), lambda: pc.check_lpips(1),
               lambda: _sc().check_step("mini", 1, respacing="50", steps=2, B=2, init_scale=100.0)],
     "unet64": [lambda: pc.check_unet("cfg64", 0), lambda: pc.check_unet("cfg64", 1), lambda: pc.check_unet("cfg64", 2)],

@@ -20,7 +20,7 @@ def make_tape(B, H, W, nsteps, num_classes, cutn, cut_size, cut_pow=1.0, seed=0)
 
 def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_cfg=(64, 16, 128, 2, 2, 64), P=1, hw=None,
                respacing="50", schedule="linear", use_magnitude=False, sat_scale=0.0, scales=(1000.0, 150.0, 50.0), skip=0,
-               weights=None, init_scale=0.0, rn_cfg=None):
+               weights=None, init_scale=0.0, rn_cfg=None, dual=False):
     from cgd_amd import diffusion as dd
     from cgd_amd import guidance as dg
     from cgd_amd import lib, nets, sampler
@@ -48,6 +48,18 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
     for p in ref_clip.parameters():
         p.requires_grad_(False)
     dev_clip.load_clip_state_dict({k: v.to(DEV) for k, v in ref_clip.state_dict().items() if "num_batches_tracked" not in k})
+    # dual-CLIP (BASELINE config 5, build extension): a second, ViT tower with its own embedding width
+    ref_clip2 = dev_clip2 = None
+    if dual:
+        cfg2 = (32, 8, 64, 1, 1, 48)
+        ref_clip2 = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
+        th.nn.Module.__init__(ref_clip2)
+        ref_clip2.visual = ocv.VisionTransformer(*cfg2)
+        ocv.synthetic_init_(ref_clip2, seed=999).eval()
+        for p in ref_clip2.parameters():
+            p.requires_grad_(False)
+        dev_clip2 = nets.ClipImageTower(ctx, config=cfg2)
+        dev_clip2.load_clip_state_dict({k: v.to(DEV) for k, v in ref_clip2.state_dict().items()})
 
     spec = ("ddim" + respacing) if ddim else respacing
     rescale = False
@@ -57,6 +69,7 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
     N = o_diff.num_timesteps
     tape = make_tape(B, H, W, steps, kw.get("num_classes"), cutn, res)
     targets = th.randn(P, outd, generator=g(80))
+    targets2 = th.randn(P, 48, generator=g(81)) if dual else None
     w = th.tensor(weights if weights is not None else [1.0, 0.5, -0.3][:P])
     w = w / w.sum().abs()
     cgs, tvs, rs = scales
@@ -73,7 +86,10 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
 
     # ---- oracle ----
     mk = og.MakeCutouts(res, cutn)
-    o_cond, o_state = og.make_cond_fn(diffusion=o_diff, clip_model=ref_clip, make_cutouts=mk, target_embeds=targets, weights=w,
+    o_models = [ref_clip, ref_clip2] if dual else ref_clip
+    o_targets = [targets, targets2] if dual else targets
+    o_cutters = [mk, og.MakeCutouts(32, cutn)] if dual else mk
+    o_cond, o_state = og.make_cond_fn(diffusion=o_diff, clip_model=o_models, make_cutouts=o_cutters, target_embeds=o_targets, weights=w,
                                       num_cutouts=cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs, sat_scale=sat_scale,
                                       use_magnitude=use_magnitude, coords_tape=tape["coords"], lpips_model=o_lp, init_tensor=init_cpu,
                                       init_scale=init_scale)
@@ -90,7 +106,9 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
         o_out.append((out["sample"].clone(), out["pred_xstart"].clone(), dict(o_state["log"])))
 
     # ---- device ----
-    guid = dg.ClipGuidance(ctx, dev_unet, dev_clip, smp, targets.to(DEV), w, cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs,
+    d_towers = [dev_clip, dev_clip2] if dual else dev_clip
+    d_targets = [targets.to(DEV), targets2.to(DEV)] if dual else targets.to(DEV)
+    guid = dg.ClipGuidance(ctx, dev_unet, d_towers, smp, d_targets, w, cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs,
                            sat_scale=sat_scale, use_magnitude=use_magnitude, lpips=d_lp,
                            init_tensor=None if init_cpu is None else init_cpu.to(DEV), init_scale=init_scale)
     guid.coords_tape = tape["coords"]

@@ -50,6 +50,12 @@ def test_guided_steps_with_resnet_clip_tower():
     _assert_all(sc.check_step("mini", 0, respacing="50", steps=2, B=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32)))
 
 
+def test_dual_clip_towers_sum_their_losses():
+    # BASELINE config 5 (build extension): a ResNet and a ViT tower guide together; same boxes, prompt weights and scale
+    _assert_all(sc.check_step("mini", 0, respacing="50", steps=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32), dual=True))
+    _assert_all(sc.check_step("mini", 1, respacing="50", steps=2, B=2, P=2, dual=True))
+
+
 def test_dropin_generator_yields_batch_idx_path(tmp_path, monkeypatch):
     """reference test.py:159-168 (yield order for batch_size=2) and :139-143 (first item not None), on synthetic weights."""
     monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
@@ -85,7 +91,8 @@ def test_dropin_generator_with_init_image_and_lpips(tmp_path, monkeypatch):
 
 
 def test_dropin_generator_with_rn50_tower(tmp_path, monkeypatch):
-    """clip_model_name='RN50' (reference clip_util.py:17) through the drop-in generator on synthetic weights."""
+    """clip_model_name='RN50' (reference clip_util.py:17) plus a second tower ("A+B" multi-CLIP extension) through the drop-in
+    generator on synthetic weights."""
     monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.chdir(tmp_path)
     from cgd import clip_util
@@ -93,7 +100,7 @@ def test_dropin_generator_with_rn50_tower(tmp_path, monkeypatch):
     from cgd.cgd import clip_guided_diffusion
     gen = clip_guided_diffusion(prompts=["Loose seal."], image_size=64, batch_size=1, num_cutouts=2, timestep_respacing="25",
                                 noise_schedule="cosine", prefix_path=str(tmp_path / "out"), checkpoints_dir=str(tmp_path / "ckpt"),
-                                save_frequency=1, progress=False, device="cuda", clip_model_name="RN50")
+                                save_frequency=1, progress=False, device="cuda", clip_model_name="RN50+ViT-B/32")
     b, path = next(gen)
     assert b == 0 and os.path.isfile(path)
     clip_util.load_clip.cache_clear()
