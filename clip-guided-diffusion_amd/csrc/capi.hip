@@ -73,7 +73,7 @@ int cgd_profile(cgd_ctx* ctx, int enable) {
 }
 
 // out[0..2] = igemm_kernel launches (with their split-K reduce): summed time (ms), algorithmic FLOP, launches;
-// out[3..5] = the same for hconv_kernel launches alone.  Resets the records.
+// out[3..5] = the same for hconv2_kernel launches alone.  Resets the records.
 int cgd_profile_read(cgd_ctx* ctx, double* out) {
   CGD_HIP(ctx, hipDeviceSynchronize());
   CGD_TRY(cgd_prof_fold(ctx, 0));

@@ -16,7 +16,7 @@ enum { CGD_PREC_F32 = 0, CGD_PREC_BF16X3 = 1, CGD_PREC_BF16 = 2 };
 struct ProfRec {
   hipEvent_t a, b;
   double flops;
-  int kind;  // 0: igemm_kernel (+ its split-K reduce), 1: hconv_kernel alone (the dominant kernel of the step)
+  int kind;  // 0: igemm_kernel (+ its split-K reduce), 1: hconv2_kernel alone (the dominant kernel of the step)
 };
 
 struct FragEntry {  // fragment-order copy of a persistent weight (hgemm.hip)
