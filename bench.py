@@ -143,12 +143,16 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # CGD_BENCH_DEVICE / CGD_BENCH_BACKEND: test knobs only (exercise the N > 1 flow on a 1-GPU box: every rank on one device, gloo)
+    local = int(os.environ.get("CGD_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     th.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=th.device(dev))
+        if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl":
+            dist.init_process_group("nccl", device_id=th.device(dev))  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(os.environ["CGD_BENCH_BACKEND"])
 
     import cgd_amd  # noqa: F401
     from cgd_amd import lib
