@@ -149,6 +149,14 @@ int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, 
   GemmParams p;
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.force_tile = force_tile; p.splitk = splitk;
+  if (force_tile == 514) {  // micro-benchmarks: weight GEMM kernel with the fragment copy cached by B's pointer (B must persist)
+    p.force_tile = 513;
+    p.weight = 1;
+  }
+  if (splitk < 0) {  // -1: one slice, never split automatically (micro-benchmarks)
+    p.splitk = 1;
+    p.no_split = 1;
+  }
   return cgd_launch_gemm(ctx, p, S(stream));
 }
 int cgd_op_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, void* stream) {

@@ -174,7 +174,10 @@ int cgd_sample_update(cgd_ctx* ctx, const float* x, const float* pred_xstart, co
                       int W, const cgd_step_coef* k, int mode, void* stream);
 
 /* ---- single ops, exported for parity tests and for user-supplied cond_fn plumbing ---- */
-/* C[M][N] = alpha * A[M][K] B[N][K]^T (+bias[N]) (+R[M][N]); conv3x3: A is NHWC (Bn,H,W,Cin), B = [N][9*Cin] */
+/* C[M][N] = alpha * A[M][K] B[N][K]^T (+bias[N]) (+R[M][N]); conv3x3: A is NHWC (Bn,H,W,Cin), B = [N][9*Cin].
+ * force_tile: 0 auto, 64 / 128 / 256 / 257 (+1000: two-deep prefetch) igemm tiles, 513 weight GEMM kernel (B re-packed per call),
+ * 514 the same with the packed copy cached by B's pointer (B must persist; micro-benchmarks).  splitk: >= 1 slices (1 = automatic), -1 = one
+ * slice, never split automatically. */
 int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, const float* R,
                 int ldr, int M, int N, int K, float alpha, int force_tile, int splitk, void* stream);
 /* w_packed: [Cout][9*Cin] fp32 (generic kernel); w_frag (optional): the same weights in MFMA-fragment order, bf16 hi/lo planes,
