@@ -36,8 +36,8 @@ struct cgd_ctx {
   int hconv_var = 0;  // halo conv tile: 0 = 8x16 pixels / 4 wavefronts / two workgroups per CU (default, +0.8 % on the step),
                       // bit 0 = 16x16 / 8 wavefronts everywhere, bit 1 = 16x16 below 16384 pixels
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
-  int hgemm_mode = 1, hgemm_min_m = 2048, hgemm_min_chunks = 3;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it the
-                                                                 // launch is latency-bound and igemm's finer tiles win, gemm_r1ae), chunks per split-K slice
+  int hgemm_mode = 1, hgemm_min_m = 512, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
+                                                                // igemm's finer tiles win), chunks per split-K slice
   std::vector<FragEntry> frag_cache;                           // packed weights, keyed by pointer; cleared by finalize / set_param / destroy
   void* frag_tmp = nullptr;                                    // packed copy of a non-persistent B operand (forced hgemm, tests)
   size_t frag_tmp_bytes = 0;

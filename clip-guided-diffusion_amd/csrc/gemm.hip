@@ -435,7 +435,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     const long tiles = cgd_hgemm_tiles(p);
     const int nch = cgd_hgemm_chunks(p);
     if (auto_split && tiles < ctx->num_cu) {
-      long want = std::min<long>(cdiv(2L * ctx->num_cu, tiles), nch / ctx->hgemm_min_chunks);
+      // about one workgroup per CU and >= hgemm_min_chunks chunks per slice (gemm_r1bb: ViT shapes, M = 800)
+      long want = std::min<long>(ctx->num_cu / tiles, nch / ctx->hgemm_min_chunks);
       while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
       if (want >= 2) p.splitk = (int)want;
     }
