@@ -417,9 +417,12 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     if (p.M % tm) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel needs M to be a multiple of its pixel tile");
     const long tiles = (long)(p.M / tm) * cdiv(p.N, 128);
     const int nchunk = p.Cin / 32;
-    const long slots = (long)ctx->num_cu * (tm == 128 ? 2 : 1);  // resident workgroups (the 128-pixel tile runs two per CU)
+    // split-K target: about one workgroup per CU and >= 4 chunks per slice (sweep r1bc: 2 per CU / 2 chunks 37.3 steps/s,
+    // 1 per CU / 4 chunks 38.0-38.5, 0.75 per CU 38.7, 0.5 per CU 37.9): fewer, longer slices beat filling both resident slots
+    const long slots = ctx->num_cu;
+    const int min_ch = 4;
     if (auto_split && tiles < slots) {
-      long want = std::min<long>(cdiv(slots, tiles), nchunk / 2);
+      long want = std::min<long>(cdiv(slots, tiles), nchunk / min_ch);
       while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
       if (want >= 2) p.splitk = (int)want;
     }
