@@ -34,7 +34,9 @@ struct cgd_ctx {
   int num_cu = 256;
   int tile_huge = 1256, tile_large = 128, tile_small = 64;  // GEMM tile codes of the automatic selection (gemm.hip)
   int hconv_var = 0;  // halo conv tile: 0 = 8x16 pixels / 4 wavefronts / two workgroups per CU (default, +0.8 % on the step),
-                      // bit 0 = 16x16 / 8 wavefronts everywhere, bit 1 = 16x16 below 16384 pixels
+                      // bit 0 = 16x16 / 8 wavefronts everywhere, bit 1 = 16x16 below 16384 pixels, bit 2 = wavefront sub-tile
+                      // 64 pixels x 64 channels instead of 128 x 32 (the kernel is power-limited: 128 x 32 moves half of the
+                      // fragment traffic from the vector-memory path to the LDS, +1.2..1.8 % per layer at the 1.36 kW cap)
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   int hgemm_mode = 1, hgemm_min_m = 512, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
                                                                 // igemm's finer tiles win), chunks per split-K slice

@@ -55,7 +55,7 @@ struct HConvParams {
 //   * tile = TH x 16 pixels (TH = 16: 8 wavefronts / 512 threads; TH = 8: 4 wavefronts / 256 threads, two workgroups per CU,
 //     whose barrier and load stalls are uncorrelated); the halo patch is (TH+2) x 18 rows (1.27x / 1.41x the tile, against
 //     3.0x for a 256-wide row segment), 6 staging passes instead of 13;
-//   * the patch is DOUBLE-buffered in LDS (103,680 / 57,600 B): chunk c+1 is loaded at the start of chunk c, converted and
+//   * the patch is DOUBLE-buffered in LDS (110,592 / 61,440 B): chunk c+1 is loaded at the start of chunk c, converted and
 //     written into the other buffer in the middle of chunk c's taps (VALU/LDS work hidden under MFMA), ONE barrier per chunk;
 //   * explicit register software pipeline over the 18 k-steps of a chunk: A fragments (ds_read_b128) one k-step ahead,
 //     B fragments (global -> registers) several k-steps ahead in a register ring whose depth divides 18 (chunk-periodic,
@@ -65,22 +65,31 @@ struct HConvParams {
 //     pattern), so a wavefront's own MFMA queue never drains;
 //   * MFMA operands are swapped (D = W_frag x X_frag^T): a lane then owns 4 consecutive output CHANNELS of one pixel per
 //     accumulator quad, so residual loads and output stores are 16-byte accesses along the NHWC channel axis.
+//   * wave -> sub-tile mapping NJ: NJ = 2: 64 pixels x 64 channels per wavefront (2 x 2 MFMA blocks: per k-step 4 LDS reads and
+//     4 global fragment loads); NJ = 1: 128 pixels x 32 channels (4 x 1 blocks: 8 LDS reads, 2 global loads).  The PMC passes
+//     of profiles/r1_pmc_hconv2_before.txt show the texture path (TA/TD) 78-86 % busy with NJ = 2 against 69 % for the MFMA pipe and
+//     27 % for the LDS: NJ = 1 moves half of the fragment traffic from the vector-memory path to the LDS;
+//   * LDS patch layout: pixel pitch 80 B, patch-ROW pitch 1536 B (18 pixels = 1440 B, padded to a multiple of 256 B): a
+//     32-pixel MFMA block spans two tile rows, and with the unpadded row pitch lanes 12,13 / 28,29 (and 4,5 / 20,21) of each
+//     ds_read_b128 lane group hit the same banks (SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE before the padding).
 constexpr int PW2 = 18;     // patch width: 16 + 2
+constexpr int HRS = 768;    // LDS pitch of a patch row (bf16 elements)
 constexpr int NPASS2 = 6;   // staging passes (both tile heights)
 
-template <int MODE, int TH>
+template <int MODE, int TH, int NJ>
 __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                          const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                          const HConvParams p) {
   constexpr int NPL = MODE == 1 ? 2 : 1;   // bf16 planes (hi, lo)
   constexpr int NP2 = (TH + 2) * PW2;      // patch rows: 324 / 180
-  constexpr int PLANE = NP2 * HPH;         // elements per plane
+  constexpr int PLANE = (TH + 2) * HRS;    // elements per plane
+  constexpr int NI = 4 / NJ;               // 32-pixel blocks per wavefront (NI x NJ = 4 MFMA blocks)
   constexpr int NT = TH * 32;              // threads
   constexpr int RPP = NT / 8;              // patch rows per staging pass
   static_assert(NPASS2 * RPP >= NP2, "staging passes must cover the patch");
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NJ == 2 ? wave >> 1 : wave >> 2, wn = NJ == 2 ? wave & 1 : wave & 3;  // pixel group, channel group
   const int l31 = lane & 31, hh = lane >> 5;
 
   const int ntn = (p.N + HB_N - 1) / HB_N;
@@ -99,13 +108,16 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
 
   // per-thread patch staging slots: RPP patch rows per pass, 8 float4 per row
   const int c4 = tid & 7;
-  int poff[NPASS2];
+  int poff[NPASS2], soff[NPASS2];  // global offset, LDS offset
 #pragma unroll
   for (int j = 0; j < NPASS2; ++j) {
     const int prow = (tid >> 3) + RPP * j;
-    poff[j] = -2;  // beyond the patch
+    poff[j] = -2;  // beyond the patch (last pass only): such a thread stores zeros into the unused tail of LDS patch row 0, which
+    soff[j] = PW2 * HPH + c4 * 4;  // keeps the store unconditional (a skipped store leaves the load pending at the loop back
+                                   // edge in the compiler's wait-count model and costs a vmcnt(0) drain of the fragment ring)
     if (prow < NP2) {
       const int py = prow / PW2, px = prow - py * PW2;
+      soff[j] = py * HRS + px * HPH + c4 * 4;
       int yy = y0 + py - 1, xx = x0 + px - 1;
       const bool inb = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
       if (p.ups) {
@@ -115,14 +127,14 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
       poff[j] = inb ? (yy * Ws + xx) * p.lda + c4 * 4 : -1;  // -1: zero padding
     }
   }
-  // this lane's two pixels (one per 32-pixel block of the wavefront's 64): patch row and output row
-  int fro[2];
-  long mrow[2];
+  // this lane's pixels (one per 32-pixel block of the wavefront's NI): patch position and output row
+  int fro[NI];
+  long mrow[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pix = wm * 64 + i * 32 + l31;
+  for (int i = 0; i < NI; ++i) {
+    const int pix = wm * (NI * 32) + i * 32 + l31;
     const int ty = pix >> 4, tx = pix & 15;
-    fro[i] = (ty * PW2 + tx) * HPH + hh * 8;
+    fro[i] = ty * HRS + tx * HPH + hh * 8;
     mrow[i] = (long)img * HW + (long)(y0 + ty) * p.W + x0 + tx;
   }
 
@@ -133,18 +145,18 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     c0 = blockIdx.z * per;
     c1 = min(nchunk, c0 + per);
   }
-  const int nb0 = (n0 + wn * 64) >> 5;
+  const int nb0 = (n0 >> 5) + wn * NJ;
   const int nbN = p.N >> 5;
   const long bstride_nb = (long)nchunk * 9 * 4 * 64;
   const int nbc = nb0 < nbN ? nb0 : nbN - 1;  // clamped first block
   const long bj1 = (nb0 + 1 < nbN) ? bstride_nb : 0;
   const uint4* __restrict__ Bw0 = Bg + (long)nbc * bstride_nb + lane;
 
-  f32x16 acc[2][2];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -160,20 +172,17 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
 #define PATCH_STORE2(DSTB, J0, J1)                                                                  \
   {                                                                                                 \
     _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                               \
-      if (j < NPASS2 - 1 || poff[j] != -2) { /* only the last pass has rows beyond the patch */     \
-        const int prow = (tid >> 3) + RPP * j;                                                      \
-        const f32x4 v = poff[j] >= 0 ? pr[j] : z4;                                                  \
-        const bf16x4 hi = to_bf16x4(v);                                                             \
-        *(bf16x4*)&(DSTB)[prow * HPH + c4 * 4] = hi;                                                \
-        if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + prow * HPH + c4 * 4] = to_bf16x4(residual4(v, hi)); \
-      }                                                                                             \
+      const f32x4 v = poff[j] >= 0 ? pr[j] : z4;                                                    \
+      const bf16x4 hi = to_bf16x4(v);                                                               \
+      *(bf16x4*)&(DSTB)[soff[j]] = hi;                                                              \
+      if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + soff[j]] = to_bf16x4(residual4(v, hi));    \
     }                                                                                               \
   }
   // A fragments of k-step (TAP, KS): [pixel block i][plane]
 #define A_LOAD2(DST, SRCB, TAP, KS)                                                                 \
   {                                                                                                 \
-    constexpr int o_ = (((TAP) / 3) * PW2 + ((TAP) % 3)) * HPH + (KS) * 16;                         \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+    constexpr int o_ = ((TAP) / 3) * HRS + ((TAP) % 3) * HPH + (KS) * 16;                           \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                \
       DST[i][0] = *(const bf16x8*)&(SRCB)[fro[i] + o_];                                             \
       if constexpr (MODE == 1) DST[i][1] = *(const bf16x8*)&(SRCB)[PLANE + fro[i] + o_];            \
     }                                                                                               \
@@ -184,19 +193,21 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     const uint4* bp_ = (BASE) + ((TAP) * 4 + (KS) * 2) * 64;                                        \
     DST[0][0] = bp_[0];                                                                             \
     if constexpr (MODE == 1) DST[0][1] = bp_[64];                                                   \
-    DST[1][0] = bp_[bj1];                                                                           \
-    if constexpr (MODE == 1) DST[1][1] = bp_[bj1 + 64];                                             \
+    if constexpr (NJ == 2) {                                                                        \
+      DST[1][0] = bp_[bj1];                                                                         \
+      if constexpr (MODE == 1) DST[1][1] = bp_[bj1 + 64];                                           \
+    }                                                                                               \
   }
   // 12 MFMAs of one k-step; product-major so that the same accumulator recurs only every 4th instruction
 #define MFMA12(AQ, BQ)                                                                              \
   {                                                                                                 \
     if constexpr (MODE == 1) {                                                                      \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)   \
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[j][0]), AQ[i][1], acc[i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)   \
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[j][1]), AQ[i][0], acc[i][j], 0, 0, 0); \
     }                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)     \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)   \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[j][0]), AQ[i][0], acc[i][j], 0, 0, 0); \
   }
 
@@ -204,9 +215,9 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
   // a k-step is compile-time and the ring runs across chunk boundaries without a drain.  The 4-wavefront tile has the
   // registers for 6 slots (5 k-steps ~ 2 us of slack: covers the patch loads queued in front of the B loads in the in-order
   // vmcnt counter); the 8-wavefront tile spills beyond 3.
-  constexpr int RING = TH == 8 ? 6 : 3, DIST = RING - 1;
-  bf16x8 af[2][2][NPL];     // [pipeline slot][pixel block][plane]
-  uint4 bq[RING][2][NPL];   // [ring slot][channel block][plane]
+  constexpr int RING = (TH == 8 || NJ == 1) ? 6 : 3, DIST = RING - 1;
+  bf16x8 af[2][NI][NPL];     // [pipeline slot][pixel block][plane]
+  uint4 bq[RING][NJ][NPL];   // [ring slot][channel block][plane]
   if (c0 < c1) {
     PATCH_LOAD2(c0);
     const uint4* __restrict__ cb = Bw0 + (long)c0 * (9 * 4 * 64);
@@ -221,7 +232,8 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     __bf16* nxt = lds + (((c - c0) & 1) ^ 1) * (NPL * PLANE);
     const uint4* __restrict__ cb = Bw0 + (long)c * (9 * 4 * 64);
     const uint4* __restrict__ nb = Bw0 + (long)(c + 1 < nchunk ? c + 1 : c) * (9 * 4 * 64);  // clamped: loads stay unconditional
-    if (more) PATCH_LOAD2(c + 1);  // in flight during the first taps
+    PATCH_LOAD2(more ? c + 1 : c);  // in flight during the first taps; unconditional (the last chunk re-reads its own patch): a
+                                    // branch here makes the wait counts of the first k-step conservative (fragment ring drained)
     A_LOAD2(af[0], cur, 0, 0);
 #pragma unroll
     for (int q = 0; q < 18; ++q) {
@@ -245,11 +257,16 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
       if (q >= 6 && q <= 11) PATCH_STORE2(nxt, q - 6, q - 5);
 #pragma unroll
       for (int r = 0; r < 12; ++r) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
-        if (r % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-        if (r % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                  // VALU
-        if (r % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        if constexpr (NJ == 2) {
+          if (r % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read (4 per k-step)
+          if (r % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (4)
+        } else {
+          if (r % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read (8 per k-step)
+          if (r % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (2)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                    // VALU
+        if (r % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -266,10 +283,10 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
   if (p.splitk > 1) {
     float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int cb0 = n0 + wn * 64 + j * 32;
+      for (int j = 0; j < NJ; ++j) {
+        const int cb0 = (nb0 + j) * 32;
         if (cb0 < p.N) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
@@ -280,10 +297,10 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int cb0 = n0 + wn * 64 + j * 32;
+    for (int j = 0; j < NJ; ++j) {
+      const int cb0 = (nb0 + j) * 32;
       if (cb0 >= p.N) continue;
       f32x4 rv[4];
       if (Rg) {
@@ -366,18 +383,22 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   const int tm = cgd_hconv_tile_m(ctx, g);
   dim3 grid((g.M / tm) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
-#define HC2_LAUNCH(M_, TH_) hipLaunchKernelGGL((hconv2_kernel<M_, TH_>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
-  if (ctx->precision == CGD_PREC_BF16X3) {
-    if (tm == 128)
-      HC2_LAUNCH(1, 8);
-    else
-      HC2_LAUNCH(1, 16);
-  } else {
-    if (tm == 128)
-      HC2_LAUNCH(2, 8);
-    else
-      HC2_LAUNCH(2, 16);
+#define HC2_LAUNCH(M_, TH_, NJ_) \
+  hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
+#define HC2_LAUNCH_T(M_, NJ_)  \
+  {                            \
+    if (tm == 128)             \
+      HC2_LAUNCH(M_, 8, NJ_);  \
+    else                       \
+      HC2_LAUNCH(M_, 16, NJ_); \
   }
+  const bool nj1 = (ctx->hconv_var & 4) == 0;  // wave -> sub-tile mapping (kernel header): 128 pixels x 32 channels unless bit 2
+  if (ctx->precision == CGD_PREC_BF16X3) {
+    if (nj1) HC2_LAUNCH_T(1, 1) else HC2_LAUNCH_T(1, 2)
+  } else {
+    if (nj1) HC2_LAUNCH_T(2, 1) else HC2_LAUNCH_T(2, 2)
+  }
+#undef HC2_LAUNCH_T
 #undef HC2_LAUNCH
   return 0;
 }

@@ -185,7 +185,8 @@ int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, 
  * halo-staged kernel (force_tile 512 or automatic for large images) */
 int cgd_op_pack_conv3x3_frag(cgd_ctx* ctx, const float* w_torch, float* out /* Co*Ci*9 floats of storage */, int Co, int Ci, int dgrad,
                              void* stream);
-/* tuning knob: mode & 15 = 0 off / 1 auto (M >= min_m); mode >> 4 = tile variant (0: 8x16 pixels, 1: 16x16, 2: 16x16 below 16384 pixels) */
+/* tuning knob: mode & 15 = 0 off / 1 auto (M >= min_m); mode >> 4 = tile variant bits (0: 8x16 pixels, 1: 16x16, 2: 16x16 below 16384
+ * pixels, 4: wavefront sub-tile 64 pixels x 64 channels instead of the default 128 x 32) */
 int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m);
 int cgd_op_conv3x3(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_packed, const float* w_frag, float* y_nhwc, int ldy,
                    const float* bias, const float* R, int ldr, int Bn, int H, int W, int Cin, int Cout, int upsample_input, int force_tile,

@@ -19,7 +19,7 @@ SHAPES_ALL = [  # (H=W, Cin, Cout, launches per step in config 2 (fwd+dgrad, app
     (8, 1024, 1024, 18), (8, 2048, 1024, 3), (8, 1024, 2048, 3),
 ]
 SHAPES = SHAPES_ALL
-TILES = [128, 5121, 5120]  # igemm 128x128 | hconv2 16x16 tiles | hconv2 8x16 tiles (2 workgroups / CU)  # 512x = halo-staged conv kernel, tile variant x
+TILES = [int(t) for t in os.environ["CGD_BENCH_TILES"].split(",")] if os.environ.get("CGD_BENCH_TILES") else [128, 5121, 5120]  # igemm 128x128 | hconv2 16x16 tiles | hconv2 8x16 tiles (2 workgroups / CU)  # 512x = halo-staged conv kernel, tile variant x
 
 
 def main():
@@ -71,7 +71,7 @@ def main():
     # best-per-shape projection
     tot_best = sum(min([v for v in r["us"].values() if v] or [0]) * r["count"] for r in res)
     tot_cur = sum((r["us"].get("1256") or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
-    for code in ("5121", "5120"):
+    for code in [str(t) for t in TILES if t >= 5120]:
         tot_h = sum((r["us"].get(code) or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
         print(f"halo conv kernel {code} wherever supported: {tot_h / 1e3:.2f} ms")
     print(f"projected conv time/step: default-ish {tot_cur / 1e3:.2f} ms, best-per-shape {tot_best / 1e3:.2f} ms")

@@ -100,8 +100,9 @@ def check_conv(precision):
             out.append(rec(f"conv3x3 dgrad[p{precision}] {Ci}<-{Co}", got.permute(0, 3, 1, 2), xr.grad.float()))
     # halo-staged conv kernel (tile code 512): fragment-packed bf16 weights, patch staging, split-K over channel chunks
     if precision != 0:
-        # hconv2_kernel tile variants: 0 = 8x16 pixels (4 wavefronts, default), 1 = 16x16 pixels (8 wavefronts)
-        for var in (0, 1):
+        # hconv2_kernel variants: bit 0: 0 = 8x16-pixel tile (4 wavefronts), 1 = 16x16 pixels (8 wavefronts);
+        # bit 2: wavefront sub-tile 0 = 128 pixels x 32 channels (default), 1 = 64 pixels x 64 channels
+        for var in (0, 1, 4, 5):
             ctx.check(ctx.lib.cgd_set_hconv(ctx.h, 1 + 16 * var, 256))
             for (Bn, H, W, Ci, Co, ups, sk) in [(1, 256, 256, 32, 64, 0, 1), (2, 16, 16, 64, 160, 0, 1), (1, 32, 32, 128, 128, 0, 2),
                                                 (1, 64, 64, 64, 96, 1, 1), (1, 128, 128, 32, 32, 0, 1), (1, 16, 32, 64, 64, 0, 1),
