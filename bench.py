@@ -214,6 +214,12 @@ def main():
                 "other_mfma_kernel": {"kernel": "igemm_kernel / hgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / args.steps,
                                       "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
                                       "kernel_time_share": round(ig_ms * 1e-3 / dt, 4)}}
+        if h_n == 0:  # exact-fp32 mode: the halo kernel is bf16-only, every contraction runs in igemm_kernel on v_mfma_f32_32x32x2_f32
+            ach = ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12
+            roof = {"bound": "mfma", "kernel": "igemm_kernel<f32> (implicit GEMM, gemm.hip)", "achieved": round(ach, 2), "peak": 157.3,
+                    "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None, "launches_per_step": ig_n / args.steps,
+                    "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2), "flop_per_launch": ig_flop / max(ig_n, 1),
+                    "kernel_time_share": round(ig_ms * 1e-3 / dt, 4), "mfma_products_per_flop": 1, "mfma_issue_frac": round(ach / 157.3, 4)}
     assert th.isfinite(out["sample"]).all().item(), "non-finite sample"
     tmax = th.tensor([dt], device=dev, dtype=th.float64)
     if world > 1:
