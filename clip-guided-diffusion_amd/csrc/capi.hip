@@ -41,19 +41,29 @@ void cgd_ctx_destroy(cgd_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   cgd_frag_cache_clear(ctx);
   if (ctx->frag_tmp) (void)hipFree(ctx->frag_tmp);
+  for (ProfRec& r : ctx->prof_recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   delete ctx;
 }
 
 const char* cgd_last_error(cgd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+#define CGD_NEED_CTX(ctx) \
+  if (!(ctx)) return -3
+
 int cgd_set_precision(cgd_ctx* ctx, int mode) {
+  CGD_NEED_CTX(ctx);
   if (mode < 0 || mode > 2) CGD_FAIL(ctx, "precision mode must be 0 (f32), 1 (bf16x3) or 2 (bf16)");
   ctx->precision = mode;
   return 0;
 }
-int cgd_get_precision(cgd_ctx* ctx) { return ctx->precision; }
+int cgd_get_precision(cgd_ctx* ctx) { return ctx ? ctx->precision : -3; }
 
 int cgd_set_tiles(cgd_ctx* ctx, int large, int small) {
+  CGD_NEED_CTX(ctx);
   ctx->tile_huge = large >= 1000000 ? large / 1000000 : ctx->tile_huge;  // optional: huge*1e6 + large
   ctx->tile_large = large % 1000000;
   ctx->tile_small = small;
@@ -61,6 +71,7 @@ int cgd_set_tiles(cgd_ctx* ctx, int large, int small) {
 }
 
 int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks) {
+  CGD_NEED_CTX(ctx);
   ctx->hgemm_mode = mode;
   if (min_m > 0) ctx->hgemm_min_m = min_m;
   if (min_chunks > 0) ctx->hgemm_min_chunks = min_chunks;
@@ -68,6 +79,7 @@ int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks) {
 }
 
 int cgd_profile(cgd_ctx* ctx, int enable) {
+  CGD_NEED_CTX(ctx);
   ctx->prof_on = enable != 0;
   return 0;
 }
@@ -75,6 +87,8 @@ int cgd_profile(cgd_ctx* ctx, int enable) {
 // out[0..2] = igemm_kernel launches (with their split-K reduce): summed time (ms), algorithmic FLOP, launches;
 // out[3..5] = the same for hconv2_kernel launches alone.  Resets the records.
 int cgd_profile_read(cgd_ctx* ctx, double* out) {
+  CGD_NEED_CTX(ctx);
+  if (!out) CGD_FAIL(ctx, "cgd_profile_read: out is null");
   CGD_HIP(ctx, hipDeviceSynchronize());
   CGD_TRY(cgd_prof_fold(ctx, 0));
   for (int k = 0; k < 2; ++k) {
@@ -88,6 +102,7 @@ int cgd_profile_read(cgd_ctx* ctx, double* out) {
 }  // extern "C"
 
 int cgd_prof_fold(cgd_ctx* ctx, size_t keep_last) {
+  CGD_NEED_CTX(ctx);
   if (ctx->prof_recs.size() <= keep_last) return 0;
   const size_t n = ctx->prof_recs.size() - keep_last;
   for (size_t i = 0; i < n; ++i) {
@@ -109,43 +124,52 @@ extern "C" {
 
 int cgd_cutouts_fwd(cgd_ctx* ctx, const float* x_in, const int32_t* coords, float* out, int B, int H, int W, int cutn, int cut_size,
                     int layout, int patch, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_cutouts_fwd(ctx, x_in, coords, out, B, H, W, cutn, cut_size, layout, patch, S(stream));
 }
 int cgd_cutouts_bwd(cgd_ctx* ctx, const float* d_out, const int32_t* coords, float* g_in, int B, int H, int W, int cutn, int cut_size,
                     int layout, int patch, int accumulate, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_cutouts_bwd(ctx, d_out, coords, g_in, B, H, W, cutn, cut_size, layout, patch, accumulate, S(stream));
 }
 int cgd_spherical_loss(cgd_ctx* ctx, const float* emb, const float* targets_n, const float* weights, float* d_emb, float* loss_part,
                        int cutn, int B, int P, int D, float scale, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_spherical_loss(ctx, emb, targets_n, weights, d_emb, loss_part, cutn, B, P, D, scale, S(stream));
 }
 int cgd_pmv_blend(cgd_ctx* ctx, const float* x, const float* out6, float* x0, float* mean, float* logvar, float* xin, int B, int H, int W,
                   const cgd_step_coef* k, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_pmv_blend(ctx, x, out6, x0, mean, logvar, xin, B, H, W, *k, S(stream));
 }
 int cgd_guidance_combine(cgd_ctx* ctx, const float* g_clip_in, const float* x_in, const float* x0, float* g_direct, float* seed6,
                          float* loss_part, int B, int H, int W, const cgd_step_coef* k, float tv_scale, float range_scale,
                          float sat_scale, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_guidance_combine(ctx, g_clip_in, x_in, x0, g_direct, seed6, loss_part, B, H, W, *k, tv_scale, range_scale, sat_scale,
                                      S(stream));
 }
 int cgd_grad_finish(cgd_ctx* ctx, const float* g_direct, const float* g_unet, float* g, float* g_part, int B, int H, int W,
                     void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_grad_finish(ctx, g_direct, g_unet, g, g_part, B, H, W, S(stream));
 }
 int cgd_scalars(cgd_ctx* ctx, const float* clip_part, int n_clip, const float* loss_part, const float* g_part, int B, int H, int W,
                 int use_magnitude, float* scalars, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_scalars(ctx, clip_part, n_clip, loss_part, g_part, B, H, W, use_magnitude, scalars, S(stream));
 }
 int cgd_sample_update(cgd_ctx* ctx, const float* x, const float* x0, const float* mean, const float* logvar, const float* g,
                       const float* noise, const float* scalars, float* sample, float* x0_out, int B, int H, int W,
                       const cgd_step_coef* k, int mode, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_sample_update(ctx, x, x0, mean, logvar, g, noise, scalars, sample, x0_out, B, H, W, *k, mode, S(stream));
 }
 
 // ---- single ops -------------------------------------------------------------------------------------------------
 int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, const float* R,
                 int ldr, int M, int N, int K, float alpha, int force_tile, int splitk, void* stream) {
+  CGD_NEED_CTX(ctx);
   GemmParams p;
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.force_tile = force_tile; p.splitk = splitk;
@@ -160,9 +184,11 @@ int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, 
   return cgd_launch_gemm(ctx, p, S(stream));
 }
 int cgd_op_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_pack_conv3x3_frag(ctx, w, out, Co, Ci, dgrad, S(stream));
 }
 int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m) {
+  CGD_NEED_CTX(ctx);
   ctx->hconv_mode = mode & 15;
   ctx->hconv_var = mode >> 4;
   ctx->hconv_min_m = min_m;
@@ -170,6 +196,7 @@ int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m) {
 }
 int cgd_op_conv3x3(cgd_ctx* ctx, const float* x, int ldx, const float* w, const float* w_frag, float* y, int ldy, const float* bias,
                    const float* R, int ldr, int Bn, int H, int W, int Cin, int Cout, int ups, int force_tile, int splitk, void* stream) {
+  CGD_NEED_CTX(ctx);
   GemmParams p;
   p.Bpk = w_frag;
   p.A = x; p.lda = ldx; p.B = w; p.ldb = 9 * Cin; p.C = y; p.ldc = ldy; p.bias = bias; p.R = R; p.ldr = ldr;
@@ -178,36 +205,45 @@ int cgd_op_conv3x3(cgd_ctx* ctx, const float* x, int ldx, const float* w, const 
 }
 int cgd_op_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int Bn, int H, int W, int Cin, int Cout,
                    void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_conv_in(ctx, x, w, bias, y, Bn, H, W, Cin, Cout, S(stream));
 }
 int cgd_op_conv_thin_out(cgd_ctx* ctx, const float* x, int ldx, const float* w, const float* bias, float* y, int Bn, int H, int W,
                          int Cin, int Cout, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_conv_thin_out(ctx, x, ldx, w, bias, y, Bn, H, W, Cin, Cout, S(stream));
 }
 int64_t cgd_op_gn_scratch_floats(int B, int HW, int C) { return (int64_t)cgd_gn_scratch_floats(B, HW, C); }
 int cgd_op_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma, const float* beta,
                   const float* film, int act, float eps, float* scratch, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_gn_fwd(ctx, x, ldx, y, ldy, B, HW, C, gamma, beta, film, 2 * C, act, eps, scratch, S(stream));
 }
 int cgd_op_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add, int ldadd,
                   int B, int HW, int C, int act, float* scratch, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_gn_bwd(ctx, x, ldx, dz, lddz, dx, lddx, add, ldadd, B, HW, C, act, scratch, S(stream));
 }
 int cgd_op_ln_fwd(cgd_ctx* ctx, const float* x, float* y, int rows, int C, const float* gamma, const float* beta, float eps, float* stats,
                   void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_ln_fwd(ctx, x, C, y, C, rows, C, gamma, beta, eps, stats, S(stream));
 }
 int cgd_op_ln_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx, int rows, int C, const float* gamma, const float* stats,
                   void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_ln_bwd(ctx, x, C, dy, C, dx, C, nullptr, 0, rows, C, gamma, stats, S(stream));
 }
 int cgd_op_pool2x2(cgd_ctx* ctx, const float* in, float* out, int B, int Ho, int Wo, int C, float scale, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_pool2x2(ctx, in, C, out, C, nullptr, 0, B, Ho, Wo, C, scale, S(stream));
 }
 int cgd_op_upsample2x(cgd_ctx* ctx, const float* in, float* out, int B, int Ho, int Wo, int C, float scale, void* stream) {
+  CGD_NEED_CTX(ctx);
   return cgd_launch_upsample2x(ctx, in, C, out, C, nullptr, 0, B, Ho, Wo, C, scale, S(stream));
 }
 int cgd_op_act(cgd_ctx* ctx, const float* x, const float* dy, float* out, int64_t n, int act, void* stream) {
+  CGD_NEED_CTX(ctx);
   if (dy) return cgd_launch_act_bwd(ctx, x, dy, out, n, act, S(stream));
   return cgd_launch_act_fwd(ctx, x, out, n, act, S(stream));
 }
@@ -222,12 +258,14 @@ int64_t cgd_op_attn_buf_floats(int nb, int heads, int T, int d, int which) {
 }
 int cgd_op_attn_fwd(cgd_ctx* ctx, const float* qkv, float* out, int nb, int heads, int T, int d, int legacy, float* bufs[5],
                     void* stream) {
+  CGD_NEED_CTX(ctx);
   AttnShape sh{nb, heads, T, d, heads * d, legacy};
   AttnBufs bf{bufs[0], bufs[1], bufs[2], bufs[3], bufs[4]};
   return cgd_attn_fwd(ctx, sh, qkv, 3 * heads * d, out, heads * d, bf, S(stream));
 }
 int cgd_op_attn_bwd(cgd_ctx* ctx, const float* qkv, const float* dout, float* dqkv, int nb, int heads, int T, int d, int legacy,
                     float* bufs[5], void* stream) {
+  CGD_NEED_CTX(ctx);
   AttnShape sh{nb, heads, T, d, heads * d, legacy};
   AttnBufs bf{bufs[0], bufs[1], bufs[2], bufs[3], bufs[4]};
   return cgd_attn_bwd(ctx, sh, qkv, 3 * heads * d, dout, heads * d, dqkv, 3 * heads * d, bf, S(stream));

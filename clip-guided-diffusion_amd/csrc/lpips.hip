@@ -401,19 +401,31 @@ int cgd_lpips_create(cgd_ctx* ctx, cgd_lpips** out) {
   return 0;
 }
 void cgd_lpips_destroy(cgd_lpips* v) { delete v; }
-int cgd_lpips_num_params(cgd_lpips* v) { return (int)v->net.params.size(); }
+int cgd_lpips_num_params(cgd_lpips* v) {
+  if (!v) return -3;
+  return (int)v->net.params.size();
+}
 int cgd_lpips_param_info(cgd_lpips* v, int i, char* buf, int len, int64_t* numel) {
+  if (!v) return -3;
   if (i < 0 || i >= (int)v->net.params.size()) return -1;
   snprintf(buf, len, "%s", v->net.params[i].name.c_str());
   if (numel) *numel = v->net.params[i].numel;
   return 0;
 }
-int cgd_lpips_set_param(cgd_lpips* v, const char* name, const float* data, int64_t numel) { return v->net.set_param(name, data, numel); }
-int cgd_lpips_finalize(cgd_lpips* v) { return v->net.finalize(nullptr); }
+int cgd_lpips_set_param(cgd_lpips* v, const char* name, const float* data, int64_t numel) {
+  if (!v) return -3;
+  return v->net.set_param(name, data, numel);
+}
+int cgd_lpips_finalize(cgd_lpips* v) {
+  if (!v) return -3;
+  return v->net.finalize(nullptr);
+}
 int cgd_lpips_set_reference(cgd_lpips* v, const float* ref_nchw, int B, int H, int W, void* stream) {
+  if (!v) return -3;
   return v->net.set_reference(ref_nchw, B, H, W, LS(stream));
 }
 int cgd_lpips_loss_grad(cgd_lpips* v, const float* x_nchw, float grad_scale, float* loss, float* g_nchw, int accumulate, void* stream) {
+  if (!v) return -3;
   return v->net.loss_grad(x_nchw, grad_scale, loss, g_nchw, accumulate, LS(stream));
 }
 }  // extern "C"

@@ -561,21 +561,33 @@ void cgd_rn_destroy(cgd_rn* v) {
   if (v) cgd_frag_cache_clear(v->net.ctx);
   delete v;
 }
-int cgd_rn_num_params(cgd_rn* v) { return (int)v->net.params.size(); }
+int cgd_rn_num_params(cgd_rn* v) {
+  if (!v) return -3;
+  return (int)v->net.params.size();
+}
 int cgd_rn_param_info(cgd_rn* v, int i, char* buf, int len, int64_t* numel) {
+  if (!v) return -3;
   if (i < 0 || i >= (int)v->net.params.size()) return -1;
   snprintf(buf, len, "%s", v->net.params[i].name.c_str());
   if (numel) *numel = v->net.params[i].numel;
   return 0;
 }
 int cgd_rn_set_param(cgd_rn* v, const char* name, const float* data, int64_t numel) {
+  if (!v) return -3;
   cgd_frag_cache_clear(v->net.ctx);
   return v->net.set_param(name, data, numel);
 }
 int cgd_rn_finalize(cgd_rn* v) {
+  if (!v) return -3;
   cgd_frag_cache_clear(v->net.ctx);
   return v->net.finalize(nullptr);
 }
-int cgd_rn_forward(cgd_rn* v, const float* img, int N, float* emb, void* stream) { return v->net.forward(img, N, emb, (hipStream_t)stream); }
-int cgd_rn_dgrad(cgd_rn* v, const float* d_emb, float* d_img, void* stream) { return v->net.dgrad(d_emb, d_img, (hipStream_t)stream); }
+int cgd_rn_forward(cgd_rn* v, const float* img, int N, float* emb, void* stream) {
+  if (!v) return -3;
+  return v->net.forward(img, N, emb, (hipStream_t)stream);
+}
+int cgd_rn_dgrad(cgd_rn* v, const float* d_emb, float* d_img, void* stream) {
+  if (!v) return -3;
+  return v->net.dgrad(d_emb, d_img, (hipStream_t)stream);
+}
 }  // extern "C"

@@ -36,13 +36,13 @@ const char* cgd_last_error(cgd_ctx* ctx);
 int cgd_set_precision(cgd_ctx* ctx, int mode);
 int cgd_get_precision(cgd_ctx* ctx);
 const char* cgd_version(void);
-/* HIP-event timing of every MFMA GEMM/conv launch on its own stream (measurement only; bench.py roofline leg).
- * cgd_profile_read: out[0..2] = igemm_kernel launches incl. their split-K reduce {summed ms, algorithmic FLOP, launches},
- * out[3..5] = the same for hconv2_kernel launches alone (the dominant kernel); resets. */
 /* tuning knob: GEMM tile codes for the automatic selection (64, 128, 256 = 256x128, 257 = 128x256; +1000 = 2-deep prefetch) */
 int cgd_set_tiles(cgd_ctx* ctx, int large_tile, int small_tile);
 /* tuning knob: weight GEMM kernel (hgemm.hip): mode 0 off / 1 auto, smallest M, 64-column chunks per split-K slice (0 = keep) */
 int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks);
+/* HIP-event timing of every MFMA GEMM/conv launch on its own stream (measurement only; bench.py roofline leg).
+ * cgd_profile_read: out[0..2] = igemm_kernel / hgemm_kernel launches incl. their split-K reduce {summed ms, algorithmic FLOP,
+ * launches}, out[3..5] = the same for hconv2_kernel launches alone (the dominant kernel); synchronises the device and resets. */
 int cgd_profile(cgd_ctx* ctx, int enable);
 int cgd_profile_read(cgd_ctx* ctx, double* out6);
 

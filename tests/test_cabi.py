@@ -45,3 +45,26 @@ def test_no_silent_fallback_without_gpu():
     from cgd import cgd as mine
     with pytest.raises(ValueError):
         next(mine.clip_guided_diffusion(prompts=["x"], device="cpu"))
+
+
+def test_null_handles_are_rejected_not_dereferenced():
+    """Error behaviour of the boundary: a NULL handle returns the invalid-argument code (-3) on every entry point that takes one."""
+    handle = lib.load()
+    assert handle.cgd_set_precision(None, 1) == -3
+    assert handle.cgd_get_precision(None) == -3
+    assert handle.cgd_profile(None, 1) == -3
+    assert handle.cgd_set_hconv(None, 1, 256) == -3
+    assert handle.cgd_last_error(None) == b"null context"
+    for net in ("unet", "vit", "rn", "lpips"):
+        assert getattr(handle, f"cgd_{net}_num_params")(None) == -3
+        assert getattr(handle, f"cgd_{net}_finalize")(None) == -3
+        getattr(handle, f"cgd_{net}_destroy")(None)  # no-op
+    assert handle.cgd_unet_forward(None, None, None, None, None, 1, 64, 64, None) == -3
+    assert handle.cgd_unet_dgrad(None, None, None, None) == -3
+    assert handle.cgd_vit_forward(None, None, 0, 1, None, None) == -3
+    assert handle.cgd_rn_forward(None, None, 1, None, None) == -3
+    assert handle.cgd_lpips_loss_grad(None, None, 1.0, None, None, 0, None) == -3
+    handle.cgd_ctx_destroy(None)  # no-op
+    assert handle.cgd_op_gemm(None, None, 0, None, 0, None, 0, None, None, 0, 1, 1, 1, 1.0, 0, 1, None) == -3
+    assert handle.cgd_cutouts_fwd(None, None, None, None, 1, 64, 64, 4, 224, 0, 0, None) == -3
+    assert handle.cgd_sample_update(None, None, None, None, None, None, None, None, None, None, 1, 64, 64, None, 0, None) == -3
