@@ -146,15 +146,38 @@ def clip_guided_diffusion(
                        model_kwargs=model_kwargs, cond_fn=cond_fn, progress=progress, skip_timesteps=skip_timesteps, init_image=init_tensor,
                        randomize_class=randomize_class, cond_fn_with_grad=True)
         cond_fn.current_timestep = diffusion.num_timesteps - 1
-        for step, sample in enumerate(samples):
-            cond_fn.current_timestep -= 1
-            if progress and cond_fn.scalars is not None:
-                tqdm.write("\t".join(f"{k}: {v:.3f}" for k, v in cond_fn.log().items() if "loss" in k.lower()))
-            if wandb_run is not None and cond_fn.scalars is not None:
-                wandb_run.log(cond_fn.log())
-            if step % save_frequency == 0 or cond_fn.current_timestep == -1:
-                for batch_idx, image_tensor in enumerate(sample["pred_xstart"]):
-                    yield batch_idx, script_util.log_image(image_tensor, prefix_path, prompts, step, batch_idx)
+
+        # Output path (reference cgd.py:180-186,234-238,265-270), software-pipelined by one timestep: the GPU work of timestep
+        # k+1 is enqueued BEFORE the host looks at timestep k (loss scalars, uint8 frames), and those reads travel on a side
+        # stream (cgd_amd/hostcopy.py).  With the CLI default --save_frequency 1 the two PNG encodes per sample then overlap the
+        # next step on the GPU instead of idling it.  Yield order and file naming are unchanged.
+        def enqueue_steps():
+            for step, sample in enumerate(samples):
+                cond_fn.current_timestep -= 1
+                want_log = (progress or wandb_run is not None) and cond_fn.scalars is not None
+                save = step % save_frequency == 0 or cond_fn.current_timestep == -1
+                yield (step, cond_fn.snapshot() if want_log else None, script_util.stage_images(sample["pred_xstart"]) if save else None)
+
+        def finish(item):
+            step, snapshot, frames = item
+            if snapshot is not None:
+                log = cond_fn.log(snapshot)
+                if progress:
+                    tqdm.write("\t".join(f"{k}: {v:.3f}" for k, v in log.items() if "loss" in k.lower()))
+                if wandb_run is not None:
+                    wandb_run.log(log)
+            if frames is not None:
+                arr = frames.get().numpy()
+                for batch_idx in range(arr.shape[0]):
+                    yield batch_idx, script_util.write_image(arr[batch_idx], prefix_path, prompts, step, batch_idx)
+
+        previous = None
+        for item in enqueue_steps():
+            if previous is not None:
+                yield from finish(previous)
+            previous = item
+        if previous is not None:
+            yield from finish(previous)
     except (RuntimeError, KeyboardInterrupt) as runtime_ex:
         if "out of memory" in str(runtime_ex).lower():
             print("CUDA OOM error occurred.")

@@ -61,17 +61,33 @@ def clean_and_combine_prompts(base_path, txts, batch_idx, max_length=255) -> str
     return os.path.join(base_path, stem, f"{batch_idx:02}")
 
 
-def log_image(image: th.Tensor, base_path: str, txts: list, current_step: int, batch_idx: int) -> str:
-    """(3,H,W) in [-1,1] -> '<base>/<prompts>/<batch:02>/<step:04>.png' (+ ./current.png), returns the path."""
+def to_uint8_hwc(image: th.Tensor) -> th.Tensor:
+    """(...,3,H,W) in [-1,1] -> (...,H,W,3) uint8, on the tensor's device (reference: TF.to_pil_image(image.add(1).div(2).clamp(0, 1)))."""
+    return image.detach().float().add(1).div(2).clamp(0, 1).mul(255).byte().movedim(-3, -1).contiguous()
+
+
+def stage_images(pred_xstart: th.Tensor):
+    """Starts the uint8 conversion and an asynchronous device->host copy of a (B,3,H,W) batch; `.get()` of the returned
+    handle yields the (B,H,W,3) uint8 host tensor without waiting for GPU work enqueued after this call."""
+    from cgd_amd.hostcopy import HostCopy
+    return HostCopy(to_uint8_hwc(pred_xstart))
+
+
+def write_image(arr, base_path: str, txts: list, current_step: int, batch_idx: int) -> str:
+    """(H,W,3) uint8 array -> '<base>/<prompts>/<batch:02>/<step:04>.png' (+ ./current.png), returns the path."""
     from PIL import Image
     dirname = clean_and_combine_prompts(base_path, txts, batch_idx)
     os.makedirs(dirname, exist_ok=True)
     filename = os.path.join(dirname, f"{current_step:04}.png")
-    arr = image.detach().float().add(1).div(2).clamp(0, 1).mul(255).byte().permute(1, 2, 0).cpu().numpy()
     pil_image = Image.fromarray(arr)
     pil_image.save(os.path.join(os.getcwd(), "current.png"))
     pil_image.save(filename)
     return str(filename)
+
+
+def log_image(image: th.Tensor, base_path: str, txts: list, current_step: int, batch_idx: int) -> str:
+    """(3,H,W) in [-1,1] -> PNG as above (reference signature, /root/reference/cgd/script_util.py:93-101)."""
+    return write_image(to_uint8_hwc(image).cpu().numpy(), base_path, txts, current_step, batch_idx)
 
 
 def download(url: str, filename: str, root: str = CACHE_PATH, max_retries: int = 3) -> str:

@@ -218,15 +218,21 @@ class ClipGuidance:
         self._keep = geo
         return g
 
-    def log(self):
-        """Scalar log of the last call with the reference's keys (one host sync; call lazily)."""
-        v = self.scalars.tolist()
+    def snapshot(self):
+        """Asynchronous host copies of the last call's scalars: `log(snapshot)` later costs no wait on newer GPU work."""
+        from .hostcopy import HostCopy
+        return {"scalars": HostCopy(self.scalars.clone()), "lpips": HostCopy(self.lpips_loss.clone()) if self.lpips is not None else None}
+
+    def log(self, snapshot=None):
+        """Scalar log of the last call (or of a `snapshot()`) with the reference's keys (one host sync; call lazily)."""
+        v = (snapshot["scalars"].get() if snapshot is not None else self.scalars).tolist()
+        lpips_loss = snapshot["lpips"].get() if (snapshot is not None and snapshot["lpips"] is not None) else self.lpips_loss
         out = {"CLIP Loss": v[0], "Range Loss": v[2], "TV Loss": v[1]}
         if self.sats != 0:
             out["Saturation Loss"] = v[3]
         out["Total Loss"] = v[4]
         if self.lpips is not None:
-            out["Init VGG Loss"] = float(self.lpips_loss.sum().item()) * self.init_scale
+            out["Init VGG Loss"] = float(lpips_loss.sum().item()) * self.init_scale
             out["Total Loss"] += out["Init VGG Loss"]
         if self.use_magnitude:
             out["Magnitude"] = v[5]

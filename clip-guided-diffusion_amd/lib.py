@@ -5,6 +5,7 @@ every wrapper raises RuntimeError(cgd_last_error()) on a non-zero status.
 """
 import ctypes as C
 import os
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcgd_mi355x.so")
@@ -152,6 +153,7 @@ class Context:
             raise CgdError(f"cgd_ctx_create failed with status {rc} (is device {device} a gfx950?)")
         self.h = h
         self.device = int(device)
+        self._nets = weakref.WeakSet()  # network handles created on this context (nets._Net._adopt)
         if precision is not None:
             self.set_precision(precision)
         tiles = os.environ.get("CGD_TILES")  # tuning only: "<large>,<small>" igemm tile codes (see cgd_set_tiles)
@@ -167,7 +169,9 @@ class Context:
 
     def check(self, rc):
         if rc != 0:
-            raise CgdError(self.lib.cgd_last_error(self.h).decode())
+            what = {-1: "HIP runtime error", -2: "invalid argument or state", -3: "NULL handle or pointer", -4: "not a gfx950 device"}.get(rc, "error")
+            msg = self.lib.cgd_last_error(self.h).decode() if rc in (-1, -2) else ""
+            raise CgdError(f"{what} (status {rc})" + (f": {msg}" if msg else ""))
 
     def set_precision(self, mode):
         mode = {"f32": 0, "bf16x3": 1, "bf16": 2}.get(mode, mode)
@@ -179,6 +183,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for net in list(self._nets):
+                net.close()
             self.lib.cgd_ctx_destroy(self.h)
             self.h = None
 

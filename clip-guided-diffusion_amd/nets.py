@@ -51,9 +51,14 @@ class _Net:
         self.ctx.check(self._fn("finalize")(self.h))
         return self
 
+    def _adopt(self, h):
+        self.h = h
+        self.ctx._nets.add(self)  # the context closes its networks before it goes away (their handles point into it)
+
     def close(self):
         if getattr(self, "h", None):
-            self._fn("destroy")(self.h)
+            if getattr(self.ctx, "h", None):  # after Context.close() the native side is already gone
+                self._fn("destroy")(self.h)
             self.h = None
 
     def __del__(self):
@@ -90,7 +95,7 @@ class UNet(_Net):
         self.out_channels = out_channels
         h = C.c_void_p()
         ctx.check(ctx.lib.cgd_unet_create(ctx.h, C.byref(cfg), C.byref(h)))
-        self.h = h
+        self._adopt(h)
 
     def forward(self, x, timesteps, y=None, out=None):
         """x (B,3,H,W) fp32 NCHW on the GPU; timesteps (B,) (any dtype; converted to fp32); y (B,) int64."""
@@ -131,7 +136,7 @@ class ClipImageTower(_Net):
         self.patch, self.out_dim = patch, out
         h = C.c_void_p()
         ctx.check(ctx.lib.cgd_vit_create(ctx.h, C.byref(cfg), C.byref(h)))
-        self.h = h
+        self._adopt(h)
         self._layout = 0
         self._n = 0
 
@@ -185,7 +190,7 @@ class ClipResNetTower(_Net):
         self.input_resolution, self.out_dim = res, out
         h = C.c_void_p()
         ctx.check(ctx.lib.cgd_rn_create(ctx.h, C.byref(cfg), C.byref(h)))
-        self.h = h
+        self._adopt(h)
 
     def load_clip_state_dict(self, sd):
         prefix = "visual." if any(k.startswith("visual.") for k in sd) else ""
@@ -219,7 +224,7 @@ class LpipsVGG(_Net):
         self.ctx = ctx
         h = C.c_void_p()
         ctx.check(ctx.lib.cgd_lpips_create(ctx.h, C.byref(h)))
-        self.h = h
+        self._adopt(h)
         self._ref = None
 
     def set_reference(self, ref):

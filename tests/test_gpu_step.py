@@ -72,6 +72,44 @@ def test_dropin_generator_yields_batch_idx_path(tmp_path, monkeypatch):
     assert os.path.isfile(tmp_path / "current.png")
 
 
+def test_dropin_generator_full_run_pipelined_output(tmp_path, monkeypatch, capsys):
+    """A complete short run with frames and loss lines every step: the output path is pipelined by one timestep (frames and
+    scalars of step k are read on a side stream after step k+1 has been enqueued) and must still yield every
+    (batch_idx, path) in step order, write every PNG before it is yielded and print the reference's loss line per step."""
+    import numpy as np
+    from PIL import Image
+    monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.chdir(tmp_path)
+    from cgd.cgd import clip_guided_diffusion
+    items = []
+    for b, path in clip_guided_diffusion(prompts=["Loose seal."], image_size=64, batch_size=2, num_cutouts=2, timestep_respacing="5",
+                                         noise_schedule="cosine", prefix_path=str(tmp_path / "out"), checkpoints_dir=str(tmp_path / "ckpt"),
+                                         save_frequency=2, progress=True, device="cuda"):
+        assert os.path.isfile(path), path  # written before it is handed out
+        items.append((b, os.path.basename(path)))
+    # steps 0, 2, 4 (save_frequency 2; step 4 is also the last one), two samples each, in order
+    assert items == [(0, "0000.png"), (1, "0000.png"), (0, "0002.png"), (1, "0002.png"), (0, "0004.png"), (1, "0004.png")]
+    frames = [np.asarray(Image.open(tmp_path / "out" / "Loose_seal" / f"{b:02}" / name)) for b, name in items]
+    assert all(f.shape == (64, 64, 3) and f.dtype == np.uint8 for f in frames)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if "CLIP Loss" in ln]
+    assert len(lines) == 5 and all("TV Loss" in ln and "Range Loss" in ln and "Total Loss" in ln for ln in lines)
+
+
+def test_hostcopy_snapshots_the_value_at_call_time():
+    """cgd_amd.hostcopy.HostCopy: the copy depends only on work enqueued before it, and later writes to the source do not leak in."""
+    import torch as th
+    from cgd_amd.hostcopy import HostCopy
+    x = th.arange(1 << 20, device="cuda", dtype=th.float32)
+    snap = HostCopy(x.clone())
+    big = th.randn(4096, 4096, device="cuda")
+    for _ in range(8):
+        big = big @ big * 1e-3  # later work on the compute stream
+    x.zero_()
+    got = snap.get()
+    assert got.is_pinned() and th.equal(got, th.arange(1 << 20, dtype=th.float32))
+    th.cuda.synchronize()
+
+
 def test_dropin_generator_with_init_image_and_lpips(tmp_path, monkeypatch):
     """init_image + skip_timesteps + init_scale (config 4 of BASELINE.json, reference cgd.py:111-119,147-148,220-224) through the drop-in
     generator: the LPIPS-VGG16 module is created lazily and its loss shows up in the scalar log."""
