@@ -93,6 +93,21 @@ def prompt_weight_matrix(weights, batch, device):
     return m.contiguous().to(device)
 
 
+def guidance_schedule(total, current_timestep, num_cutouts, reduce_clip=False, progressive_cutout=False):
+    """(skip_guidance, cutouts_this_step) of /root/reference/cgd/cgd.py:155-175: with reduce_clip, guidance runs on every 4th
+    step while less than 70 % of the schedule is done (the first 20 % are skipped through skip_timesteps, cgd.py:140-144); with
+    progressive_cutout the cutout count is max(4, n//4) below 30 %, max(8, n//2) below 70 %, n afterwards.  `current_timestep`
+    is the reference's closure counter, not the sampler's t."""
+    pct = (total - current_timestep) / total
+    if reduce_clip and pct < 0.7:
+        if int((pct - 0.2) * total) % 4 != 0:
+            return True, 0
+    if progressive_cutout:
+        n = num_cutouts
+        return False, (max(4, n // 4) if pct < 0.3 else (max(8, n // 2) if pct < 0.7 else n))
+    return False, num_cutouts
+
+
 class ClipGuidance:
     def __init__(self, ctx, unet, clip_tower, diffusion, target_embeds, weights, num_cutouts, cutout_power=1.0,
                  clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0, sat_scale=0.0, use_magnitude=False,
@@ -136,15 +151,8 @@ class ClipGuidance:
 
     def schedule(self):
         """Returns (skip_guidance, current_cutn) per cgd.py:155-175."""
-        total = self.diffusion.num_timesteps
-        pct = (total - self.current_timestep) / total
-        if self.reduce_clip and pct < 0.7:
-            if int((pct - 0.2) * total) % 4 != 0:
-                return True, 0
-        if self.progressive_cutout:
-            n = self.num_cutouts
-            return False, (max(4, n // 4) if pct < 0.3 else (max(8, n // 2) if pct < 0.7 else n))
-        return False, self.num_cutouts
+        return guidance_schedule(self.diffusion.num_timesteps, self.current_timestep, self.num_cutouts, self.reduce_clip,
+                                 self.progressive_cutout)
 
     def fac_index(self):
         return self.current_timestep

@@ -38,7 +38,8 @@ GROUPS = {
              lambda: _sc().check_step("mini", 1, ddim=True, respacing="4", steps=4),
              lambda: _sc().check_step("mini", 1, respacing="50", steps=3, B=2, P=2, use_magnitude=True, sat_scale=30.0),
              lambda: _sc().check_step("mini64", 1, respacing="25", schedule="cosine", steps=2, P=3, hw=(32, 48), scales=(5.0, 1e-5, 50.0),
-                                      use_magnitude=True)],
+                                      use_magnitude=True),
+             lambda: _sc().check_step("mini", 1, respacing="50", steps=6, cutn=16, reduce_clip=True, progressive_cutout=True)],
 }
 
 

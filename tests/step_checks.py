@@ -20,7 +20,7 @@ def make_tape(B, H, W, nsteps, num_classes, cutn, cut_size, cut_pow=1.0, seed=0)
 
 def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_cfg=(64, 16, 128, 2, 2, 64), P=1, hw=None,
                respacing="50", schedule="linear", use_magnitude=False, sat_scale=0.0, scales=(1000.0, 150.0, 50.0), skip=0,
-               weights=None, init_scale=0.0, rn_cfg=None, dual=False):
+               weights=None, init_scale=0.0, rn_cfg=None, dual=False, reduce_clip=False, progressive_cutout=False):
     from cgd_amd import diffusion as dd
     from cgd_amd import guidance as dg
     from cgd_amd import lib, nets, sampler
@@ -68,6 +68,10 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
     smp = sampler.GuidedSampler(ctx, d_tab)
     N = o_diff.num_timesteps
     tape = make_tape(B, H, W, steps, kw.get("num_classes"), cutn, res)
+    # reduce_clip / progressive_cutout (cgd.py:155-175): the closure counter starts at N-1 whatever skip_timesteps is; a skipped
+    # call consumes no tape entry and a guided one takes the first `cutn_k` boxes of its entry
+    gate = [dg.guidance_schedule(N, N - 1 - k, cutn, reduce_clip, progressive_cutout) for k in range(steps)]
+    tape["coords"] = [tape["coords"][k][:n_k] for k, (skipped, n_k) in enumerate(gate) if not skipped]
     targets = th.randn(P, outd, generator=g(80))
     targets2 = th.randn(P, 48, generator=g(81)) if dual else None
     w = th.tensor(weights if weights is not None else [1.0, 0.5, -0.3][:P])
@@ -92,7 +96,7 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
     o_cond, o_state = og.make_cond_fn(diffusion=o_diff, clip_model=o_models, make_cutouts=o_cutters, target_embeds=o_targets, weights=w,
                                       num_cutouts=cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs, sat_scale=sat_scale,
                                       use_magnitude=use_magnitude, coords_tape=tape["coords"], lpips_model=o_lp, init_tensor=init_cpu,
-                                      init_scale=init_scale)
+                                      init_scale=init_scale, reduce_clip=reduce_clip, progressive_cutout=progressive_cutout)
     mkw = {"y": th.zeros(B, dtype=th.long)} if kw.get("num_classes") else {}
     loop = o_diff.ddim_sample_loop_progressive if ddim else o_diff.p_sample_loop_progressive
     o_gen = loop(ref_unet, (B, 3, H, W), clip_denoised=False, cond_fn=o_cond, model_kwargs=dict(mkw), device="cpu",
@@ -103,13 +107,14 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
     o_out = []
     for out in o_gen:
         o_state["current_timestep"] -= 1
-        o_out.append((out["sample"].clone(), out["pred_xstart"].clone(), dict(o_state["log"])))
+        o_out.append((out["sample"].clone(), out["pred_xstart"].clone(), dict(o_state.get("log", {}))))
 
     # ---- device ----
     d_towers = [dev_clip, dev_clip2] if dual else dev_clip
     d_targets = [targets.to(DEV), targets2.to(DEV)] if dual else targets.to(DEV)
     guid = dg.ClipGuidance(ctx, dev_unet, d_towers, smp, d_targets, w, cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs,
-                           sat_scale=sat_scale, use_magnitude=use_magnitude, lpips=d_lp,
+                           sat_scale=sat_scale, use_magnitude=use_magnitude, lpips=d_lp, reduce_clip=reduce_clip,
+                           progressive_cutout=progressive_cutout,
                            init_tensor=None if init_cpu is None else init_cpu.to(DEV), init_scale=init_scale)
     guid.coords_tape = tape["coords"]
     smp.tape = tape
@@ -119,13 +124,16 @@ def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_c
                   randomize_class=bool(dmkw), cond_fn_with_grad=True)
     guid.current_timestep = N - 1
     recs = []
-    tag = f"step[{case} p{precision} {'ddim' if ddim else 'p'} B{B} {H}x{W} mag{int(use_magnitude)} sat{sat_scale} init{init_scale}]"
+    tag = (f"step[{case} p{precision} {'ddim' if ddim else 'p'} B{B} {H}x{W} mag{int(use_magnitude)} sat{sat_scale} init{init_scale}"
+           f"{' reduce' if reduce_clip else ''}{' progressive' if progressive_cutout else ''}]")
     for k, out in enumerate(d_gen):
         guid.current_timestep -= 1
         th.cuda.synchronize()
         o_s, o_x0, o_log = o_out[k]
         recs.append(rec(f"{tag} step{k} sample", out["sample"], o_s))
         recs.append(rec(f"{tag} step{k} pred_xstart", out["pred_xstart"], o_x0))
+        if gate[k][0]:  # guidance skipped on this step (the reference returns zeros_like(x)): no new scalars
+            continue
         lg = guid.log()
         for key in ("CLIP Loss", "TV Loss", "Range Loss", "Total Loss") + (("Init VGG Loss",) if init_scale else ()):
             recs.append(rec(f"{tag} step{k} {key}", th.tensor([lg[key]]), th.tensor([o_log[key]])))

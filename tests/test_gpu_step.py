@@ -37,6 +37,12 @@ def test_cosine_nonsquare_weighted_prompts():
                               use_magnitude=True))
 
 
+def test_reduce_clip_and_progressive_cutout_gating():
+    """guidance skipped on 4 of 6 steps (zeros_like(x) in the reference, no cond_fn work here), cutn/4
+    cutouts on the guided ones; trajectory and scalars against the oracle."""
+    _assert_all(sc.check_step("mini", 1, respacing="50", steps=6, cutn=16, reduce_clip=True, progressive_cutout=True))
+
+
 def test_init_image_lpips_term():
     # init image broadcast over the batch + LPIPS-VGG16 perceptual term (cgd.py:220-224).  init_scale 100: the LPIPS gradient is
     # discontinuous (ReLU / max-pool masks), so two fp32 implementations differ by a few mask flips; at the reference's

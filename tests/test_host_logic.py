@@ -105,3 +105,37 @@ def test_model_config_overrides():
     # user-level noise_schedule/dropout override the per-checkpoint flags
     assert cfg["noise_schedule"] == "linear" and cfg["dropout"] == 0.0 and cfg["num_channels"] == 192 and cfg["use_new_attention_order"]
     assert script_util.model_config(512, False, 1000, "1000")["rescale_timesteps"] is True
+
+
+def test_reduce_clip_and_progressive_cutout_schedule():
+    """SURVEY.md 8a row a10 (reference cgd.py:140-144,155-175): guidance gating and the cutn/4 -> cutn/2 -> cutn ladder, driven by
+    the closure counter `current_timestep` (N-1 before the first sample, decremented after each)."""
+    N, cutn = 250, 16
+    # plain: never skipped, always all cutouts
+    assert all(dg.guidance_schedule(N, cur, cutn) == (False, cutn) for cur in range(N))
+    # --reduce-clip: the generator skips the first 20 % through skip_timesteps, yet the counter still starts at N-1
+    # (offset quirk), so the counter walks N-1 ... N-200 over the 200 executed steps.
+    skip = int(N * 0.2)
+    run = [k for k in range(N - skip) if not dg.guidance_schedule(N, N - 1 - k, cutn, reduce_clip=True)[0]]
+    early = [k for k in run if (k + 1) / N < 0.7]
+    late = [k for k in run if (k + 1) / N >= 0.7]
+    assert late == [k for k in range(N - skip) if (k + 1) / N >= 0.7]  # the last 30 % of the counter's range: every step
+    assert all(int(((k + 1) / N - 0.2) * N) % 4 == 0 for k in early)
+    assert len(early) == 46  # every 4th of 174 steps, plus the two extra hits where int() truncates the phases -0.x and +0.x to 0
+    assert early[:3] == [1, 5, 9]  # int((pct - 0.2) * N) = -48, -44, -40: truncation towards zero, negative phase
+    # literal values of the reference formula
+    assert dg.guidance_schedule(50, 49, 16, reduce_clip=True) == (True, 0)     # int((0.02 - 0.2) * 50) = -9 -> skipped
+    assert dg.guidance_schedule(50, 48, 16, reduce_clip=True) == (False, 16)   # -8 -> guided
+    assert dg.guidance_schedule(50, 14, 16, reduce_clip=True) == (False, 16)   # pct 0.72 >= 0.7 -> every step
+    # --progressive-cutout ladder and its floors
+    assert dg.guidance_schedule(N, N - 1, 16, progressive_cutout=True) == (False, 4)
+    assert dg.guidance_schedule(N, N - 75, 16, progressive_cutout=True) == (False, 8)    # pct = 0.3
+    assert dg.guidance_schedule(N, N - 175, 16, progressive_cutout=True) == (False, 16)  # pct = 0.7
+    assert dg.guidance_schedule(N, N - 1, 8, progressive_cutout=True) == (False, 4)      # max(4, 8 // 4)
+    assert dg.guidance_schedule(N, N - 100, 8, progressive_cutout=True) == (False, 8)    # max(8, 8 // 2)
+    assert dg.guidance_schedule(N, N - 1, 64, progressive_cutout=True) == (False, 16)
+    # the oracle's closure gates identically (same expression, tests/step_checks.py compares the trajectories on the GPU)
+    from oracle import guidance as og
+    import inspect
+    src = inspect.getsource(og.make_cond_fn)
+    assert "int((pct - 0.2) * total) % 4 != 0" in src and "max(4, num_cutouts // 4)" in src and "max(8, num_cutouts // 2)" in src
