@@ -139,3 +139,25 @@ def test_reduce_clip_and_progressive_cutout_schedule():
     import inspect
     src = inspect.getsource(og.make_cond_fn)
     assert "int((pct - 0.2) * total) % 4 != 0" in src and "max(4, num_cutouts // 4)" in src and "max(8, num_cutouts // 2)" in src
+
+
+def test_cached_cutouts_reuse_and_argument_order_quirk():
+    """reference modules.py:26-36,50-58 and cgd.py:112-113: `--cached-cutouts` draws the boxes once, with (side_x, side_y) =
+    (image_size + width_offset, image_size + height_offset), and every later call takes the first `cutn` of them; without the
+    cache each call consumes three draws per cutout from the global CPU generator, in the reference's order."""
+    from oracle import guidance as og
+    mk = dg.MakeCutouts(224, 8, 1.0)
+    th.manual_seed(7)
+    mk.cache_coordinates(256 + 32, 256 + 0)  # (W, H) order, as the generator calls it
+    th.manual_seed(7)
+    expect = og.generate_coords(288, 256, 8, 224, 1.0)
+    assert mk.cached_coords == expect and len(expect) == 8
+    assert mk.draw(256, 288, use_cache=True, num_cutouts_override=4) == expect[:4]   # progressive_cutout takes a prefix
+    assert mk.draw(256, 288, use_cache=True) == expect
+    th.manual_seed(11)
+    fresh = mk.draw(256, 288, use_cache=False, num_cutouts_override=3)
+    th.manual_seed(11)
+    assert fresh == og.generate_coords(256, 288, 3, 224, 1.0) and fresh != expect[:3]
+    # boxes cached for (288, 256) may stick out of a (256, 288) image along H: the crop is truncated like a Python slice
+    geo = dg.crop_geometry(expect, 256, 288)
+    assert all(0 <= oy and 0 <= ox and h <= 256 - oy and w <= 288 - ox for (oy, ox, h, w) in geo)
