@@ -171,5 +171,7 @@ def encode_image_prompt(image: str, weight: float, diffusion_size: int, num_cuto
     pil_img = pil_img.resize((max(1, round(pil_img.size[0] * scale)), max(1, round(pil_img.size[1] * scale))), Image.LANCZOS)
     img = th.from_numpy(np.asarray(pil_img)).float().div(255).permute(2, 0, 1).unsqueeze(0).to(device)
     batch = make_cutouts(img)
+    # quirk kept: the reference's `tf` is torch.nn.functional, so `tf.normalize(batch)` (clip_util.py:99) L2-normalises along the
+    # channel axis instead of applying CLIP_NORMALIZE
     batch_embed = clip_model.encode_image(th.nn.functional.normalize(batch)).float()
     return batch_embed, [weight / make_cutouts.cutn] * make_cutouts.cutn
