@@ -63,6 +63,19 @@ class _Visual:
         self.tower = tower
 
 
+class _EncodeImageFunction(th.autograd.Function):
+    """tower.encode_image as an autograd node; backward = the tower's hand-derived backward-to-image of its LAST forward."""
+
+    @staticmethod
+    def forward(ctx, image, tower):
+        ctx.tower, ctx.in_shape = tower, tuple(image.shape)
+        return tower.encode_image(image.detach().float().contiguous())
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        return ctx.tower.dgrad(d_emb.float().contiguous()).view(ctx.in_shape), None
+
+
 class ClipModel:
     """The slice of clip.model.CLIP the generator touches: `.visual.input_resolution`, `.encode_image`, and (when the
     `clip` package + checkpoint are present) `.encode_text`."""
@@ -74,6 +87,10 @@ class ClipModel:
         self.name = name
 
     def encode_image(self, image):
+        """(N,3,res,res) CLIP-normalised -> (N,D).  Differentiable w.r.t. `image` (autograd node over cgd_*_forward / _dgrad) so
+        that a user-supplied cond_fn written like the reference's (cgd.py:190-228) works unchanged."""
+        if image.requires_grad and th.is_grad_enabled():
+            return _EncodeImageFunction.apply(image, self.tower)
         return self.tower.encode_image(image)
 
     def encode_text(self, tokens):

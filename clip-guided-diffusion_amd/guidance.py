@@ -57,21 +57,50 @@ class MakeCutouts(th.nn.Module):
         return generate_coords(side_x, side_y, cutn, self.cut_size, self.cut_pow)
 
     def forward(self, input, use_cache=False, num_cutouts_override=None):
-        """input (B,3,H,W) in [0,1] -> (cutn*B,3,cut,cut) NCHW, *not* normalised (as in the reference)."""
+        """input (B,3,H,W) in [0,1] -> (cutn*B,3,cut,cut) NCHW, *not* normalised (as in the reference).  Differentiable: when
+        `input` requires grad the result is an autograd node whose backward is the cutout scatter kernel (cgd_cutouts_bwd)."""
         if self.ctx is None:
             self.ctx = L.Context(input.device.index or 0)
-        B, _, H, W = input.shape
+        _, _, H, W = input.shape
         coords = self.draw(H, W, use_cache, num_cutouts_override)  # (side_x, side_y) = (H, W): reference naming
         self.last_coords = coords
         geo = th.tensor(crop_geometry(coords, H, W), dtype=th.int32, device=input.device)
+        if input.requires_grad and th.is_grad_enabled():
+            return _CutoutsFunction.apply(input, self, geo, len(coords))
+        return self._pool(input, geo, len(coords))
+
+    def _pool(self, input, geo, ncut):
+        B, _, H, W = input.shape
         # the kernel pools (x+1)/2 and applies the CLIP normalisation; undo both to return the raw pooled crop
-        x_pm1 = (input.float() * 2 - 1).contiguous()
-        out = th.empty((len(coords) * B, 3, self.cut_size, self.cut_size), device=input.device, dtype=th.float32)
-        self.ctx.check(self.ctx.lib.cgd_cutouts_fwd(self.ctx.h, x_pm1.data_ptr(), geo.data_ptr(), out.data_ptr(), B, H, W, len(coords),
+        x_pm1 = (input.detach().float() * 2 - 1).contiguous()
+        out = th.empty((ncut * B, 3, self.cut_size, self.cut_size), device=input.device, dtype=th.float32)
+        self.ctx.check(self.ctx.lib.cgd_cutouts_fwd(self.ctx.h, x_pm1.data_ptr(), geo.data_ptr(), out.data_ptr(), B, H, W, ncut,
                                                     self.cut_size, 0, 0, L.stream_ptr()))
         mean = th.tensor(CLIP_MEAN, device=input.device).view(1, 3, 1, 1)
         std = th.tensor(CLIP_STD, device=input.device).view(1, 3, 1, 1)
         return out * std + mean
+
+
+class _CutoutsFunction(th.autograd.Function):
+    """MakeCutouts.forward as an autograd node (user-supplied cond_fns that follow the reference recipe, cgd.py:190-194)."""
+
+    @staticmethod
+    def forward(ctx, input, mk, geo, ncut):
+        ctx.mk, ctx.geo, ctx.ncut, ctx.in_shape = mk, geo, ncut, tuple(input.shape)
+        return mk._pool(input, geo, ncut)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        mk = ctx.mk
+        B, _, H, W = ctx.in_shape
+        # cgd_cutouts_bwd returns d/dx of the kernel's own convention, out = (pool((x+1)/2) - mean) / std: feed it d_out * std and
+        # double the result to get the adjoint of the plain crop + adaptive average pool
+        std = th.tensor(CLIP_STD, device=d_out.device).view(1, 3, 1, 1)
+        d = (d_out.float() * std).contiguous()
+        g = th.empty(ctx.in_shape, device=d_out.device, dtype=th.float32)
+        mk.ctx.check(mk.ctx.lib.cgd_cutouts_bwd(mk.ctx.h, d.data_ptr(), ctx.geo.data_ptr(), g.data_ptr(), B, H, W, ctx.ncut, mk.cut_size,
+                                                0, 0, 0, L.stream_ptr()))
+        return g * 2, None, None, None
 
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)

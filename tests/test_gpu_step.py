@@ -177,3 +177,49 @@ def test_user_cond_fn_through_autograd_functions():
                                                                     randomize_class=True, cond_fn_with_grad=True, tape=tape), 2))
     recs = [pc.rec(f"user cond_fn step{k} sample", a["sample"], b["sample"]) for k, (a, b) in enumerate(zip(outs, o_outs))]
     _assert_all(recs)
+
+
+def test_reference_recipe_cond_fn_with_the_plugin_callables():
+    """SURVEY.md 8b plugin surface: `MakeCutouts.forward`, `CLIP_NORMALIZE`, `clip_model.encode_image`, `losses.spherical_dist_loss`
+    composed exactly like the reference's cond_fn (cgd.py:190-200,228) and differentiated with torch.autograd on the GPU — the cutout
+    and CLIP-tower nodes run the C ABI forward / backward kernels — against the same recipe on the CPU oracle."""
+    import cgd_amd  # noqa: F401
+    from cgd import clip_util, losses
+    from cgd_amd import guidance as dg
+    from cgd_amd import lib, nets
+    from oracle import clip_vit as ocv
+    from oracle import guidance as og
+    from tests import parity_checks as pc
+    ctx = lib.Context(0, 1)
+    vit_cfg = (64, 16, 128, 2, 2, 64)
+    ref_clip = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
+    th.nn.Module.__init__(ref_clip)
+    ref_clip.visual = ocv.VisionTransformer(*vit_cfg)
+    ocv.synthetic_init_(ref_clip).eval()
+    for p in ref_clip.parameters():
+        p.requires_grad_(False)
+    tower = nets.ClipImageTower(ctx, config=vit_cfg)
+    tower.load_clip_state_dict({k: v.to("cuda") for k, v in ref_clip.state_dict().items()})
+    clip_model = clip_util.ClipModel(tower)
+    B, H, W, cutn = 2, 48, 80, 3
+    coords = og.generate_coords(H, W, cutn, 64, 1.0, generator=pc.g(3))  # 64 > 48: full-height boxes, pooled UP to 64
+    target = th.randn(1, 64, generator=pc.g(4))
+    x_cpu = th.tanh(th.randn(B, 3, H, W, generator=pc.g(5)))
+
+    def recipe(x, make_cutouts, normalize, model, tgt, **kw):
+        clip_in = normalize(make_cutouts(x.add(1).div(2), **kw))
+        emb = model.encode_image(clip_in).float().view([cutn, B, -1])
+        dists = losses.spherical_dist_loss(emb.unsqueeze(0), tgt.unsqueeze(0))
+        loss = dists.view([cutn, B, -1]).sum(2).mean(0).sum() * 1000.0
+        return emb, th.autograd.grad(loss, x)[0]
+
+    xo = x_cpu.clone().requires_grad_()
+    o_emb, o_grad = recipe(xo, og.MakeCutouts(64, cutn), og.clip_normalize, ref_clip, target, coords=coords)
+    mk = dg.MakeCutouts(64, cutn, ctx=ctx)
+    mk.draw = lambda *a, **k: coords  # replay the oracle's boxes
+    xd = x_cpu.clone().to("cuda").requires_grad_()
+    d_emb, d_grad = recipe(xd, mk, clip_util.CLIP_NORMALIZE, clip_model, target.to("cuda"))
+    _assert_all([pc.rec("plugin recipe: embeddings", d_emb, o_emb), pc.rec("plugin recipe: d loss / d x", d_grad, o_grad)])
+    # without grad the same callables are plain functions
+    with th.no_grad():
+        assert not clip_model.encode_image(clip_util.CLIP_NORMALIZE(mk(xd.detach().add(1).div(2)))).requires_grad
