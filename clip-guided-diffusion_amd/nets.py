@@ -111,7 +111,11 @@ class UNet(_Net):
         self._keep = (x, t, y)  # inputs must outlive the enqueued work
         return out
 
-    __call__ = forward
+    def __call__(self, x, timesteps, y=None, out=None):
+        """model(x, timesteps, y) as the sampler and user cond_fns call it: an autograd node when `x` requires grad."""
+        if x.requires_grad and th.is_grad_enabled():
+            return UNetFunction.apply(x, self, timesteps, y)
+        return self.forward(x, timesteps, y, out)
 
     def dgrad(self, g_out, g_x=None):
         """d(sum(out*g_out))/dx for the last forward."""
@@ -122,6 +126,19 @@ class UNet(_Net):
         self.ctx.check(self.ctx.lib.cgd_unet_dgrad(self.h, g_out.data_ptr(), g_x.data_ptr(), L.stream_ptr()))
         self._keep_g = g_out
         return g_x
+
+
+class UNetFunction(th.autograd.Function):
+    """model(x, ts, y) as an autograd node: backward = cgd_unet_dgrad of the LAST forward (only d/dx exists)."""
+
+    @staticmethod
+    def forward(ctx, x, unet, ts, y):
+        ctx.unet = unet
+        return unet.forward(x.detach(), ts, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.unet.dgrad(g.contiguous()), None, None, None
 
 
 class ClipImageTower(_Net):

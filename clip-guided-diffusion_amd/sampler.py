@@ -11,19 +11,7 @@ import torch as th
 
 from . import lib as L
 from .guidance import ClipGuidance
-
-
-class UNetFunction(th.autograd.Function):
-    """model(x, ts, y) as an autograd node: backward = cgd_unet_dgrad (only d/dx exists)."""
-
-    @staticmethod
-    def forward(ctx, x, unet, ts, y):
-        ctx.unet = unet
-        return unet.forward(x, ts, y)
-
-    @staticmethod
-    def backward(ctx, g):
-        return ctx.unet.dgrad(g.contiguous()), None, None, None
+from .nets import UNetFunction  # noqa: F401  (re-exported: the autograd node of model(x, ts, y))
 
 
 class GuidedSampler:
@@ -75,7 +63,7 @@ class GuidedSampler:
             # generic plugin path: reference semantics via autograd over the C-ABI UNet node
             with th.enable_grad():
                 xr = x.detach().requires_grad_()
-                out6 = UNetFunction.apply(xr, model, ts, y)
+                out6 = model(xr, ts, y)  # autograd node over cgd_unet_forward / cgd_unet_dgrad (nets.UNetFunction)
                 eps, v = out6[:, :3], out6[:, 3:]
                 frac = (v + 1) / 2
                 lv = frac * coef.max_log + (1 - frac) * coef.min_log
