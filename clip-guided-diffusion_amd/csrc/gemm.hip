@@ -397,8 +397,9 @@ static void tile_dims(int tile, int* bm, int* bn) {
   }
 }
 
-int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
-  if (p.M <= 0 || p.N <= 0) return 0;
+// Kernel selection and split-K policy: pure host logic (no HIP calls), shared by the launcher and by cgd_op_plan (CPU tests).
+// kernel: 0 igemm_kernel (tile code in *tile_out), 1 hconv2_kernel, 2 hgemm_kernel; p.K / p.splitk are finalised in place.
+int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) CGD_FAIL(ctx, "cgd_launch_gemm: K, lda, ldb must be multiples of 4");
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) CGD_FAIL(ctx, "cgd_launch_gemm: A/B must be 16-byte aligned");
   if (p.conv && (p.Cin % BK)) CGD_FAIL(ctx, "cgd_launch_gemm: conv Cin must be a multiple of 32");
@@ -471,8 +472,18 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (p.splitk > 1) {
     if (p.nbatch != 1) CGD_FAIL(ctx, "cgd_launch_gemm: split-K with batches is not supported");
     if ((size_t)p.splitk * p.M * p.N * sizeof(float) > ctx->ws_bytes) CGD_FAIL(ctx, "cgd_launch_gemm: split-K workspace too small");
-    p.ws = ctx->ws;
   }
+  *tile_out = tile;
+  *kernel_out = use_h ? 1 : (use_g ? 2 : 0);
+  return 0;
+}
+
+int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0) return 0;
+  int tile = 0, kernel = 0;
+  CGD_TRY(cgd_plan_gemm(ctx, p, &tile, &kernel));
+  const bool use_h = kernel == 1, use_g = kernel == 2;
+  if (p.splitk > 1) p.ws = ctx->ws;
   ProfRec pr;
   if (ctx->prof_on) {
     // bound the number of live events: retire all but the newest 1024 records (they completed long ago)
@@ -515,5 +526,38 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     ctx->prof_recs.push_back(pr);
   }
   CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+// Host-only view of the selection above (no GPU, no context): which kernel, tile code, split-K factor and grid size the launcher
+// picks for a problem, with the default knobs of a fresh context.  Exported for the CPU tests of the dispatch policy.
+extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin, int weight, int precision, int num_cu, int* out4) {
+  if (!out4) return -3;
+  cgd_ctx ctx;  // plain host object: defaults of cgd_ctx_create, nothing allocated
+  ctx.precision = precision;
+  if (num_cu > 0) ctx.num_cu = num_cu;
+  ctx.ws_bytes = (size_t)256 << 20;
+  GemmParams p;
+  float* const dummy = (float*)(uintptr_t)4096;  // only the alignment of the pointers is inspected
+  p.A = p.B = dummy;
+  p.C = dummy;
+  p.M = M; p.N = N; p.K = conv ? 9 * Cin : K;
+  p.lda = conv ? Cin : K; p.ldb = p.K; p.ldc = N;
+  p.conv = conv; p.H = H; p.W = W; p.Cin = Cin; p.weight = weight;
+  if (conv) p.Bpk = dummy;
+  int tile = 0, kernel = 0;
+  const int rc = cgd_plan_gemm(&ctx, p, &tile, &kernel);
+  if (rc != 0) return rc;
+  long wg;
+  if (kernel == 1) {
+    wg = (long)(p.M / cgd_hconv_tile_m(&ctx, p)) * cdiv(p.N, 128);
+  } else if (kernel == 2) {
+    wg = cgd_hgemm_tiles(p);
+  } else {
+    int bm = 0, bn = 0;
+    tile_dims(tile, &bm, &bn);
+    wg = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
+  }
+  out4[0] = kernel; out4[1] = tile; out4[2] = p.splitk; out4[3] = (int)(wg * p.splitk);
   return 0;
 }

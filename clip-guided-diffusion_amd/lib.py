@@ -95,6 +95,7 @@ _SIGS = {
     "cgd_scalars": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp]),
     "cgd_sample_update": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(StepCoef), i32, vp]),
     "cgd_op_gemm": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
+    "cgd_op_plan": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)]),
     "cgd_op_pack_conv3x3_frag": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cgd_set_hconv": (i32, [vp, i32, i32]),
     "cgd_op_conv3x3": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -185,6 +185,10 @@ int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, 
  * halo-staged kernel (force_tile 512 or automatic for large images) */
 int cgd_op_pack_conv3x3_frag(cgd_ctx* ctx, const float* w_torch, float* out /* Co*Ci*9 floats of storage */, int Co, int Ci, int dgrad,
                              void* stream);
+/* host-only (no GPU, no context): the launcher's choice for a GEMM (conv = 0: C[M][N] over K, weight = 1 when B is a persistent
+ * weight) or a conv3x3 (conv = 1: M = B*H*W pixels, N = Cout) with the default knobs: out4 = {kernel: 0 igemm_kernel, 1 hconv2_kernel,
+ * 2 hgemm_kernel; tile code; split-K slices; workgroups of the main launch}.  CPU tests of the dispatch policy use it. */
+int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin, int weight, int precision, int num_cu, int* out4);
 /* tuning knob: mode & 15 = 0 off / 1 auto (M >= min_m); mode >> 4 = tile variant bits (0: 8x16 pixels, 1: 16x16, 2: 16x16 below 16384
  * pixels, 4: wavefront sub-tile 64 pixels x 64 channels instead of the default 128 x 32) */
 int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m);

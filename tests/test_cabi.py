@@ -68,3 +68,45 @@ def test_null_handles_are_rejected_not_dereferenced():
     assert handle.cgd_op_gemm(None, None, 0, None, 0, None, 0, None, None, 0, 1, 1, 1, 1.0, 0, 1, None) == -3
     assert handle.cgd_cutouts_fwd(None, None, None, None, 1, 64, 64, 4, 224, 0, 0, None) == -3
     assert handle.cgd_sample_update(None, None, None, None, None, None, None, None, None, None, 1, 64, 64, None, 0, None) == -3
+
+
+def _plan(handle, **kw):
+    import ctypes as C
+    a = dict(conv=0, M=0, N=0, K=0, H=0, W=0, Cin=0, weight=0, precision=1, num_cu=256)
+    a.update(kw)
+    out = (C.c_int * 4)()
+    rc = handle.cgd_op_plan(a["conv"], a["M"], a["N"], a["K"], a["H"], a["W"], a["Cin"], a["weight"], a["precision"], a["num_cu"], out)
+    return rc, tuple(out)  # (kernel: 0 igemm / 1 hconv2 / 2 hgemm, tile code, split-K, workgroups)
+
+
+def test_dispatch_policy_of_the_contraction_launcher():
+    """Host logic of cgd_launch_gemm (csrc/gemm.hip), evaluated without a GPU through cgd_op_plan: which kernel, tile and split-K the
+    UNet / ViT layer shapes of BASELINE config 2 get on a 256-CU MI355X."""
+    handle = lib.load()
+
+    def conv(H, ci, co, **kw):
+        return _plan(handle, conv=1, M=H * H, N=co, H=H, W=H, Cin=ci, **kw)
+
+    # 3x3 convs: the halo kernel from 16^2 pixels up; split-K over 32-channel chunks once there are fewer tiles than CUs
+    # (about one workgroup per CU, >= 4 chunks per slice); 8x8 maps fall back to the 64x64 igemm tile
+    assert conv(256, 256, 256) == (0, (1, 512, 1, 1024))
+    assert conv(256, 512, 256) == (0, (1, 512, 1, 1024))
+    assert conv(128, 256, 256) == (0, (1, 512, 1, 256))
+    assert conv(64, 512, 512) == (0, (1, 512, 2, 256))
+    assert conv(32, 512, 512) == (0, (1, 512, 4, 128))
+    assert conv(16, 1024, 1024) == (0, (1, 512, 8, 128))
+    assert conv(8, 1024, 1024) == (0, (0, 64, 32, 512))
+    assert conv(256, 256, 256, precision=0) == (0, (0, 1256, 1, 512))  # exact-fp32 mode: the halo kernel is bf16-only
+    # weight GEMMs (ViT-B/32 on 16 cutouts = 800 tokens): hgemm with the cached fragment copy, split-K to about one workgroup per CU
+    assert _plan(handle, M=800, N=768, K=768, weight=1) == (0, (2, 513, 3, 126))
+    assert _plan(handle, M=800, N=2304, K=768, weight=1) == (0, (2, 513, 2, 252))
+    assert _plan(handle, M=800, N=3072, K=768, weight=1) == (0, (2, 513, 1, 168))
+    assert _plan(handle, M=800, N=768, K=3072, weight=1) == (0, (2, 513, 6, 252))
+    assert _plan(handle, M=65536, N=256, K=512, weight=1) == (0, (2, 513, 1, 1024))  # 1x1 skip conv at 256^2
+    # activations x activations (no persistent weight) and small M stay on the generic kernel
+    assert _plan(handle, M=800, N=768, K=768, weight=0)[1][0] == 0
+    assert _plan(handle, M=256, N=3072, K=1024, weight=1)[1][0] == 0
+    # fewer CUs -> fewer slices; argument validation happens before any launch
+    assert _plan(handle, conv=1, M=32 * 32, N=512, H=32, W=32, Cin=512, num_cu=64)[1][2] == 2
+    assert _plan(handle, M=800, N=768, K=770, weight=1)[0] == -2   # K must be a multiple of 4
+    assert _plan(handle, conv=1, M=64 * 64, N=64, H=64, W=64, Cin=48)[0] == -2  # conv Cin must be a multiple of 32
