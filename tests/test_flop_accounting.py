@@ -1,0 +1,71 @@
+"""The algorithmic work that bench.py / tests/bench_configs.py price their rates with (FLOP = 2 * (MAC_fwd + MAC_dgrad),
+MAC_dgrad = MAC_fwd + the attention matmuls once more, no weight gradients, no elementwise work) re-derived from the oracle networks
+with torch's FlopCounterMode on the meta device (no arithmetic is executed)."""
+import os
+import sys
+
+import pytest
+import torch as th
+from torch.utils.flop_counter import FlopCounterMode
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def macs(build, *shapes, call=None):
+    """(total GMAC, attention-matmul GMAC) of one forward of the module returned by build(), on the meta device."""
+    with th.device("meta"):
+        net = build().eval()
+        args = [th.empty(*s) if isinstance(s, tuple) else s for s in shapes]
+        with FlopCounterMode(display=False) as fc, th.no_grad():
+            (call or (lambda n, *a: n(*a)))(net, *args)
+    glob = {str(k): v for k, v in fc.get_flop_counts()["Global"].items()}
+    bmm = sum(v for k, v in glob.items() if "bmm" in k or "baddbmm" in k)
+    return fc.get_total_flops() / 2e9, bmm / 2e9
+
+
+def unet_macs(cfg, H, W):
+    from oracle import unet as ou
+    with th.device("meta"):
+        t, y = th.zeros(1), th.zeros(1, dtype=th.long)
+    return macs(lambda: ou.UNetModel(**cfg), (1, 3, H, W), t, y if cfg.get("num_classes") else None)
+
+
+def vit_macs(name):
+    from oracle import clip_vit as ocv
+    return macs(lambda: ocv.ClipImageModel(name), (1, 3, 224, 224), call=lambda n, x: n.encode_image(x))
+
+
+def test_headline_flop_per_step_matches_the_oracle_networks():
+    import bench
+    u_fwd, u_att = unet_macs(bench.UNET_256, 256, 256)
+    assert u_fwd == pytest.approx(1119.8, abs=0.1) and u_att == pytest.approx(6.09, abs=0.01)
+    v_fwd, v_att = vit_macs("ViT-B/32")
+    assert v_fwd == pytest.approx(4.409, abs=0.001)
+    u_dgrad, v_dgrad = u_fwd + u_att, v_fwd + v_att  # attention backward: 4 matmuls instead of 2, everything else 1:1
+    assert u_dgrad == pytest.approx(1125.9, abs=0.1) and v_dgrad == pytest.approx(4.455, abs=0.002)
+    flop = 2e9 * (u_fwd + u_dgrad) + 16 * 2e9 * (v_fwd + v_dgrad)
+    assert flop == pytest.approx(bench.FLOP_PER_STEP, rel=1e-3)  # 4.775 TFLOP per guided step (BASELINE config 2)
+
+
+def test_flop_per_step_of_the_other_configs():
+    from oracle import clip_resnet as ocr
+    from oracle import lpips_vgg as olp
+    from tests import bench_configs as bc
+    u256 = sum(unet_macs(bc.U256, 256, 256)) + unet_macs(bc.U256, 256, 256)[0]          # fwd + dgrad
+    # config 3: 32 cutouts through ViT-B/16
+    v16 = vit_macs("ViT-B/16")
+    c3 = 2e9 * (u256 + 32 * (2 * v16[0] + v16[1])) / 1e12
+    assert c3 == pytest.approx(bc.CONFIGS[3]["tflop"], rel=0.01)
+    # config 4: 512^2 UNet, 64 cutouts through ViT-B/32, LPIPS-VGG16 forward on x_in (the init image's features are cached) + dgrad
+    u512 = unet_macs(bc.U512, 512, 512)
+    v32 = vit_macs("ViT-B/32")
+    vgg = macs(lambda: olp.LpipsVGG(), (1, 3, 512, 512), call=lambda n, x: n.features(x))[0]
+    c4 = 2e9 * (2 * u512[0] + u512[1] + 64 * (2 * v32[0] + v32[1]) + 2 * vgg) / 1e12
+    assert c4 == pytest.approx(bc.CONFIGS[4]["tflop"], rel=0.03)
+    # config 5: 256x288 UNet, 16 cutouts through RN50 and ViT-L/14
+    u288 = unet_macs(bc.U256, 256, 288)
+    l14 = vit_macs("ViT-L/14")
+    rn = macs(lambda: ocr.ClipResNetImageModel("RN50"), (1, 3, 224, 224), call=lambda n, x: n.encode_image(x))
+    c5 = 2e9 * (2 * u288[0] + u288[1] + 16 * (2 * l14[0] + l14[1]) + 16 * (2 * rn[0] + rn[1])) / 1e12
+    assert c5 == pytest.approx(bc.CONFIGS[5]["tflop"], rel=0.03)
