@@ -69,3 +69,24 @@ def test_flop_per_step_of_the_other_configs():
     rn = macs(lambda: ocr.ClipResNetImageModel("RN50"), (1, 3, 224, 224), call=lambda n, x: n.encode_image(x))
     c5 = 2e9 * (2 * u288[0] + u288[1] + 16 * (2 * l14[0] + l14[1]) + 16 * (2 * rn[0] + rn[1])) / 1e12
     assert c5 == pytest.approx(bc.CONFIGS[5]["tflop"], rel=0.03)
+
+
+def test_launch_plan_agrees_with_the_committed_bench_line():
+    """tests/plan_dump.py (oracle shapes + the launcher's own selection code, both on the CPU) against what the GPU run recorded in
+    profiles/r1_bench_1gpu.json: the halo conv kernel gets 136 launches per guided step carrying 4.18 of the 4.775 TFLOP."""
+    import json
+    from tests import plan_dump
+    rows = plan_dump.step_plan()
+    hconv = [r for r in rows if r[6] == "hconv2"]
+    assert len(hconv) == 136 and all(r[1] == "conv3x3" and r[3] >= 256 for r in hconv)
+    gflop = sum(r[10] for r in hconv)
+    assert gflop == pytest.approx(4179.5, abs=0.5)
+    assert sum(1 for r in hconv if r[8] > 1) == 82  # 64^2 and smaller maps: split-K over channel chunks
+    with open(os.path.join(ROOT, "profiles", "r1_bench_1gpu.json")) as f:
+        roof = json.loads(f.read().strip().splitlines()[-1])["roofline"]
+    assert roof["launches_per_step"] == pytest.approx(136.0)
+    assert roof["flop_per_launch"] * roof["launches_per_step"] == pytest.approx(gflop * 1e9, rel=1e-3)
+    # every ViT linear (16 cutouts = 800 token rows) goes to the weight GEMM kernel; the 8x8-pixel convs and M = 1 embeddings do not
+    vit = [r for r in rows if r[0] == "vit" and r[1] == "linear" and r[3] == 800]
+    assert len(vit) == 96 and all(r[6] == "hgemm" for r in vit)
+    assert all(r[6] == "igemm" for r in rows if r[1] == "conv3x3" and r[3] == 64 and r[7] != 0)
