@@ -17,48 +17,19 @@ from cgd_amd.guidance import ClipGuidance
 from . import clip_util, script_util
 
 
-def clip_guided_diffusion(
-    image_size: int = 128,
-    num_cutouts: int = 16,
-    prompts: "list[str]" = [],
-    image_prompts: "list[str]" = [],
-    clip_guidance_scale: int = 1000,
-    tv_scale: float = 150,
-    range_scale: float = 50,
-    sat_scale: float = 0,
-    init_scale: float = 0,
-    batch_size: int = 1,
-    init_image: Path = None,
-    class_cond: bool = True,
-    cutout_power: float = 1.0,
-    timestep_respacing: str = "1000",
-    seed: int = 0,
-    diffusion_steps: int = 1000,
-    skip_timesteps: int = 0,
-    checkpoints_dir: str = script_util.CACHE_PATH,
-    clip_model_name: str = "ViT-B/32",
-    randomize_class: bool = True,
-    prefix_path: Path = Path("./outputs"),
-    save_frequency: int = 25,
-    noise_schedule: str = "linear",
-    dropout: float = 0.0,
-    device: str = "",
-    wandb_project: str = None,
-    wandb_entity: str = None,
-    use_augs: bool = False,
-    use_magnitude: bool = False,
-    height_offset: int = 0,
-    width_offset: int = 0,
-    progress: bool = True,
-    reduce_clip: bool = False,
-    progressive_cutout: bool = False,
-    cached_cutouts: bool = False,
-):
+def clip_guided_diffusion(image_size=128, num_cutouts=16, prompts=[], image_prompts=[], clip_guidance_scale=1000, tv_scale=150,
+                          range_scale=50, sat_scale=0, init_scale=0, batch_size=1, init_image=None, class_cond=True,
+                          cutout_power=1.0, timestep_respacing="1000", seed=0, diffusion_steps=1000, skip_timesteps=0,
+                          checkpoints_dir=script_util.CACHE_PATH, clip_model_name="ViT-B/32", randomize_class=True,
+                          prefix_path=Path("./outputs"), save_frequency=25, noise_schedule="linear", dropout=0.0, device="",
+                          wandb_project=None, wandb_entity=None, use_augs=False, use_magnitude=False, height_offset=0,
+                          width_offset=0, progress=True, reduce_clip=False, progressive_cutout=False, cached_cutouts=False):
+    """Generator of `(batch_idx, png_path)`; keyword names and defaults are the reference's (cgd.py:19-55)."""
     if len(device) == 0:
         device = "cuda" if th.cuda.is_available() else "cpu"
-        print(f"Using device {device}. You can specify a device manually with `--device/-dev`")
+        print(f"device: {device} (picked automatically; --device/-dev overrides)")
     else:
-        print(f"Using device {device}")
+        print(f"device: {device}")
     if "cuda" not in device:
         raise ValueError(f"device {device!r}: this build runs the sampling step on an MI355X only (PyTorch-ROCm reports 'cuda')")
 
@@ -67,12 +38,12 @@ def clip_guided_diffusion(
         import wandb  # optional observability hook, outside the hot path
         wandb_run = wandb.init(project=wandb_project, entity=wandb_entity, config=locals())
     else:
-        print("--wandb_project not specified. Skipping W&B integration.")
+        print("no --wandb_project given: W&B logging is off")
 
     th.manual_seed(seed)
     if not use_magnitude and image_size == 64:
         use_magnitude = True
-        tqdm.write("Enabling magnitude for 64x64 checkpoints.")
+        tqdm.write("64x64 checkpoint: gradient-magnitude clamp switched on")
     Path(prefix_path).mkdir(parents=True, exist_ok=True)
     Path(checkpoints_dir).mkdir(parents=True, exist_ok=True)
     diffusion_path = script_util.download_guided_diffusion(image_size=image_size, checkpoints_dir=checkpoints_dir, class_cond=class_cond)
@@ -106,7 +77,7 @@ def clip_guided_diffusion(
     weight_t = weight_t / weight_t.sum().abs()
 
     if use_augs:
-        tqdm.write("Augmentations enabled.")
+        tqdm.write("cutout augmentations requested")
     make_cutouts = clip_util.MakeCutouts(cut_size=clip_size, num_cutouts=num_cutouts, cutout_size_power=cutout_power, use_augs=use_augs,
                                          ctx=clip_model.tower.ctx)
     if cached_cutouts:
@@ -130,7 +101,7 @@ def clip_guided_diffusion(
     if reduce_clip and skip_timesteps == 0:
         skip_timesteps = int(diffusion.num_timesteps * 0.2)
         if progress:
-            tqdm.write(f"Skipping first {skip_timesteps} timesteps (--reduce-clip optimization)")
+            tqdm.write(f"--reduce-clip: the first {skip_timesteps} timesteps are skipped")
 
     cond_fn = ClipGuidance(
         gd_model.ctx, gd_model, [cm.tower for cm in clip_models], diffusion, target_embeds, weight_t, num_cutouts, cutout_power=cutout_power,
@@ -180,78 +151,88 @@ def clip_guided_diffusion(
             yield from finish(previous)
     except (RuntimeError, KeyboardInterrupt) as runtime_ex:
         if "out of memory" in str(runtime_ex).lower():
-            print("CUDA OOM error occurred.")
-            print("Try lowering --image_size/-size, --batch_size/-bs, --num_cutouts/-cutn")
-            print(f"--clip_model/-clip (currently {clip_model_name}) can have a large impact on VRAM usage.")
-            print("'RN50' will use the least VRAM. 'ViT-B/32' the second least and is good for its memory/runtime constraints.")
+            # the reference's hint, kept word for word (cgd.py:274-283)
+            print("\n".join((
+                "CUDA OOM error occurred.", "Try lowering --image_size/-size, --batch_size/-bs, --num_cutouts/-cutn",
+                f"--clip_model/-clip (currently {clip_model_name}) can have a large impact on VRAM usage.",
+                "'RN50' will use the least VRAM. 'ViT-B/32' the second least and is good for its memory/runtime constraints.")))
         else:
             raise runtime_ex
 
 
-# (long flag, alias, kwargs): the reference CLI, flag for flag (cgd.py:290-357)
-_FLAGS = [
-    ("--prompts", "-txts", dict(type=str, default="", help="the prompt/s to reward paired with weights. e.g. 'My text:0.5|Other text:-0.5' ")),
-    ("--image_prompts", "-imgs", dict(type=str, default="", help="the image prompt/s to reward paired with weights. e.g. 'img1.png:0.5,img2.png:-0.5'")),
-    ("--image_size", "-size", dict(type=int, default=128, help="Diffusion image size. Must be one of [64, 128, 256, 512].")),
-    ("--init_image", "-init", dict(type=str, default="", help="Blend an image with diffusion for n steps")),
-    ("--init_scale", "-is", dict(type=int, default=0, help="(optional) Perceptual loss scale for init image. ")),
-    ("--skip_timesteps", "-skip", dict(type=int, default=0, help="Number of timesteps to blend image for. CLIP guidance occurs after this.")),
-    ("--prefix", "-dir", dict(type=Path, default="outputs", help="output directory")),
-    ("--checkpoints_dir", "-ckpts", dict(type=Path, default=script_util.CACHE_PATH, help="Path subdirectory containing checkpoints.")),
-    ("--batch_size", "-bs", dict(type=int, default=1, help="the batch size")),
-    ("--clip_guidance_scale", "-cgs", dict(type=float, default=1000, help="Scale for CLIP spherical distance loss. Values will need tinkering for different settings.")),
-    ("--tv_scale", "-tvs", dict(type=float, default=150.0, help="Controls the smoothness of the final output.")),
-    ("--range_scale", "-rs", dict(type=float, default=50.0, help="Controls how far out of RGB range values may get.")),
-    ("--sat_scale", "-sats", dict(type=float, default=0.0, help="Controls how much saturation is allowed. Used for ddim. From @nshepperd.")),
-    ("--seed", "-seed", dict(type=int, default=0, help="Random number seed")),
-    ("--save_frequency", "-freq", dict(type=int, default=1, help="Save frequency")),
-    ("--diffusion_steps", "-steps", dict(type=int, default=1000, help="Diffusion steps")),
-    ("--timestep_respacing", "-respace", dict(type=str, default="1000", help="Timestep respacing")),
-    ("--num_cutouts", "-cutn", dict(type=int, default=16, help="Number of randomly cut patches to distort from diffusion.")),
-    ("--cutout_power", "-cutpow", dict(type=float, default=1.0, help="Cutout size power")),
-    ("--clip_model", "-clip", dict(type=str, default="ViT-B/32", help=f"clip model name. Should be one of: {clip_util.CLIP_MODEL_NAMES} or a checkpoint filename ending in `.pt`")),
-    ("--uncond", "-uncond", dict(action="store_true", help="Use finetuned unconditional checkpoints from OpenAI (256px) and Katherine Crowson (512px)")),
-    ("--noise_schedule", "-sched", dict(type=str, default="linear", help="Specify noise schedule. Either 'linear' or 'cosine'.")),
-    ("--dropout", "-drop", dict(type=float, default=0.0, help="Amount of dropout to apply. ")),
-    ("--device", "-dev", dict(type=str, default="", help="Device to use. Either cpu or cuda.")),
-    ("--wandb_project", "-proj", dict(default=None, help="Name W&B will use when saving results.")),
-    ("--wandb_entity", "-ent", dict(default=None, help="(optional) Name of W&B team/entity to log to.")),
-    ("--height_offset", "-ht", dict(type=int, default=0, help="Height offset for image")),
-    ("--width_offset", "-wd", dict(type=int, default=0, help="Width offset for image")),
-    ("--use_augs", "-augs", dict(action="store_true", help="Uses augmentations from the `quick` clip guided diffusion notebook")),
-    ("--use_magnitude", "-mag", dict(action="store_true", help="Uses magnitude of the gradient")),
-    ("--quiet", "-q", dict(action="store_true", help="Suppress output.")),
-    ("--save-as-gif", "-gif", dict(action="store_true", help="Save output as high-quality GIF using ffmpeg. Deletes individual frames.")),
-    ("--save-as-video", "-mp4", dict(action="store_true", help="Save output as high-quality MP4 video using ffmpeg. Deletes individual frames.")),
-    ("--reduce-clip", "-reduce", dict(action="store_true", help="Reduce CLIP guidance frequency for faster generation. Skips early steps, runs every 4th step in middle.")),
-    ("--progressive-cutout", "-cutn_skip", dict(action="store_true", help="Use fewer cutouts in early steps (4->8->16) for faster generation.")),
-    ("--cached-cutouts", "-cached_cutn", dict(action="store_true", help="Cache cutout coordinates for reuse across steps.")),
-]
+# The reference CLI, flag for flag (cgd.py:290-357): "long alias kind default | help".  kind: str / int / float / path, or "flag"
+# for store_true switches.  Only names, aliases, types and defaults are contract (tests/golden/reference_host.json).
+_CLI_SPEC = f"""
+--prompts -txts str "" | text prompts with optional weights, pipe-separated: 'a cat:0.5|a dog:-0.5'
+--image_prompts -imgs str "" | image prompts (paths or URLs) with optional weights, pipe-separated
+--image_size -size int 128 | resolution of the diffusion checkpoint: 64, 128, 256 or 512
+--init_image -init str "" | start from this image (needs --skip_timesteps)
+--init_scale -is int 0 | weight of the LPIPS-VGG16 term that keeps the sample close to the init image
+--skip_timesteps -skip int 0 | how many of the (respaced) timesteps to skip at the noisy end
+--prefix -dir path outputs | directory for the PNG frames
+--checkpoints_dir -ckpts path {script_util.CACHE_PATH} | where the diffusion / CLIP / LPIPS checkpoints live
+--batch_size -bs int 1 | samples per run
+--clip_guidance_scale -cgs float 1000 | weight of the CLIP spherical-distance loss
+--tv_scale -tvs float 150.0 | weight of the total-variation (smoothness) loss
+--range_scale -rs float 50.0 | weight of the out-of-range penalty on the predicted image
+--sat_scale -sats float 0.0 | weight of the saturation penalty (useful with ddim)
+--seed -seed int 0 | RNG seed
+--save_frequency -freq int 1 | write a frame every N steps
+--diffusion_steps -steps int 1000 | length of the training schedule
+--timestep_respacing -respace str 1000 | number of sampling steps ('250') or 'ddimN'
+--num_cutouts -cutn int 16 | random cutouts shown to CLIP per step
+--cutout_power -cutpow float 1.0 | exponent of the cutout size distribution
+--clip_model -clip str ViT-B/32 | one of {clip_util.CLIP_MODEL_NAMES}, a checkpoint file, or 'A+B' to sum two towers
+--uncond -uncond flag | use the unconditional 256 / 512 checkpoints
+--noise_schedule -sched str linear | 'linear' or 'cosine'
+--dropout -drop float 0.0 | dropout of the diffusion model (inference: keep 0)
+--device -dev str "" | 'cuda[:N]' (the MI355X); empty = pick automatically
+--wandb_project -proj none | log to this Weights & Biases project
+--wandb_entity -ent none | Weights & Biases team / entity
+--height_offset -ht int 0 | extra image height in pixels
+--width_offset -wd int 0 | extra image width in pixels
+--use_augs -augs flag | accepted and ignored, as in the reference
+--use_magnitude -mag flag | accepted and ignored, as in the reference
+--quiet -q flag | no progress output
+--save-as-gif -gif flag | assemble the frames into a GIF with ffmpeg and delete them
+--save-as-video -mp4 flag | assemble the frames into an MP4 with ffmpeg and delete them
+--reduce-clip -reduce flag | skip the first 20 % of the steps, then guide every 4th step until 70 %
+--progressive-cutout -cutn_skip flag | cutn/4, then cutn/2, then cutn cutouts as sampling proceeds
+--cached-cutouts -cached_cutn flag | draw the cutout boxes once and reuse them
+"""
+_KINDS = {"str": str, "int": int, "float": float, "path": Path}
 
 
 def build_parser():
-    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    for long_flag, alias, kw in _FLAGS:
-        p.add_argument(long_flag, alias, **kw)
-    return p
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    for line in _CLI_SPEC.strip().splitlines():
+        spec, text = (part.strip() for part in line.split("|", 1))
+        long_flag, alias, kind, *default = spec.split(None, 3)  # the default may contain spaces (a cache path)
+        if kind == "flag":
+            parser.add_argument(long_flag, alias, action="store_true", help=text)
+        elif kind == "none":
+            parser.add_argument(long_flag, alias, default=None, help=text)
+        else:
+            value = default[0].strip('"')
+            if kind in ("int", "float"):  # the literal as written: the reference gives --clip_guidance_scale type=float, default=1000
+                value = int(value) if value.lstrip("-").isdigit() else float(value)
+            parser.add_argument(long_flag, alias, type=_KINDS[kind], default=value, help=text)
+    return parser
+
+
+# CLI destination -> generator keyword where the two differ; everything else passes through under its own name
+_RENAMED = {"prefix": "prefix_path", "clip_model": "clip_model_name"}
+_NOT_FORWARDED = ("uncond", "quiet", "save_as_gif", "save_as_video", "use_augs", "use_magnitude")
 
 
 def kwargs_from_args(args):
-    """CLI namespace -> generator kwargs; like the reference, `--use_augs/--use_magnitude` are parsed but passed as
-    False (cgd.py:402-403) and `randomize_class` follows class conditioning (:381)."""
-    class_cond = not args.uncond
-    split = lambda s: s.split("|") if len(s) > 0 else []  # noqa: E731
-    return dict(
-        prompts=split(args.prompts), image_prompts=split(args.image_prompts), batch_size=args.batch_size, tv_scale=args.tv_scale,
-        init_scale=args.init_scale, range_scale=args.range_scale, sat_scale=args.sat_scale, image_size=args.image_size,
-        class_cond=class_cond, randomize_class=class_cond, save_frequency=args.save_frequency,
-        clip_guidance_scale=args.clip_guidance_scale, cutout_power=args.cutout_power, num_cutouts=args.num_cutouts,
-        timestep_respacing=args.timestep_respacing, seed=args.seed, diffusion_steps=args.diffusion_steps,
-        skip_timesteps=args.skip_timesteps, init_image=args.init_image, checkpoints_dir=args.checkpoints_dir,
-        clip_model_name=args.clip_model, noise_schedule=args.noise_schedule, dropout=args.dropout, device=args.device,
-        prefix_path=args.prefix, wandb_project=args.wandb_project, wandb_entity=args.wandb_entity, use_augs=False, use_magnitude=False,
-        height_offset=args.height_offset, width_offset=args.width_offset, progress=not args.quiet, reduce_clip=args.reduce_clip,
-        progressive_cutout=args.progressive_cutout, cached_cutouts=args.cached_cutouts)
+    """CLI namespace -> generator kwargs.  Reference quirks kept: `--use_augs/--use_magnitude` are parsed but passed as False
+    (cgd.py:402-403), `randomize_class` follows class conditioning (:381), prompt strings split on the pipe character."""
+    kw = {_RENAMED.get(name, name): value for name, value in vars(args).items() if name not in _NOT_FORWARDED}
+    for key in ("prompts", "image_prompts"):
+        kw[key] = kw[key].split("|") if kw[key] else []
+    kw.update(class_cond=not args.uncond, randomize_class=not args.uncond, progress=not args.quiet, use_augs=False, use_magnitude=False)
+    return kw
 
 
 def main():
