@@ -11,8 +11,9 @@ Pinned against golden vectors produced by importing the real reference modules
 (tests/golden/make_golden.py -> tests/golden/*.npz; tests/test_oracle_golden.py), and `make_cond_fn` against trajectories
 recorded while the REAL reference generator and its cond_fn closure (/root/reference/cgd/cgd.py, unmodified) drove the oracle
 networks through its own load_guided_diffusion / load_clip seams (tests/golden/make_golden_condfn.py -> reference_condfn.npz|json):
-bit-exact on the build machine over five cases (weighted prompts + magnitude + saturation, B == P broadcast with DDIM / cosine,
-non-square + reduce_clip + progressive_cutout + cached_cutouts, skip_timesteps offset quirk, non-default scales and cutout power).
+bit-exact on the build machine over six cases (weighted prompts + magnitude + saturation, B == P broadcast with DDIM / cosine,
+non-square + reduce_clip + progressive_cutout + cached_cutouts, skip_timesteps offset quirk, non-default scales and cutout power,
+init image + skip_timesteps + the LPIPS term with the oracle's LPIPS-VGG16 in place of the lpips package).
 """
 import torch as th
 import torch.nn.functional as F

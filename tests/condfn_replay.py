@@ -20,7 +20,22 @@ CASES = {
                                                 progressive_cutout=True, cached_cutouts=True, steps=6),
     "skip_without_init_offset_quirk": dict(prompts=["a tree:1.5"], skip_timesteps=10, height_offset=16, steps=3, seed=11),
     "tv_range_scales": dict(prompts=["x"], clip_guidance_scale=5, tv_scale=1e-5, range_scale=7.0, cutout_power=0.5, steps=2, seed=5),
+    # init image + LPIPS term (cgd.py:111-119,147-148,220-224): the PNG is written from init_image_array() by whoever runs the case
+    "init_image_lpips_skip": dict(prompts=["a lake"], init_image="<init.png>", init_scale=800, skip_timesteps=12, steps=3, seed=7),
 }
+
+
+def init_image_array():
+    import numpy as np
+    return np.random.default_rng(0).integers(0, 256, (40, 56, 3), dtype=np.uint8)
+
+
+def build_lpips():
+    from oracle import lpips_vgg as olp
+    m = olp.synthetic_init_(olp.LpipsVGG()).eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m
 
 
 def build_models():
@@ -67,6 +82,14 @@ def replay_with_oracle(name):
     if kw.get("cached_cutouts"):
         mk.cache_coordinates(size + kw.get("width_offset", 0), size + kw.get("height_offset", 0))
     diff = od.create_gaussian_diffusion(kw.get("diffusion_steps", 1000), kw["noise_schedule"], kw["timestep_respacing"], False)
+    init_tensor, lp = None, None
+    if kw.get("init_image"):  # cgd.py:111-119: PIL resize to (image_size, image_size), [0,1] -> [-1,1]
+        import numpy as np
+        from PIL import Image
+        pil = Image.fromarray(init_image_array()).convert("RGB").resize((size, size))
+        init_tensor = th.from_numpy(np.array(pil)).float().div(255).permute(2, 0, 1).unsqueeze(0).mul(2).sub(1)
+        if kw.get("init_scale", 0) != 0:
+            lp = build_lpips()
     skip = kw.get("skip_timesteps", 0)
     if kw.get("reduce_clip") and skip == 0:
         skip = int(diff.num_timesteps * 0.2)
@@ -74,11 +97,12 @@ def replay_with_oracle(name):
                                   clip_guidance_scale=kw.get("clip_guidance_scale", 1000), tv_scale=kw.get("tv_scale", 150),
                                   range_scale=kw.get("range_scale", 50), sat_scale=kw.get("sat_scale", 0),
                                   use_magnitude=kw.get("use_magnitude", False) or size == 64, reduce_clip=kw.get("reduce_clip", False),
-                                  progressive_cutout=kw.get("progressive_cutout", False), cached_cutouts=kw.get("cached_cutouts", False))
+                                  progressive_cutout=kw.get("progressive_cutout", False), cached_cutouts=kw.get("cached_cutouts", False),
+                                  lpips_model=lp, init_tensor=init_tensor, init_scale=kw.get("init_scale", 0))
     loop = diff.ddim_sample_loop_progressive if kw["timestep_respacing"].startswith("ddim") else diff.p_sample_loop_progressive
     shape = (B, 3, size + kw.get("height_offset", 0), size + kw.get("width_offset", 0))
     gen = loop(unet, shape, clip_denoised=False, model_kwargs={"y": th.zeros([B], dtype=th.long)}, cond_fn=cond, skip_timesteps=skip,
-               init_image=None, randomize_class=True, cond_fn_with_grad=True, device="cpu")
+               init_image=init_tensor, randomize_class=True, cond_fn_with_grad=True, device="cpu")
     state["current_timestep"] = diff.num_timesteps - 1
     out = []
     for k, o in enumerate(gen):

@@ -44,7 +44,12 @@ def main():
         from PIL import Image
         return Image.fromarray(t.mul(255).byte().permute(1, 2, 0).numpy())
 
-    tvt.Normalize, tvf.to_pil_image = Normalize, to_pil_image
+    class ToTensor:  # torchvision.transforms.ToTensor on an RGB PIL image
+        def __call__(self, pil):
+            return th.from_numpy(np.array(pil)).permute(2, 0, 1).float().div(255)
+
+    tvt.Normalize, tvt.ToTensor, tvf.to_pil_image = Normalize, ToTensor, to_pil_image
+    sys.modules["lpips"].LPIPS = lambda net: cr.build_lpips()  # the oracle's LPIPS-VGG16 with seeded synthetic weights
     sys.path.insert(0, make_golden.REF)
     ref = importlib.import_module("cgd.cgd")
     assert ref.__file__.startswith(make_golden.REF), ref.__file__
@@ -92,6 +97,10 @@ def main():
         cwd = os.getcwd()
         with tempfile.TemporaryDirectory() as d:
             os.chdir(d)  # the reference writes ./current.png
+            if kw.get("init_image"):
+                from PIL import Image
+                Image.fromarray(cr.init_image_array()).save(os.path.join(d, "init.png"))
+                kw = dict(kw, init_image=os.path.join(d, "init.png"))
             try:
                 gen = ref.clip_guided_diffusion(prefix_path=os.path.join(d, "out"), checkpoints_dir=os.path.join(d, "ckpt"), **kw)
                 yielded = []
@@ -103,7 +112,7 @@ def main():
                 os.chdir(cwd)
         fx[f"{name}/sample"] = th.stack([s for s, _ in recorded[:steps]]).numpy()
         fx[f"{name}/pred_xstart"] = th.stack([x for _, x in recorded[:steps]]).numpy()
-        meta[name] = {"kwargs": {k: v for k, v in kw.items()}, "steps": steps, "yielded": yielded[:steps * kw["batch_size"]],
+        meta[name] = {"kwargs": {k: (v if k != "init_image" else "<init.png>") for k, v in kw.items()}, "steps": steps, "yielded": yielded[:steps * kw["batch_size"]],
                       "loss_lines": [ln for ln in lines if "CLIP Loss" in ln]}
         # self-check: the oracle replay of the same case, here and now
         mine = cr.replay_with_oracle(name)
