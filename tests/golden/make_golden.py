@@ -126,6 +126,9 @@ def main():
     import inspect
     sig = inspect.signature(ref_cgd.clip_guided_diffusion)
     meta["generator_signature"] = [[k, repr(p.default)] for k, p in sig.parameters.items()]
+    # per-checkpoint UNet flags (data/diffusion_model_flags.py): they fix every layer shape of the supported models
+    lookup = importlib.import_module("data.diffusion_model_flags").DIFFUSION_LOOKUP
+    meta["diffusion_lookup"] = {cond: {str(size): entry for size, entry in table.items()} for cond, table in lookup.items()}
     with open(os.path.join(OUT, "reference_host.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote", os.path.join(OUT, "reference_ops.npz"), os.path.join(OUT, "reference_host.json"))

@@ -161,3 +161,11 @@ def test_cached_cutouts_reuse_and_argument_order_quirk():
     # boxes cached for (288, 256) may stick out of a (256, 288) image along H: the crop is truncated like a Python slice
     geo = dg.crop_geometry(expect, 256, 288)
     assert all(0 <= oy and 0 <= ox and h <= 256 - oy and w <= 288 - ox for (oy, ox, h, w) in geo)
+
+
+def test_checkpoint_flag_table_equals_the_reference_data_file():
+    """cgd/model_flags.py (base + per-checkpoint deltas) against a dump of the real /root/reference/data/diffusion_model_flags.py
+    (tests/golden/make_golden.py): urls, file names and every UNet flag of the six published checkpoints."""
+    from cgd import model_flags
+    mine = {cond: {str(size): entry for size, entry in table.items()} for cond, table in model_flags.DIFFUSION_LOOKUP.items()}
+    assert mine == HOST["diffusion_lookup"]
