@@ -129,6 +129,32 @@ def main():
     # per-checkpoint UNet flags (data/diffusion_model_flags.py): they fix every layer shape of the supported models
     lookup = importlib.import_module("data.diffusion_model_flags").DIFFUSION_LOOKUP
     meta["diffusion_lookup"] = {cond: {str(size): entry for size, entry in table.items()} for cond, table in lookup.items()}
+    # load_guided_diffusion (script_util.py:281-324): the config the REAL function hands to create_model_and_diffusion (stubbed;
+    # guided_diffusion's own defaults are an empty dict here, so this is checkpoint flags + user-level overrides)
+    captured = []
+
+    class Captured(Exception):
+        pass
+
+    def fake_create(**cfg):
+        captured.append(cfg)
+        raise Captured
+
+    script_util.create_model_and_diffusion = fake_create
+    configs = []
+    for size, cond, over in [(64, True, dict(diffusion_steps=1000, timestep_respacing="25", noise_schedule="cosine", dropout=0.0)),
+                             (128, True, dict(diffusion_steps=1000, timestep_respacing="ddim50", noise_schedule="linear", dropout=0.0)),
+                             (256, True, dict(diffusion_steps=1000, timestep_respacing="250", noise_schedule="linear", dropout=0.1)),
+                             (512, True, dict(diffusion_steps=500, timestep_respacing="1000", noise_schedule="linear", dropout=0.0)),
+                             (256, False, dict(diffusion_steps=1000, timestep_respacing="1000", noise_schedule="linear", dropout=0.0)),
+                             (512, False, dict(diffusion_steps=1000, timestep_respacing="100", noise_schedule="cosine", dropout=0.0))]:
+        try:
+            script_util.load_guided_diffusion(checkpoint_path="unused.pt", image_size=size, class_cond=cond, use_fp16=(size != 64),
+                                              device="cpu", **over)
+        except Captured:
+            pass
+        configs.append({"image_size": size, "class_cond": cond, "use_fp16": size != 64, "overrides": over, "config": captured[-1]})
+    meta["model_configs"] = configs
     with open(os.path.join(OUT, "reference_host.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote", os.path.join(OUT, "reference_ops.npz"), os.path.join(OUT, "reference_host.json"))

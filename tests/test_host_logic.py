@@ -169,3 +169,14 @@ def test_checkpoint_flag_table_equals_the_reference_data_file():
     from cgd import model_flags
     mine = {cond: {str(size): entry for size, entry in table.items()} for cond, table in model_flags.DIFFUSION_LOOKUP.items()}
     assert mine == HOST["diffusion_lookup"]
+
+
+def test_model_config_equals_what_the_reference_passes_to_create_model():
+    """script_util.model_config against the kwargs the REAL load_guided_diffusion (script_util.py:281-324) handed to a stubbed
+    create_model_and_diffusion: per-checkpoint flags overridden by the user-level diffusion_steps / timestep_respacing / use_fp16 /
+    noise_schedule / dropout, for all six checkpoints."""
+    from cgd import script_util
+    assert len(HOST["model_configs"]) == 6
+    for c in HOST["model_configs"]:
+        mine = script_util.model_config(c["image_size"], c["class_cond"], use_fp16=c["use_fp16"], **c["overrides"])
+        assert {k: mine[k] for k in c["config"]} == c["config"], (c["image_size"], c["class_cond"])
