@@ -155,6 +155,14 @@ def main():
             pass
         configs.append({"image_size": size, "class_cond": cond, "use_fp16": size != 64, "overrides": over, "config": captured[-1]})
     meta["model_configs"] = configs
+    # CLIP checkpoint table (clip_util.py:17-42): what download_clip_model asks script_util.download for, and the normalisation constants
+    clip_util = importlib.import_module("cgd.clip_util")
+    asked = []
+    script_util.download = lambda url, filename, root=None, **k: asked.append([url, filename, os.path.relpath(root, script_util.CACHE_PATH)]) or "x"
+    for name in clip_util.CLIP_MODEL_URLS:
+        clip_util.download_clip_model(name)
+    meta["clip_models"] = {"names": list(clip_util.CLIP_MODEL_NAMES), "downloads": dict(zip(clip_util.CLIP_MODEL_URLS, asked)),
+                           "normalize_mean": list(clip_util.CLIP_NORMALIZE.mean), "normalize_std": list(clip_util.CLIP_NORMALIZE.std)}
     with open(os.path.join(OUT, "reference_host.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote", os.path.join(OUT, "reference_ops.npz"), os.path.join(OUT, "reference_host.json"))

@@ -180,3 +180,18 @@ def test_model_config_equals_what_the_reference_passes_to_create_model():
     for c in HOST["model_configs"]:
         mine = script_util.model_config(c["image_size"], c["class_cond"], use_fp16=c["use_fp16"], **c["overrides"])
         assert {k: mine[k] for k in c["config"]} == c["config"], (c["image_size"], c["class_cond"])
+
+
+def test_clip_checkpoint_table_and_normalisation_equal_the_reference(monkeypatch):
+    """clip_util.CLIP_MODEL_NAMES / CLIP_MODEL_URLS / download_clip_model / CLIP_NORMALIZE against a dump of the real module."""
+    import os
+    from cgd import clip_util, script_util
+    ref = HOST["clip_models"]
+    assert list(clip_util.CLIP_MODEL_NAMES) == ref["names"]
+    assert list(clip_util.CLIP_NORMALIZE.mean) == ref["normalize_mean"] and list(clip_util.CLIP_NORMALIZE.std) == ref["normalize_std"]
+    asked = []
+    monkeypatch.delenv("CGD_SYNTHETIC_WEIGHTS", raising=False)
+    monkeypatch.setattr(script_util, "download", lambda url, filename, root=None, **k: asked.append([url, filename, os.path.relpath(root, script_util.CACHE_PATH)]) or "x")
+    for name in clip_util.CLIP_MODEL_URLS:
+        clip_util.download_clip_model(name)
+    assert dict(zip(clip_util.CLIP_MODEL_URLS, asked)) == ref["downloads"]
