@@ -28,6 +28,9 @@ import torch.distributed as dist  # noqa: E402
 
 UNET_256 = dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64)
 FLOP_PER_STEP = 4.775e12  # UNet 2*(1119.8+1125.9) GMAC + CLIP 16*2*(4.409+4.455) GMAC
+# mean algorithmic HBM bytes of a halo-conv launch in this workload: 4 B * M * (Cin + Cout) activations + 4 B * 9 * Cin * Cout packed
+# weights, averaged over the 136 launches of a step (tests/plan_dump.py; checked by tests/test_flop_accounting.py)
+HCONV_ALGO_BYTES_PER_LAUNCH = 55.27e6
 
 
 def build_device(ctx, rank, world, precision, clip_name="ViT-B/32"):
@@ -208,6 +211,7 @@ def main():
         nprod = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
         roof = {"bound": "mfma", "kernel": f"hconv2_kernel<{args.precision}> (halo-staged 3x3 conv, hconv.hip)", "achieved": round(ach, 2),
                 "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": pmc_traffic("hconv2_kernel"),
+                "algorithmic_bytes_per_launch": HCONV_ALGO_BYTES_PER_LAUNCH,
                 "launches_per_step": h_n / args.steps, "avg_launch_us": round(h_ms * 1e3 / max(h_n, 1), 2),
                 "flop_per_launch": h_flop / max(h_n, 1), "kernel_time_share": round(h_ms * 1e-3 / dt, 4),
                 "mfma_products_per_flop": nprod, "mfma_issue_frac": round(nprod * ach / 2500.0, 4),

@@ -82,6 +82,9 @@ def test_launch_plan_agrees_with_the_committed_bench_line():
     gflop = sum(r[10] for r in hconv)
     assert gflop == pytest.approx(4179.5, abs=0.5)
     assert sum(1 for r in hconv if r[8] > 1) == 82  # 64^2 and smaller maps: split-K over channel chunks
+    import bench
+    algo_bytes = sum(4 * r[3] * (r[5][2] + r[4]) + 4 * 9 * r[5][2] * r[4] for r in hconv) / len(hconv)
+    assert algo_bytes == pytest.approx(bench.HCONV_ALGO_BYTES_PER_LAUNCH, rel=1e-3)
     with open(os.path.join(ROOT, "profiles", "r1_bench_1gpu.json")) as f:
         roof = json.loads(f.read().strip().splitlines()[-1])["roofline"]
     assert roof["launches_per_step"] == pytest.approx(136.0)
