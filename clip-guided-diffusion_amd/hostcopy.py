@@ -24,16 +24,17 @@ class HostCopy:
 
     def __init__(self, t):
         t = t.detach()
-        produced = th.cuda.Event()
-        produced.record()  # on the current (compute) stream: everything `t` depends on has been enqueued
-        side = side_stream(t.device)
-        self.host = th.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        with th.cuda.stream(side):
-            side.wait_event(produced)
-            self.host.copy_(t, non_blocking=True)
-            self.done = th.cuda.Event()
-            self.done.record()
-        t.record_stream(side)  # the caching allocator must not hand t's block out before the side-stream copy has read it
+        with th.cuda.device(t.device):  # events and streams of the tensor's GPU, whatever the caller's current device is
+            produced = th.cuda.Event()
+            produced.record()  # on the current (compute) stream: everything `t` depends on has been enqueued
+            side = side_stream(t.device)
+            self.host = th.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            with th.cuda.stream(side):
+                side.wait_event(produced)
+                self.host.copy_(t, non_blocking=True)
+                self.done = th.cuda.Event()
+                self.done.record()
+            t.record_stream(side)  # the caching allocator must not hand t's block out before the side-stream copy has read it
         self._src = t
 
     def get(self):
