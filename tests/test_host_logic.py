@@ -195,3 +195,48 @@ def test_clip_checkpoint_table_and_normalisation_equal_the_reference(monkeypatch
     for name in clip_util.CLIP_MODEL_URLS:
         clip_util.download_clip_model(name)
     assert dict(zip(clip_util.CLIP_MODEL_URLS, asked)) == ref["downloads"]
+
+
+def test_download_returns_target_full_path(tmp_path, monkeypatch):
+    """reference test.py:36-42 (`script_util.download` returns the full target path and the file exists) without a network: the HTTP
+    layer is a fake; plus the cache hit, the retry-then-fail path (script_util.py:214-267) and download_guided_diffusion's lookup."""
+    import requests
+    from cgd import script_util
+    calls = []
+
+    class Resp:
+        def __init__(self, fail):
+            self.fail = fail
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def raise_for_status(self):
+            if self.fail:
+                raise requests.exceptions.HTTPError("503")
+
+        def iter_content(self, chunk_size=0):
+            yield b"\\x89PNG"
+            yield b"payload"
+
+    def fake_get(url, **kw):
+        calls.append(url)
+        return Resp(fail="bad" in url)
+
+    monkeypatch.setattr(requests, "get", fake_get)
+    result = script_util.download("https://example.org/photon.png", "photon.png", root=str(tmp_path))
+    expected = tmp_path / "photon.png"
+    assert result == str(expected) and expected.exists() and expected.read_bytes() == b"\\x89PNGpayload"
+    assert script_util.download("https://example.org/photon.png", "photon.png", root=str(tmp_path)) == str(expected) and len(calls) == 1
+    with pytest.raises(RuntimeError, match="Download failed after 2 attempts"):
+        script_util.download("https://example.org/bad.png", "bad.png", root=str(tmp_path), max_retries=2)
+    assert calls.count("https://example.org/bad.png") == 2 and not (tmp_path / "bad.png").exists() and not (tmp_path / "bad.tmp").exists()
+    # checkpoint lookup: an existing file is returned as is, a missing one is requested from the table's url
+    monkeypatch.delenv("CGD_SYNTHETIC_WEIGHTS", raising=False)
+    (tmp_path / "256x256_diffusion.pt").write_bytes(b"x")
+    assert script_util.download_guided_diffusion(256, True, str(tmp_path)) == str(tmp_path / "256x256_diffusion.pt")
+    script_util.download_guided_diffusion(64, True, str(tmp_path))
+    assert calls[-1].endswith("/64x64_diffusion.pt")
