@@ -196,7 +196,7 @@ _CLI_SPEC = f"""
 --quiet -q flag | no progress output
 --save-as-gif -gif flag | assemble the frames into a GIF with ffmpeg and delete them
 --save-as-video -mp4 flag | assemble the frames into an MP4 with ffmpeg and delete them
---reduce-clip -reduce flag | skip the first 20 % of the steps, then guide every 4th step until 70 %
+--reduce-clip -reduce flag | skip the first fifth of the steps, then guide every 4th step until 70 percent are done
 --progressive-cutout -cutn_skip flag | cutn/4, then cutn/2, then cutn cutouts as sampling proceeds
 --cached-cutouts -cached_cutn flag | draw the cutout boxes once and reuse them
 """
@@ -207,6 +207,7 @@ def build_parser():
     parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     for line in _CLI_SPEC.strip().splitlines():
         spec, text = (part.strip() for part in line.split("|", 1))
+        text = text.replace("%", "%%")  # argparse %-formats help strings
         long_flag, alias, kind, *default = spec.split(None, 3)  # the default may contain spaces (a cache path)
         if kind == "flag":
             parser.add_argument(long_flag, alias, action="store_true", help=text)

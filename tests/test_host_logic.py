@@ -240,3 +240,9 @@ def test_download_returns_target_full_path(tmp_path, monkeypatch):
     assert script_util.download_guided_diffusion(256, True, str(tmp_path)) == str(tmp_path / "256x256_diffusion.pt")
     script_util.download_guided_diffusion(64, True, str(tmp_path))
     assert calls[-1].endswith("/64x64_diffusion.pt")
+
+
+def test_cli_help_renders():
+    from cgd import cgd as mine
+    text = mine.build_parser().format_help()
+    assert "--clip_guidance_scale" in text and "--cached-cutouts" in text and "(default: 1000)" in text
