@@ -246,3 +246,27 @@ def test_cli_help_renders():
     from cgd import cgd as mine
     text = mine.build_parser().format_help()
     assert "--clip_guidance_scale" in text and "--cached-cutouts" in text and "(default: 1000)" in text
+
+
+def test_cli_main_forwards_kwargs_and_guards_ffmpeg(tmp_path, monkeypatch):
+    """`cgd.cgd:main` (reference cgd.py:359-430): parses, creates the output directory, drains the generator with the mapped kwargs;
+    --save-as-gif without ffmpeg on PATH is a clear error instead of a silent no-op."""
+    import shutil
+    import sys
+    from cgd import cgd as mine
+    seen = {}
+
+    def fake_generator(**kw):
+        seen.update(kw)
+        return iter([(0, "x.png")])
+
+    monkeypatch.setattr(mine, "clip_guided_diffusion", fake_generator)
+    monkeypatch.setattr(sys, "argv", ["cgd", "-txts", "a boat:2|fog", "-dir", str(tmp_path / "o"), "-size", "256", "-respace", "ddim50", "-cutn", "8", "-q"])
+    mine.main()
+    assert (tmp_path / "o").is_dir() and seen["prompts"] == ["a boat:2", "fog"] and seen["prefix_path"] == tmp_path / "o"
+    assert seen["image_size"] == 256 and seen["timestep_respacing"] == "ddim50" and seen["num_cutouts"] == 8 and seen["progress"] is False
+    assert seen["save_frequency"] == 1 and seen["class_cond"] is True  # CLI default 1 (the Python default is 25, cgd.py:41 vs :318)
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    monkeypatch.setattr(sys, "argv", ["cgd", "-txts", "x", "-dir", str(tmp_path / "o2"), "-gif"])
+    with pytest.raises(RuntimeError, match="ffmpeg"):
+        mine.main()
