@@ -270,3 +270,81 @@ def test_cli_main_forwards_kwargs_and_guards_ffmpeg(tmp_path, monkeypatch):
     monkeypatch.setattr(sys, "argv", ["cgd", "-txts", "x", "-dir", str(tmp_path / "o2"), "-gif"])
     with pytest.raises(RuntimeError, match="ffmpeg"):
         mine.main()
+
+
+def test_generator_body_with_fake_device_objects(tmp_path, monkeypatch, capsys):
+    """The body of `clip_guided_diffusion` (set-up order, weight normalisation, reduce_clip -> skip_timesteps, the one-step software
+    pipeline of the output path, save_frequency / last-step rule, loss lines) run on the CPU: the GPU-backed collaborators (CLIP loader,
+    UNet loader + sampler, ClipGuidance, staged frame copies) are replaced by recording fakes, everything else is the real code."""
+    import types
+    from cgd import cgd as mine
+    from cgd import clip_util, script_util
+    monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.chdir(tmp_path)
+    events = []
+
+    class FakeTorch:  # torch, minus the device placement (there is no GPU here)
+        def __getattr__(self, k):
+            return getattr(th, k)
+
+        @staticmethod
+        def tensor(data, device=None, **kw):
+            return th.tensor(data, **kw)
+
+        @staticmethod
+        def zeros(shape, device=None, **kw):
+            return th.zeros(shape, **kw)
+
+    monkeypatch.setattr(mine, "th", FakeTorch())
+    tower = types.SimpleNamespace(ctx="ctx", input_resolution=16, out_dim=8, patch=8)
+    monkeypatch.setattr(clip_util, "load_clip", lambda name, device: (types.SimpleNamespace(tower=tower), 16))
+    monkeypatch.setattr(clip_util, "encode_text_prompt", lambda txt, w, name, device: (th.full((1, 8), float(len(txt))), w))
+
+    class FakeDiffusion:
+        num_timesteps = 10
+
+        def p_sample_loop_progressive(self, model, shape, **kw):
+            events.append(("loop", shape, kw["skip_timesteps"], kw["randomize_class"], kw["cond_fn_with_grad"], kw["clip_denoised"]))
+            for i in range(self.num_timesteps - kw["skip_timesteps"]):
+                events.append(("enqueue", i))
+                yield {"sample": th.zeros(shape), "pred_xstart": th.full(shape, -1.0 + 0.1 * i)}
+
+        ddim_sample_loop_progressive = p_sample_loop_progressive
+
+    monkeypatch.setattr(script_util, "load_guided_diffusion", lambda **kw: (types.SimpleNamespace(ctx="ctx"), FakeDiffusion()))
+
+    class FakeGuidance:
+        def __init__(self, ctx, unet, towers, diffusion, target_embeds, weights, num_cutouts, **kw):
+            events.append(("guidance", [tuple(e.shape) for e in target_embeds], weights.tolist(), num_cutouts, kw["reduce_clip"]))
+            self.scalars, self.current_timestep, self.n = th.zeros(8), None, 0
+
+        def snapshot(self):
+            self.n += 1
+            return self.n
+
+        def log(self, snap):
+            events.append(("log", snap))
+            return {"CLIP Loss": float(snap), "TV Loss": 0.5, "Grad": 0.0}
+
+    monkeypatch.setattr(mine, "ClipGuidance", FakeGuidance)
+    monkeypatch.setattr(script_util, "stage_images", lambda x: types.SimpleNamespace(get=lambda: script_util.to_uint8_hwc(x)))
+    items = list(mine.clip_guided_diffusion(prompts=["ab:3", "c:-1"], image_size=128, batch_size=2, num_cutouts=4, timestep_respacing="10",
+                                            prefix_path=str(tmp_path / "out"), checkpoints_dir=str(tmp_path / "ck"), save_frequency=3,
+                                            device="cuda", reduce_clip=True, width_offset=16, progress=True))
+    # reduce_clip with skip_timesteps == 0 skips the first 20 % (2 of 10); 8 steps run, frames at steps 0, 3, 6.  Reference quirk kept: the
+    # 'always save the last step' rule tests the closure counter against -1, which starts at N-1 whatever is skipped, so with skipped
+    # timesteps it never fires (cgd.py:264-268)
+    guidance = [e for e in events if e[0] == "guidance"][0]
+    assert guidance[1] == [(2, 8)] and guidance[2] == pytest.approx([1.5, -0.5]) and guidance[3] == 4 and guidance[4] is True
+    loop = [e for e in events if e[0] == "loop"][0]
+    assert loop[1:] == ((2, 3, 128, 144), 2, True, True, False)
+    assert [(b, os.path.basename(p)) for b, p in items] == [(b, f"{s:04}.png") for s in (0, 3, 6) for b in (0, 1)]
+    assert all(os.path.isfile(p) for _, p in items)
+    # pipelining: step k's scalars are read only after step k+1 has been enqueued
+    order = [e for e in events if e[0] in ("enqueue", "log")]
+    assert order[:4] == [("enqueue", 0), ("enqueue", 1), ("log", 1), ("enqueue", 2)] and order[-1] == ("log", 8)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("CLIP Loss")]
+    assert lines[0].split("\t") == ["CLIP Loss: 1.000", "TV Loss: 0.500"] and len(lines) == 8
+    with pytest.raises(RuntimeError, match="The weights must not sum to 0."):
+        next(mine.clip_guided_diffusion(prompts=["a:1", "b:-1"], image_size=128, device="cuda", prefix_path=str(tmp_path / "o2"),
+                                        checkpoints_dir=str(tmp_path / "ck")))
