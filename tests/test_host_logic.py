@@ -348,3 +348,45 @@ def test_generator_body_with_fake_device_objects(tmp_path, monkeypatch, capsys):
     with pytest.raises(RuntimeError, match="The weights must not sum to 0."):
         next(mine.clip_guided_diffusion(prompts=["a:1", "b:-1"], image_size=128, device="cuda", prefix_path=str(tmp_path / "o2"),
                                         checkpoints_dir=str(tmp_path / "ck")))
+
+
+@pytest.mark.parametrize("skip,with_init", [(0, False), (7, False), (7, True)])
+def test_device_sampler_loop_prologue_matches_the_oracle(monkeypatch, skip, with_init):
+    """x_T draw, `skip_timesteps` (zeros init when no init image is given), q_sample blending of the init image at
+    the first executed index, reversed index order, per-step class randomisation — `GuidedSampler._loop` against the oracle's loop with
+    both per-step functions replaced by the same recording stub, under the same global seed."""
+    import types
+    from cgd_amd import sampler
+    from oracle import diffusion as od
+    tables = dd.create_gaussian_diffusion(1000, "cosine", "20", False)
+    smp = sampler.GuidedSampler(types.SimpleNamespace(device=0), tables)
+    o_diff = od.create_gaussian_diffusion(1000, "cosine", "20", False)
+    model = types.SimpleNamespace(num_classes=10, parameters=lambda: iter([th.zeros(1)]))
+    shape = (2, 3, 8, 8)
+    init = th.rand(shape, generator=th.Generator().manual_seed(1)) * 2 - 1 if with_init else None
+    seen_dev, seen_ora = [], []
+
+    def dev_step(model_, x, i, cond_fn, model_kwargs, noise, mode, bufs):
+        seen_dev.append((i, x.clone(), model_kwargs["y"].clone()))
+        return {"sample": x * 0.5 + i, "pred_xstart": x}
+
+    def ora_step(model_, x, t, clip_denoised=True, cond_fn=None, model_kwargs=None, noise=None):
+        seen_ora.append((int(t[0]), x.clone(), model_kwargs["y"].clone()))
+        return {"sample": x * 0.5 + int(t[0]), "pred_xstart": x}
+
+    monkeypatch.setattr(smp, "_step", dev_step)
+    monkeypatch.setattr(o_diff, "p_sample_with_grad", ora_step)
+    kw = dict(clip_denoised=False, cond_fn=None, model_kwargs={"y": th.zeros(2, dtype=th.long)}, device="cpu", skip_timesteps=skip,
+              init_image=init, randomize_class=True, cond_fn_with_grad=True)
+    th.manual_seed(123)
+    dev_out = [o["sample"] for o in smp.p_sample_loop_progressive(model, shape, **kw)]
+    th.manual_seed(123)
+    ora_out = [o["sample"] for o in o_diff.p_sample_loop_progressive(model, shape, **kw)]
+    assert [i for i, _, _ in seen_dev] == list(range(20 - skip))[::-1] == [i for i, _, _ in seen_ora]
+    for (_, xd, yd), (_, xo, yo) in zip(seen_dev, seen_ora):
+        assert th.allclose(xd, xo, rtol=1e-6, atol=1e-6) and th.equal(yd, yo)
+    assert len(dev_out) == len(ora_out) == 20 - skip
+    if skip and not with_init:  # zeros init: the first input is pure scaled noise, sqrt(1 - abar_t) * x_T
+        th.manual_seed(123)
+        x_T = th.randn(*shape)
+        assert th.allclose(seen_dev[0][1], float(tables.sqrt_one_minus_alphas_cumprod[19 - skip]) * x_T, atol=1e-6)
