@@ -390,3 +390,71 @@ def test_device_sampler_loop_prologue_matches_the_oracle(monkeypatch, skip, with
         th.manual_seed(123)
         x_T = th.randn(*shape)
         assert th.allclose(seen_dev[0][1], float(tables.sqrt_one_minus_alphas_cumprod[19 - skip]) * x_T, atol=1e-6)
+
+
+def test_guidance_call_sequence_with_a_recording_library(monkeypatch):
+    """the C-ABI calls `ClipGuidance.native` issues for one guided step (two CLIP towers + the LPIPS term), in
+    order, with the accumulate flags that make the towers' and the LPIPS gradients add up in one buffer.  A recording fake stands in
+    for the library and the network handles; tensors live on the CPU."""
+    import types
+    calls = []
+    monkeypatch.setattr(dg.L, "stream_ptr", lambda: 0)  # no GPU, no stream
+
+    class FakeLib:
+        def __getattr__(self, name):
+            def fn(*args):
+                calls.append((name, args))
+                return 32 if name == "cgd_guidance_part_blocks" else 0
+            return fn
+
+    ctx = types.SimpleNamespace(lib=FakeLib(), h=1, check=lambda rc: None)
+
+    class Tower:
+        def __init__(self, name, res, patch, dim):
+            self.name, self.input_resolution, self.patch, self.out_dim = name, res, patch, dim
+
+        def encode_image(self, img, layout=0, n=None, out=None):
+            calls.append((f"{self.name}.encode_image", (layout, n, tuple(img.shape))))
+            return out
+
+        def dgrad(self, d_emb, d_img=None):
+            calls.append((f"{self.name}.dgrad", (tuple(d_emb.shape),)))
+            return d_img
+
+    class Lpips:
+        def set_reference(self, ref):
+            calls.append(("lpips.set_reference", (tuple(ref.shape),)))
+
+        def loss_grad(self, x, grad_scale=1.0, g=None, accumulate=False, loss=None):
+            calls.append(("lpips.loss_grad", (grad_scale, accumulate)))
+            return loss, g
+
+    unet = types.SimpleNamespace(dgrad=lambda seed, out: calls.append(("unet.dgrad", (tuple(seed.shape),))) or out)
+    diffusion = types.SimpleNamespace(num_timesteps=50)
+    vit, rn = Tower("vit", 32, 8, 16), Tower("rn", 64, 0, 24)
+    guid = dg.ClipGuidance(ctx, unet, [vit, rn], diffusion, [th.randn(2, 16), th.randn(2, 24)], [1.0, -0.25], 6, lpips=Lpips(),
+                           init_tensor=th.zeros(1, 3, 32, 48), init_scale=500.0)
+    guid.current_timestep = 49
+    guid.coords_tape = [[(0, 0, 32)] * 6]
+    B, H, W = 2, 32, 48
+    x = th.zeros(B, 3, H, W)
+    g = guid.native(x, x.clone(), x.clone(), coef=None)
+    names = [c[0] for c in calls]
+    assert names == ["lpips.set_reference", "lpips.loss_grad",
+                     "cgd_cutouts_fwd", "vit.encode_image", "cgd_spherical_loss", "vit.dgrad", "cgd_cutouts_bwd",
+                     "cgd_cutouts_fwd", "rn.encode_image", "cgd_spherical_loss", "rn.dgrad", "cgd_cutouts_bwd",
+                     "cgd_guidance_part_blocks", "cgd_guidance_combine", "unet.dgrad", "cgd_grad_finish", "cgd_scalars"]
+    by = {n: [c[1] for c in calls if c[0] == n] for n in set(names)}
+    assert by["lpips.set_reference"] == [((B, 3, H, W),)] and by["lpips.loss_grad"] == [(500.0, False)]  # LPIPS writes the buffer first
+    fwd = by["cgd_cutouts_fwd"]  # (..., B, H, W, cutn, cut_size, layout, patch, stream)
+    assert fwd[0][4:11] == (B, H, W, 6, 32, 1, 8) and fwd[1][4:11] == (B, H, W, 6, 64, 0, 0)  # ViT: patch rows; ResNet: NCHW images
+    assert by["vit.encode_image"] == [(1, 12, (12 * 16, 3 * 64))] and by["rn.encode_image"] == [(0, 12, (12, 3, 64, 64))]
+    assert [c[-2] for c in by["cgd_cutouts_bwd"]] == [1, 1]  # both towers accumulate onto the LPIPS gradient
+    assert by["cgd_spherical_loss"][0][6:11] == (6, B, 2, 16, 1000.0) and by["cgd_spherical_loss"][1][9] == 24
+    assert by["cgd_scalars"][0][2] == 2 * 12 and tuple(g.shape) == (B, 3, H, W)
+    # without the LPIPS term the first tower overwrites and the second accumulates
+    del calls[:]
+    guid2 = dg.ClipGuidance(ctx, unet, [vit, rn], diffusion, [th.randn(2, 16), th.randn(2, 24)], [1.0, -0.25], 6)
+    guid2.current_timestep, guid2.coords_tape = 49, [[(0, 0, 32)] * 6]
+    guid2.native(x, x.clone(), x.clone(), coef=None)
+    assert [c[1][-2] for c in calls if c[0] == "cgd_cutouts_bwd"] == [0, 1]
