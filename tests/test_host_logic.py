@@ -458,3 +458,46 @@ def test_guidance_call_sequence_with_a_recording_library(monkeypatch):
     guid2.current_timestep, guid2.coords_tape = 49, [[(0, 0, 32)] * 6]
     guid2.native(x, x.clone(), x.clone(), coef=None)
     assert [c[1][-2] for c in calls if c[0] == "cgd_cutouts_bwd"] == [0, 1]
+
+
+def test_native_step_orders_noise_draw_before_guidance(monkeypatch):
+    """p_sample_with_grad draws `noise = randn_like(x)` BEFORE it calls cond_fn, so the step noise precedes the
+    cutout-coordinate draws in the global RNG stream; `GuidedSampler._step` (native ClipGuidance path) must keep that order and issue
+    model.forward -> cgd_pmv_blend -> guidance -> cgd_sample_update.  Recording fakes, CPU tensors."""
+    import types
+    from cgd_amd import sampler
+    monkeypatch.setattr(sampler.L, "stream_ptr", lambda: 0)
+    calls = []
+
+    class FakeLib:
+        def __getattr__(self, name):
+            def fn(*args):
+                calls.append(name)
+                return 0
+            return fn
+
+    ctx = types.SimpleNamespace(lib=FakeLib(), h=1, check=lambda rc: None, device=0)
+    smp = sampler.GuidedSampler(ctx, dd.create_gaussian_diffusion(1000, "linear", "10", False))
+    guid = object.__new__(dg.ClipGuidance)
+    guid.use_magnitude, guid.scalars, guid.current_timestep = True, th.zeros(8), 9
+    draws = []
+
+    def native(x, x0, x_in, coef):
+        calls.append("guidance.native")
+        draws.append(th.rand(1))  # stands for the cutout-coordinate draws
+        return th.ones_like(x)
+
+    guid.native = native
+    model = types.SimpleNamespace(forward=lambda x, ts, y, out=None: calls.append("model.forward") or out)
+    x = th.zeros(1, 3, 8, 8)
+    th.manual_seed(5)
+    out = smp._step(model, x, 9, guid, {"y": th.zeros(1, dtype=th.long)}, None, 0, bufs := {})
+    th.manual_seed(5)
+    expect_noise, expect_draw = th.randn_like(x), th.rand(1)
+    assert th.equal(bufs["_keep"][0], expect_noise) and th.equal(draws[0], expect_draw)
+    assert calls == ["model.forward", "cgd_pmv_blend", "guidance.native", "cgd_sample_update"]
+    assert set(out) == {"sample", "pred_xstart"} and out["sample"].shape == x.shape
+    # a replayed tape supplies the noise: nothing is drawn for it
+    th.manual_seed(5)
+    smp._step(model, x, 8, guid, {"y": th.zeros(1, dtype=th.long)}, th.full_like(x, 0.25), 0, bufs)
+    assert th.equal(draws[1], th.manual_seed(5) and th.rand(1))
