@@ -149,6 +149,15 @@ def model_config(image_size, class_cond, diffusion_steps=None, timestep_respacin
     return cfg
 
 
+def unet_kwargs(cfg):
+    """guided_diffusion's create_model flags -> the device UNet's constructor arguments (NUM_CLASSES = 1000 upstream; the channel
+    multipliers default per image size like upstream's create_model)."""
+    return dict(image_size=cfg["image_size"], model_channels=cfg["num_channels"], num_res_blocks=cfg["num_res_blocks"],
+                attention_resolutions=cfg["attention_resolutions"].replace(" ", ""), channel_mult=None,
+                num_classes=1000 if cfg["class_cond"] else None, num_heads=cfg["num_heads"], num_head_channels=cfg["num_head_channels"],
+                use_new_attention_order=cfg["use_new_attention_order"], out_channels=6 if cfg["learn_sigma"] else 3)
+
+
 @lru_cache(maxsize=1)
 def load_guided_diffusion(checkpoint_path: str, image_size: int, class_cond: bool, diffusion_steps: int = None,
                           timestep_respacing: str = None, use_fp16: bool = True, device: str = "", noise_schedule: str = "linear",
@@ -161,11 +170,7 @@ def load_guided_diffusion(checkpoint_path: str, image_size: int, class_cond: boo
         raise ValueError("linear_or_cosine must be set")
     cfg = model_config(image_size, class_cond, diffusion_steps, timestep_respacing, use_fp16, noise_schedule, dropout)
     ctx = get_context(device)
-    model = _nets.UNet(
-        ctx, image_size=cfg["image_size"], model_channels=cfg["num_channels"], num_res_blocks=cfg["num_res_blocks"],
-        attention_resolutions=cfg["attention_resolutions"].replace(" ", ""), channel_mult=None,
-        num_classes=1000 if cfg["class_cond"] else None, num_heads=cfg["num_heads"], num_head_channels=cfg["num_head_channels"],
-        use_new_attention_order=cfg["use_new_attention_order"], out_channels=6 if cfg["learn_sigma"] else 3)
+    model = _nets.UNet(ctx, **unet_kwargs(cfg))
     if os.path.isfile(checkpoint_path):
         model.load_state_dict(th.load(checkpoint_path, map_location="cpu"))
     elif synthetic_weights_enabled():

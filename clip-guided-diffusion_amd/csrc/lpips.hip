@@ -400,6 +400,16 @@ int cgd_lpips_create(cgd_ctx* ctx, cgd_lpips** out) {
   *out = v;
   return 0;
 }
+// host-only: parameter manifest (lpips package names, element counts); no GPU, no context
+int cgd_lpips_manifest(void (*cb)(const char*, int64_t, void*), void* user) {
+  cgd_ctx host;
+  Lpips net;
+  net.ctx = &host;
+  if (net.build() != 0) return -2;
+  if (cb)
+    for (const ParamSpec& p : net.params) cb(p.name.c_str(), p.numel, user);
+  return (int)net.params.size();
+}
 void cgd_lpips_destroy(cgd_lpips* v) { delete v; }
 int cgd_lpips_num_params(cgd_lpips* v) {
   if (!v) return -3;

@@ -557,6 +557,18 @@ int cgd_rn_create(cgd_ctx* ctx, const cgd_rn_config* cfg, cgd_rn** out) {
   *out = v;
   return 0;
 }
+// host-only: parameter manifest (OpenAI `visual.*` names without the prefix, BatchNorm statistics included); no GPU, no context
+int cgd_rn_manifest(const cgd_rn_config* cfg, void (*cb)(const char*, int64_t, void*), void* user) {
+  if (!cfg) return -3;
+  cgd_ctx host;
+  ResNet net;
+  net.ctx = &host;
+  net.cfg = *cfg;
+  if (net.build() != 0) return -2;
+  if (cb)
+    for (const ParamSpec& p : net.params) cb(p.name.c_str(), p.numel, user);
+  return (int)net.params.size();
+}
 void cgd_rn_destroy(cgd_rn* v) {
   if (v) cgd_frag_cache_clear(v->net.ctx);
   delete v;

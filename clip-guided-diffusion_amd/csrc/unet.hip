@@ -594,6 +594,19 @@ int cgd_unet_create(cgd_ctx* ctx, const cgd_unet_config* cfg, cgd_unet** out) {
   *out = u;
   return 0;
 }
+// host-only: parameter manifest of a configuration (upstream state-dict names, element counts); no GPU, no context
+int cgd_unet_manifest(const cgd_unet_config* cfg, void (*cb)(const char*, int64_t, void*), void* user) {
+  if (!cfg) return -3;
+  if (cfg->in_channels != 3 || (cfg->out_channels != 6 && cfg->out_channels != 3) || cfg->n_mult < 1 || cfg->n_mult > 8) return -2;
+  cgd_ctx host;  // plain host object: build() only records names and shapes
+  UNet net;
+  net.ctx = &host;
+  net.cfg = *cfg;
+  if (net.build() != 0) return -2;
+  if (cb)
+    for (const ParamSpec& p : net.params) cb(p.name.c_str(), p.numel, user);
+  return (int)net.params.size();
+}
 void cgd_unet_destroy(cgd_unet* u) {
   if (u) cgd_frag_cache_clear(u->net.ctx);  // packed copies are keyed by weight pointers that die with the net
   delete u;

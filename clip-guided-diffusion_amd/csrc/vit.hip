@@ -224,6 +224,18 @@ int cgd_vit_create(cgd_ctx* ctx, const cgd_vit_config* cfg, cgd_vit** out) {
   *out = v;
   return 0;
 }
+// host-only: parameter manifest (OpenAI `visual.*` names without the prefix, element counts); no GPU, no context
+int cgd_vit_manifest(const cgd_vit_config* cfg, void (*cb)(const char*, int64_t, void*), void* user) {
+  if (!cfg) return -3;
+  cgd_ctx host;
+  ViT net;
+  net.ctx = &host;
+  net.cfg = *cfg;
+  if (net.build() != 0) return -2;
+  if (cb)
+    for (const ParamSpec& p : net.params) cb(p.name.c_str(), p.numel, user);
+  return (int)net.params.size();
+}
 void cgd_vit_destroy(cgd_vit* v) {
   if (v) cgd_frag_cache_clear(v->net.ctx);
   delete v;

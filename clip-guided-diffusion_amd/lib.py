@@ -41,8 +41,14 @@ class StepCoef(C.Structure):
     ]
 
 
+MANIFEST_CB = C.CFUNCTYPE(None, C.c_char_p, i64, vp)
+
 # name -> (restype, argtypes).  Pointers to device memory are passed as integers (tensor.data_ptr()).
 _SIGS = {
+    "cgd_unet_manifest": (i32, [C.POINTER(UNetConfig), MANIFEST_CB, vp]),
+    "cgd_vit_manifest": (i32, [C.POINTER(ViTConfig), MANIFEST_CB, vp]),
+    "cgd_rn_manifest": (i32, [C.POINTER(RNConfig), MANIFEST_CB, vp]),
+    "cgd_lpips_manifest": (i32, [MANIFEST_CB, vp]),
     "cgd_version": (C.c_char_p, []),
     "cgd_ctx_create": (i32, [C.POINTER(vp), i32]),
     "cgd_ctx_destroy": (None, [vp]),

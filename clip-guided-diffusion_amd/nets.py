@@ -75,6 +75,19 @@ class UNet(_Net):
                  num_classes=None, num_heads=4, num_head_channels=-1, use_new_attention_order=False, in_channels=3,
                  out_channels=6):
         self.ctx = ctx
+        cfg = self.make_config(image_size, model_channels, num_res_blocks, attention_resolutions, channel_mult, num_classes, num_heads,
+                               num_head_channels, use_new_attention_order, in_channels, out_channels)
+        self.cfg = cfg
+        self.num_classes = num_classes
+        self.out_channels = out_channels
+        h = C.c_void_p()
+        ctx.check(ctx.lib.cgd_unet_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self._adopt(h)
+
+    @staticmethod
+    def make_config(image_size, model_channels, num_res_blocks, attention_resolutions="32,16,8", channel_mult=None, num_classes=None,
+                    num_heads=4, num_head_channels=-1, use_new_attention_order=False, in_channels=3, out_channels=6):
+        """guided_diffusion's create_model arguments -> the C struct (host-only: also feeds cgd_unet_manifest in the CPU tests)."""
         if channel_mult is None:
             channel_mult = DEFAULT_CHANNEL_MULT[image_size]
         att = [image_size // int(r) for r in str(attention_resolutions).split(",")]
@@ -90,12 +103,7 @@ class UNet(_Net):
         cfg.num_heads, cfg.num_head_channels = num_heads, num_head_channels
         cfg.use_new_attention_order = int(bool(use_new_attention_order))
         cfg.in_channels, cfg.out_channels = in_channels, out_channels
-        self.cfg = cfg
-        self.num_classes = num_classes
-        self.out_channels = out_channels
-        h = C.c_void_p()
-        ctx.check(ctx.lib.cgd_unet_create(ctx.h, C.byref(cfg), C.byref(h)))
-        self._adopt(h)
+        return cfg
 
     def forward(self, x, timesteps, y=None, out=None):
         """x (B,3,H,W) fp32 NCHW on the GPU; timesteps (B,) (any dtype; converted to fp32); y (B,) int64."""
@@ -199,15 +207,20 @@ class ClipResNetTower(_Net):
     def __init__(self, ctx, name="RN50", config=None):
         self.ctx = ctx
         res, width, layers, out, heads = config or RN_CONFIGS[name]
-        cfg = L.RNConfig()
-        cfg.resolution, cfg.width, cfg.out_dim, cfg.heads = res, width, out, heads
-        for i, v in enumerate(layers):
-            cfg.layers[i] = v
+        cfg = self.make_config(res, width, layers, out, heads)
         self.cfg = cfg
         self.input_resolution, self.out_dim = res, out
         h = C.c_void_p()
         ctx.check(ctx.lib.cgd_rn_create(ctx.h, C.byref(cfg), C.byref(h)))
         self._adopt(h)
+
+    @staticmethod
+    def make_config(res, width, layers, out, heads):
+        cfg = L.RNConfig()
+        cfg.resolution, cfg.width, cfg.out_dim, cfg.heads = res, width, out, heads
+        for i, v in enumerate(layers):
+            cfg.layers[i] = v
+        return cfg
 
     def load_clip_state_dict(self, sd):
         prefix = "visual." if any(k.startswith("visual.") for k in sd) else ""
@@ -264,3 +277,14 @@ class LpipsVGG(_Net):
                                                        int(bool(accumulate)), L.stream_ptr()))
         self._keep = x
         return loss, g
+
+
+def manifest(kind, cfg=None):
+    """[(name, numel)] of a network configuration from the library's host-only manifest functions (no GPU, no context)."""
+    out = []
+    cb = L.MANIFEST_CB(lambda name, numel, user: out.append((name.decode(), int(numel))))
+    lib = L.load()
+    n = lib.cgd_lpips_manifest(cb, None) if kind == "lpips" else getattr(lib, f"cgd_{kind}_manifest")(C.byref(cfg), cb, None)
+    if n < 0:
+        raise ValueError(f"{kind}: invalid configuration (status {n})")
+    return out

@@ -64,6 +64,11 @@ typedef struct cgd_unet_config {
   int out_channels;        /* 6 (learn_sigma) */
 } cgd_unet_config;
 
+/* host-only (no GPU, no context): the parameter manifest of a configuration — cb(name, numel, user) per parameter in upload order,
+ * returns the count (negative: invalid configuration).  The same for the other networks below.  Used by the CPU tests of checkpoint
+ * ingestion (names and shapes of all published checkpoints against the oracle networks). */
+typedef void (*cgd_manifest_cb)(const char* name, int64_t numel, void* user);
+int cgd_unet_manifest(const cgd_unet_config* cfg, cgd_manifest_cb cb, void* user);
 int cgd_unet_create(cgd_ctx* ctx, const cgd_unet_config* cfg, cgd_unet** out);
 void cgd_unet_destroy(cgd_unet* u);
 /* parameter ingestion, names = upstream state-dict keys (model.load_state_dict at script_util.py:317);
@@ -83,6 +88,7 @@ int cgd_unet_dgrad(cgd_unet* u, const float* g_out, float* g_x, void* stream);
 typedef struct cgd_vit_config {
   int resolution, patch, width, layers, heads, out_dim;
 } cgd_vit_config;
+int cgd_vit_manifest(const cgd_vit_config* cfg, cgd_manifest_cb cb, void* user);
 int cgd_vit_create(cgd_ctx* ctx, const cgd_vit_config* cfg, cgd_vit** out);
 void cgd_vit_destroy(cgd_vit* v);
 int cgd_vit_num_params(cgd_vit* v);
@@ -100,6 +106,7 @@ typedef struct cgd_rn cgd_rn;
 typedef struct cgd_rn_config {
   int resolution, width, layers[4], out_dim, heads;
 } cgd_rn_config;
+int cgd_rn_manifest(const cgd_rn_config* cfg, cgd_manifest_cb cb, void* user);
 int cgd_rn_create(cgd_ctx* ctx, const cgd_rn_config* cfg, cgd_rn** out);
 void cgd_rn_destroy(cgd_rn* v);
 int cgd_rn_num_params(cgd_rn* v);
@@ -114,6 +121,7 @@ int cgd_rn_dgrad(cgd_rn* v, const float* d_emb, float* d_img /* (N,3,res,res) */
  *      lin{k}.model.1.weight).  set_reference: the fixed second argument (init image, (B,3,H,W) NCHW in [-1,1], H and W
  *      multiples of 16).  loss_grad: loss[b] = lpips(x_b, ref_b);  g (B,3,H,W) (+)= grad_scale * d(sum_b loss_b)/dx. ---- */
 typedef struct cgd_lpips cgd_lpips;
+int cgd_lpips_manifest(cgd_manifest_cb cb, void* user);
 int cgd_lpips_create(cgd_ctx* ctx, cgd_lpips** out);
 void cgd_lpips_destroy(cgd_lpips* v);
 int cgd_lpips_num_params(cgd_lpips* v);

@@ -110,3 +110,43 @@ def test_dispatch_policy_of_the_contraction_launcher():
     assert _plan(handle, conv=1, M=32 * 32, N=512, H=32, W=32, Cin=512, num_cu=64)[1][2] == 2
     assert _plan(handle, M=800, N=768, K=770, weight=1)[0] == -2   # K must be a multiple of 4
     assert _plan(handle, conv=1, M=64 * 64, N=64, H=64, W=64, Cin=48)[0] == -2  # conv Cin must be a multiple of 32
+
+
+def test_parameter_manifests_of_every_supported_network_match_the_oracle():
+    """Checkpoint ingestion without a GPU: the library's host-only manifests — the names and element counts
+    `set_param` expects — against the oracle networks' state dicts (which carry the upstream key scheme), for all six published
+    guided-diffusion checkpoints, the seven CLIP towers of CLIP_MODEL_NAMES and LPIPS-VGG16."""
+    import torch as th
+    from cgd import clip_util, model_flags, script_util
+    from cgd_amd import nets
+    from oracle import clip_resnet as ocr
+    from oracle import clip_vit as ocv
+    from oracle import lpips_vgg as olp
+    from oracle import unet as ou
+
+    def oracle_manifest(module, prefix="", skip=()):
+        sd = module.state_dict()
+        return {k[len(prefix):]: v.numel() for k, v in sd.items() if k.startswith(prefix) and not k.endswith(skip)}
+
+    published = {("cond", 256): 553838086, ("cond", 64): 295904454}
+    for cond_key, table in model_flags.DIFFUSION_LOOKUP.items():
+        for size in table:
+            kw = script_util.unet_kwargs(script_util.model_config(size, cond_key == "cond"))
+            got = dict(nets.manifest("unet", nets.UNet.make_config(**kw)))
+            with th.device("meta"):
+                ref = oracle_manifest(ou.UNetModel(**kw))
+            assert got == ref, (cond_key, size, set(got) ^ set(ref))
+            if (cond_key, size) in published:
+                assert sum(got.values()) == published[(cond_key, size)]
+    for name in clip_util.CLIP_MODEL_NAMES:
+        with th.device("meta"):
+            if name in nets.VIT_CONFIGS:
+                got = dict(nets.manifest("vit", lib.ViTConfig(*nets.VIT_CONFIGS[name])))
+                ref = oracle_manifest(ocv.ClipImageModel(name), "visual.")
+            else:
+                got = dict(nets.manifest("rn", nets.ClipResNetTower.make_config(*nets.RN_CONFIGS[name])))
+                ref = oracle_manifest(ocr.ClipResNetImageModel(name), "visual.", skip=("num_batches_tracked",))
+        assert got == ref, (name, sorted(set(got) ^ set(ref))[:6])
+    with th.device("meta"):
+        ref = {k: v.numel() for k, v in olp.LpipsVGG().lpips_state_dict().items()}
+    assert dict(nets.manifest("lpips")) == ref
