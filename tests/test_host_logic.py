@@ -501,3 +501,21 @@ def test_native_step_orders_noise_draw_before_guidance(monkeypatch):
     th.manual_seed(5)
     smp._step(model, x, 8, guid, {"y": th.zeros(1, dtype=th.long)}, th.full_like(x, 0.25), 0, bufs)
     assert th.equal(draws[1], th.manual_seed(5) and th.rand(1))
+
+
+def test_clip_architecture_inference_from_state_dict_shapes():
+    """clip_util._vit_config_from_state_dict / _rn_config_from_state_dict (clip.model.build_model's shape inference, SURVEY.md 8f
+    rank 1) on the oracle towers' state dicts: every name of CLIP_MODEL_NAMES maps back to its published configuration."""
+    from cgd import clip_util
+    from cgd_amd import nets
+    from oracle import clip_resnet as ocr
+    from oracle import clip_vit as ocv
+    for name in clip_util.CLIP_MODEL_NAMES:
+        with th.device("meta"):
+            model = ocv.ClipImageModel(name) if name in nets.VIT_CONFIGS else ocr.ClipResNetImageModel(name)
+        sd = model.state_dict()
+        if name in nets.VIT_CONFIGS:
+            assert tuple(clip_util._vit_config_from_state_dict(sd)) == tuple(nets.VIT_CONFIGS[name]), name
+        else:
+            res, width, layers, out, heads = clip_util._rn_config_from_state_dict(sd)
+            assert (res, width, tuple(layers), out, heads) == tuple(nets.RN_CONFIGS[name]), name
