@@ -125,7 +125,8 @@ def clip_guided_diffusion(image_size=128, num_cutouts=16, prompts=[], image_prom
         def enqueue_steps():
             for step, sample in enumerate(samples):
                 cond_fn.current_timestep -= 1
-                want_log = (progress or wandb_run is not None) and cond_fn.scalars is not None
+                # a gated --reduce-clip step logs nothing (the reference's cond_fn returns before its logging, cgd.py:155-160)
+                want_log = (progress or wandb_run is not None) and cond_fn.last_ran
                 save = step % save_frequency == 0 or cond_fn.current_timestep == -1
                 yield (step, cond_fn.snapshot() if want_log else None, script_util.stage_images(sample["pred_xstart"]) if save else None)
 
@@ -143,7 +144,19 @@ def clip_guided_diffusion(image_size=128, num_cutouts=16, prompts=[], image_prom
                     yield batch_idx, script_util.write_image(arr[batch_idx], prefix_path, prompts, step, batch_idx)
 
         previous = None
-        for item in enqueue_steps():
+        pending = enqueue_steps()
+        while True:
+            try:
+                item = next(pending)
+            except StopIteration:
+                break
+            except (RuntimeError, KeyboardInterrupt):
+                # enqueuing timestep k+1 failed (OOM, ^C): timestep k is complete, so its frames are still written and yielded
+                # first, as the unpipelined reference would have done before starting k+1
+                if previous is not None:
+                    item, previous = previous, None
+                    yield from finish(item)
+                raise
             if previous is not None:
                 yield from finish(previous)
             previous = item
@@ -247,14 +260,24 @@ def main():
         if shutil.which("ffmpeg") is None:
             raise RuntimeError("--save-as-gif/--save-as-video need ffmpeg on PATH")
         for batch_idx in range(args.batch_size):
+            # file names and encoder settings of the reference (script_util.py:104-214): <frames_dir>_<batch_idx:02>.gif|.mp4
             frames_dir = script_util.clean_and_combine_prompts(args.prefix, kwargs["prompts"], batch_idx)
             pattern = f"{frames_dir}/%04d.png"
             if args.save_as_gif:
-                subprocess.check_call(["ffmpeg", "-y", "-framerate", "10", "-i", pattern, f"{frames_dir}.gif"])
+                palette = f"{frames_dir}/palette.png"
+                subprocess.check_call(["ffmpeg", "-y", "-framerate", "10", "-i", pattern, "-vf", "palettegen=max_colors=256:stats_mode=full",
+                                       palette])
+                subprocess.check_call(["ffmpeg", "-y", "-framerate", "10", "-i", pattern, "-i", palette, "-lavfi",
+                                       "paletteuse=dither=floyd_steinberg:bayer_scale=5:diff_mode=rectangle", "-loop", "0",
+                                       f"{frames_dir}_{batch_idx:02}.gif"])
+                Path(palette).unlink(missing_ok=True)
             if args.save_as_video:
-                subprocess.check_call(["ffmpeg", "-y", "-framerate", "10", "-i", pattern, "-pix_fmt", "yuv420p", f"{frames_dir}.mp4"])
+                subprocess.check_call(["ffmpeg", "-y", "-framerate", "10", "-i", pattern, "-c:v", "libx264", "-preset", "slow", "-crf", "18",
+                                       "-pix_fmt", "yuv420p", "-movflags", "+faststart", f"{frames_dir}_{batch_idx:02}.mp4"])
             for f in sorted(glob.glob(f"{frames_dir}/*.png")):
                 Path(f).unlink()
+            if Path(frames_dir).is_dir() and not list(Path(frames_dir).iterdir()):
+                Path(frames_dir).rmdir()
 
 
 if __name__ == "__main__":

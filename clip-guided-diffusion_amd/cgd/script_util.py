@@ -7,6 +7,7 @@ network retry machinery are outside the hot-path scope (control pla
 """
 import io
 import os
+import time
 import re
 from functools import lru_cache
 from pathlib import Path
@@ -101,19 +102,27 @@ def download(url: str, filename: str, root: str = CACHE_PATH, max_retries: int =
     import requests
     tmp = target.with_suffix(".tmp")
     last = None
-    for _ in range(max_retries):
+    for attempt in range(max_retries):
         try:
             with requests.get(url, stream=True, timeout=(30, 120)) as resp:
                 resp.raise_for_status()
+                expected = int(resp.headers.get("Content-Length", 0) or 0)
                 with open(tmp, "wb") as out:
                     for chunk in resp.iter_content(chunk_size=1 << 16):
                         out.write(chunk)
+                    out.flush()
+                    os.fsync(out.fileno())
+            got = tmp.stat().st_size
+            if expected and got != expected:  # a connection that closed early without raising must not reach the cache
+                raise OSError(f"download incomplete: expected {expected} bytes, got {got}")
             os.rename(tmp, target)
             return str(target)
         except (requests.exceptions.RequestException, OSError) as e:
             last = e
             if tmp.exists():
                 tmp.unlink()
+            if attempt < max_retries - 1:
+                time.sleep(float(os.environ.get("CGD_DOWNLOAD_BACKOFF", "1")) * 2 ** attempt)
     raise RuntimeError(f"Download failed after {max_retries} attempts: {last}") from last
 
 

@@ -14,10 +14,18 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (!out) return -3;
   cgd_ctx* ctx = new cgd_ctx();
   ctx->device = device;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
   if (hipSetDevice(device) != hipSuccess) {
     delete ctx;
     return -1;
   }
+  struct Restore {  // the caller's current device is not ours to change
+    int d;
+    ~Restore() {
+      if (d >= 0) (void)hipSetDevice(d);
+    }
+  } restore{prev};
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     ctx->num_cu = prop.multiProcessorCount;
@@ -38,6 +46,8 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
 
 void cgd_ctx_destroy(cgd_ctx* ctx) {
   if (!ctx) return;
+  {
+  DeviceScope dev_scope(ctx);
   if (ctx->ws) (void)hipFree(ctx->ws);
   cgd_frag_cache_clear(ctx);
   if (ctx->frag_tmp) (void)hipFree(ctx->frag_tmp);
@@ -46,13 +56,15 @@ void cgd_ctx_destroy(cgd_ctx* ctx) {
     (void)hipEventDestroy(r.b);
   }
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+  }
   delete ctx;
 }
 
 const char* cgd_last_error(cgd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-#define CGD_NEED_CTX(ctx) \
-  if (!(ctx)) return -3
+#define CGD_NEED_CTX(ctx)   \
+  if (!(ctx)) return -3;    \
+  DeviceScope dev_scope__(ctx)
 
 int cgd_set_precision(cgd_ctx* ctx, int mode) {
   CGD_NEED_CTX(ctx);

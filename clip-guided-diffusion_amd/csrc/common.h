@@ -50,6 +50,30 @@ struct cgd_ctx {
   double prof_ms[2] = {0.0, 0.0}, prof_flops[2] = {0.0, 0.0}, prof_n[2] = {0.0, 0.0};  // folded totals per ProfRec::kind
 };
 
+// RAII: exact-fp32 MFMA products (v_mfma_f32_32x32x2_f32) for the duration of a pass, whatever the context precision is.
+// Used by the ReLU / max-pool networks (LPIPS-VGG16, CLIP ModifiedResNet): their input gradient is discontinuous in the
+// activations, so the 2^-17 product error of the bf16x3 split flips enough masks to put 1-2 % on the gradient.
+struct ExactScope {
+  cgd_ctx* ctx;
+  int saved;
+  explicit ExactScope(cgd_ctx* c) : ctx(c), saved(c->precision) { c->precision = CGD_PREC_F32; }
+  ~ExactScope() { ctx->precision = saved; }
+};
+
+// RAII: make the context's GPU current for the duration of an ABI call and restore the caller's device afterwards (lazy
+// hipMalloc in NetBase::ensure, set_param's hipMemcpy and every launch must land on the context's device even when the caller
+// works with several GPUs in one process or has changed the current device since cgd_ctx_create).
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(const cgd_ctx* c) {
+    if (c && hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 // fold the oldest records (all but `keep_last`) into the running totals and recycle their events
 int cgd_prof_fold(cgd_ctx* ctx, size_t keep_last);
 

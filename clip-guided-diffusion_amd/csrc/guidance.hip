@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void scalars_kernel(const float* __restrict__ 
 }
 
 // mode 0: ancestral p_sample  (mean' = mean + var*g ; sample = mean' + nonzero*exp(.5 logvar)*noise ; yields x0)
-// mode 1: DDIM eta=0          (eps' = eps(x0) - sqrt(1-ab)*g ; x0' ; sample = sqrt(ab_prev)*x0' + sqrt(1-ab_prev)*eps')
+// mode 1: DDIM eta=0          (eps' = eps(x0) - sqrt(1-ab)*g ; x0' ; sample = sqrt(ab_prev)*x0' + sqrt(1-ab_prev)*eps' ; yields x0, not x0')
 __global__ __launch_bounds__(256) void sample_update_kernel(const float* __restrict__ x, const float* __restrict__ x0,
                                                             const float* __restrict__ mean, const float* __restrict__ logvar,
                                                             const float* __restrict__ g, const float* __restrict__ noise,
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void sample_update_kernel(const float* __restr
       const float p0 = k.sqrt_recip * xv - k.sqrt_recipm1 * eps;
       const float eps2 = (k.sqrt_recip * xv - p0) / k.sqrt_recipm1;
       sample[i] = p0 * k.sqrt_ab_prev + k.sqrt_one_minus_ab_prev * eps2;
-      x0_out[i] = p0;
+      x0_out[i] = x0[i];  // [3P] ddim_sample_with_grad yields out_orig["pred_xstart"]: the UNCONDITIONED prediction; x0' only builds the sample
     }
   }
 }

@@ -289,14 +289,6 @@ int Lpips::features(const float* x, int Bn, int Hh, int Ww, hipStream_t s) {
   return 0;
 }
 
-// RAII: exact-fp32 MFMA mode for the duration of a trunk pass
-struct ExactScope {
-  cgd_ctx* ctx;
-  int saved;
-  explicit ExactScope(cgd_ctx* c) : ctx(c), saved(c->precision) { c->precision = CGD_PREC_F32; }
-  ~ExactScope() { ctx->precision = saved; }
-};
-
 int Lpips::set_reference(const float* ref, int Bn, int Hh, int Ww, hipStream_t s) {
   ExactScope exact(ctx);
   CGD_TRY(features(ref, Bn, Hh, Ww, s));
@@ -413,10 +405,12 @@ int cgd_lpips_manifest(void (*cb)(const char*, int64_t, void*), void* user) {
 void cgd_lpips_destroy(cgd_lpips* v) { delete v; }
 int cgd_lpips_num_params(cgd_lpips* v) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return (int)v->net.params.size();
 }
 int cgd_lpips_param_info(cgd_lpips* v, int i, char* buf, int len, int64_t* numel) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   if (i < 0 || i >= (int)v->net.params.size()) return -1;
   snprintf(buf, len, "%s", v->net.params[i].name.c_str());
   if (numel) *numel = v->net.params[i].numel;
@@ -424,18 +418,22 @@ int cgd_lpips_param_info(cgd_lpips* v, int i, char* buf, int len, int64_t* numel
 }
 int cgd_lpips_set_param(cgd_lpips* v, const char* name, const float* data, int64_t numel) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return v->net.set_param(name, data, numel);
 }
 int cgd_lpips_finalize(cgd_lpips* v) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return v->net.finalize(nullptr);
 }
 int cgd_lpips_set_reference(cgd_lpips* v, const float* ref_nchw, int B, int H, int W, void* stream) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return v->net.set_reference(ref_nchw, B, H, W, LS(stream));
 }
 int cgd_lpips_loss_grad(cgd_lpips* v, const float* x_nchw, float grad_scale, float* loss, float* g_nchw, int accumulate, void* stream) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return v->net.loss_grad(x_nchw, grad_scale, loss, g_nchw, accumulate, LS(stream));
 }
 }  // extern "C"

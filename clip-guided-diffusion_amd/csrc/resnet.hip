@@ -575,10 +575,12 @@ void cgd_rn_destroy(cgd_rn* v) {
 }
 int cgd_rn_num_params(cgd_rn* v) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return (int)v->net.params.size();
 }
 int cgd_rn_param_info(cgd_rn* v, int i, char* buf, int len, int64_t* numel) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   if (i < 0 || i >= (int)v->net.params.size()) return -1;
   snprintf(buf, len, "%s", v->net.params[i].name.c_str());
   if (numel) *numel = v->net.params[i].numel;
@@ -586,20 +588,26 @@ int cgd_rn_param_info(cgd_rn* v, int i, char* buf, int len, int64_t* numel) {
 }
 int cgd_rn_set_param(cgd_rn* v, const char* name, const float* data, int64_t numel) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   cgd_frag_cache_clear(v->net.ctx);
   return v->net.set_param(name, data, numel);
 }
 int cgd_rn_finalize(cgd_rn* v) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   cgd_frag_cache_clear(v->net.ctx);
   return v->net.finalize(nullptr);
 }
 int cgd_rn_forward(cgd_rn* v, const float* img, int N, float* emb, void* stream) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
+  ExactScope exact(v->net.ctx);  // ReLU tower: exact-fp32 MFMA products (see common.h)
   return v->net.forward(img, N, emb, (hipStream_t)stream);
 }
 int cgd_rn_dgrad(cgd_rn* v, const float* d_emb, float* d_img, void* stream) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
+  ExactScope exact(v->net.ctx);
   return v->net.dgrad(d_emb, d_img, (hipStream_t)stream);
 }
 }  // extern "C"

@@ -613,10 +613,12 @@ void cgd_unet_destroy(cgd_unet* u) {
 }
 int cgd_unet_num_params(cgd_unet* u) {
   if (!u) return -3;
+  DeviceScope dev_scope(u->net.ctx);
   return (int)u->net.params.size();
 }
 int cgd_unet_param_info(cgd_unet* u, int i, char* buf, int len, int64_t* numel) {
   if (!u) return -3;
+  DeviceScope dev_scope(u->net.ctx);
   if (i < 0 || i >= (int)u->net.params.size()) return -1;
   snprintf(buf, len, "%s", u->net.params[i].name.c_str());
   if (numel) *numel = u->net.params[i].numel;
@@ -624,20 +626,24 @@ int cgd_unet_param_info(cgd_unet* u, int i, char* buf, int len, int64_t* numel) 
 }
 int cgd_unet_set_param(cgd_unet* u, const char* name, const float* data, int64_t numel) {
   if (!u) return -3;
+  DeviceScope dev_scope(u->net.ctx);
   cgd_frag_cache_clear(u->net.ctx);
   return u->net.set_param(name, data, numel);
 }
 int cgd_unet_finalize(cgd_unet* u) {
   if (!u) return -3;
+  DeviceScope dev_scope(u->net.ctx);
   cgd_frag_cache_clear(u->net.ctx);
   return u->net.finalize(nullptr);
 }
 int cgd_unet_forward(cgd_unet* u, const float* x, const float* t, const int64_t* y, float* out, int B, int H, int W, void* stream) {
   if (!u) return -3;
+  DeviceScope dev_scope(u->net.ctx);
   return u->net.forward(x, t, y, out, B, H, W, (hipStream_t)stream);
 }
 int cgd_unet_dgrad(cgd_unet* u, const float* g_out, float* g_x, void* stream) {
   if (!u) return -3;
+  DeviceScope dev_scope(u->net.ctx);
   return u->net.dgrad(g_out, g_x, (hipStream_t)stream);
 }
 }

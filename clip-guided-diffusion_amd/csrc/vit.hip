@@ -242,10 +242,12 @@ void cgd_vit_destroy(cgd_vit* v) {
 }
 int cgd_vit_num_params(cgd_vit* v) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return (int)v->net.params.size();
 }
 int cgd_vit_param_info(cgd_vit* v, int i, char* buf, int len, int64_t* numel) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   if (i < 0 || i >= (int)v->net.params.size()) return -1;
   snprintf(buf, len, "%s", v->net.params[i].name.c_str());
   if (numel) *numel = v->net.params[i].numel;
@@ -253,20 +255,24 @@ int cgd_vit_param_info(cgd_vit* v, int i, char* buf, int len, int64_t* numel) {
 }
 int cgd_vit_set_param(cgd_vit* v, const char* name, const float* data, int64_t numel) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   cgd_frag_cache_clear(v->net.ctx);
   return v->net.set_param(name, data, numel);
 }
 int cgd_vit_finalize(cgd_vit* v) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   cgd_frag_cache_clear(v->net.ctx);
   return v->net.finalize(nullptr);
 }
 int cgd_vit_forward(cgd_vit* v, const float* img, int layout, int N, float* emb, void* stream) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return v->net.forward(img, layout, N, emb, (hipStream_t)stream);
 }
 int cgd_vit_dgrad(cgd_vit* v, const float* d_emb, float* d_img, void* stream) {
   if (!v) return -3;
+  DeviceScope dev_scope(v->net.ctx);
   return v->net.dgrad(d_emb, d_img, (hipStream_t)stream);
 }
 }

@@ -75,7 +75,7 @@ class MakeCutouts(th.nn.Module):
         x_pm1 = (input.detach().float() * 2 - 1).contiguous()
         out = th.empty((ncut * B, 3, self.cut_size, self.cut_size), device=input.device, dtype=th.float32)
         self.ctx.check(self.ctx.lib.cgd_cutouts_fwd(self.ctx.h, x_pm1.data_ptr(), geo.data_ptr(), out.data_ptr(), B, H, W, ncut,
-                                                    self.cut_size, 0, 0, L.stream_ptr()))
+                                                    self.cut_size, 0, 0, self.ctx.stream()))
         mean = th.tensor(CLIP_MEAN, device=input.device).view(1, 3, 1, 1)
         std = th.tensor(CLIP_STD, device=input.device).view(1, 3, 1, 1)
         return out * std + mean
@@ -99,7 +99,7 @@ class _CutoutsFunction(th.autograd.Function):
         d = (d_out.float() * std).contiguous()
         g = th.empty(ctx.in_shape, device=d_out.device, dtype=th.float32)
         mk.ctx.check(mk.ctx.lib.cgd_cutouts_bwd(mk.ctx.h, d.data_ptr(), ctx.geo.data_ptr(), g.data_ptr(), B, H, W, ctx.ncut, mk.cut_size,
-                                                0, 0, 0, L.stream_ptr()))
+                                                0, 0, 0, mk.ctx.stream()))
         return g * 2, None, None, None
 
 
@@ -168,6 +168,7 @@ class ClipGuidance:
         self.scalars = None
         self.coords_tape = None  # optional replay of cutout coordinates (tests)
         self.calls = 0
+        self.last_ran = False    # did the last call evaluate the guidance (False on a --reduce-clip gated step)?
         self._wm = {}
         self._buf = {}
 
@@ -191,12 +192,13 @@ class ClipGuidance:
         """x, x0 = pred_xstart, x_in = blend: (B,3,H,W) on the GPU.  Returns g (B,3,H,W) or None when the
         reduce_clip gate skips this step (the reference returns zeros_like(x))."""
         skip, cutn = self.schedule()
+        self.last_ran = not skip
         if skip:
             return None
         ctx, lib = self.ctx, self.ctx.lib
         B, _, H, W = x.shape
         dev = x.device
-        s = L.stream_ptr()
+        s = ctx.stream()
         if self.coords_tape is not None:
             coords = self.coords_tape[self.calls]
         else:

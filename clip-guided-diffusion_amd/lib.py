@@ -188,6 +188,11 @@ class Context:
     def precision(self):
         return self.lib.cgd_get_precision(self.h)
 
+    def stream(self):
+        """The caller's current HIP stream ON THE CONTEXT'S DEVICE (not on whatever device happens to be current)."""
+        import torch
+        return torch.cuda.current_stream(self.device).cuda_stream
+
     def close(self):
         if getattr(self, "h", None):
             for net in list(self._nets):
@@ -210,6 +215,7 @@ def ptr(t):
     return t.data_ptr()
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """Current HIP stream of `device` (default: the current device).  Product code uses Context.stream()."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream

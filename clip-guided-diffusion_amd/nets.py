@@ -115,7 +115,7 @@ class UNet(_Net):
         if out is None:
             out = th.empty((B, self.out_channels, H, W), device=x.device, dtype=th.float32)
         self.ctx.check(self.ctx.lib.cgd_unet_forward(self.h, x.data_ptr(), t.data_ptr(), L.ptr(y), out.data_ptr(), B, H, W,
-                                                     L.stream_ptr()))
+                                                     self.ctx.stream()))
         self._keep = (x, t, y)  # inputs must outlive the enqueued work
         return out
 
@@ -131,7 +131,7 @@ class UNet(_Net):
         B, _, H, W = g_out.shape
         if g_x is None:
             g_x = th.empty((B, 3, H, W), device=g_out.device, dtype=th.float32)
-        self.ctx.check(self.ctx.lib.cgd_unet_dgrad(self.h, g_out.data_ptr(), g_x.data_ptr(), L.stream_ptr()))
+        self.ctx.check(self.ctx.lib.cgd_unet_dgrad(self.h, g_out.data_ptr(), g_x.data_ptr(), self.ctx.stream()))
         self._keep_g = g_out
         return g_x
 
@@ -176,7 +176,7 @@ class ClipImageTower(_Net):
         N = img.shape[0] if layout == 0 else int(n)
         if out is None:
             out = th.empty((N, self.out_dim), device=img.device, dtype=th.float32)
-        self.ctx.check(self.ctx.lib.cgd_vit_forward(self.h, img.data_ptr(), layout, N, out.data_ptr(), L.stream_ptr()))
+        self.ctx.check(self.ctx.lib.cgd_vit_forward(self.h, img.data_ptr(), layout, N, out.data_ptr(), self.ctx.stream()))
         self._layout, self._n, self._keep = layout, N, img
         return out
 
@@ -184,7 +184,7 @@ class ClipImageTower(_Net):
         d_emb = d_emb.contiguous().float()
         if d_img is None:
             d_img = th.empty_like(self._keep)
-        self.ctx.check(self.ctx.lib.cgd_vit_dgrad(self.h, d_emb.data_ptr(), d_img.data_ptr(), L.stream_ptr()))
+        self.ctx.check(self.ctx.lib.cgd_vit_dgrad(self.h, d_emb.data_ptr(), d_img.data_ptr(), self.ctx.stream()))
         self._keep_g = d_emb
         return d_img
 
@@ -232,7 +232,7 @@ class ClipResNetTower(_Net):
         N = img.shape[0]
         if out is None:
             out = th.empty((N, self.out_dim), device=img.device, dtype=th.float32)
-        self.ctx.check(self.ctx.lib.cgd_rn_forward(self.h, img.data_ptr(), N, out.data_ptr(), L.stream_ptr()))
+        self.ctx.check(self.ctx.lib.cgd_rn_forward(self.h, img.data_ptr(), N, out.data_ptr(), self.ctx.stream()))
         self._keep = img
         return out
 
@@ -240,7 +240,7 @@ class ClipResNetTower(_Net):
         d_emb = d_emb.contiguous().float()
         if d_img is None:
             d_img = th.empty_like(self._keep)
-        self.ctx.check(self.ctx.lib.cgd_rn_dgrad(self.h, d_emb.data_ptr(), d_img.data_ptr(), L.stream_ptr()))
+        self.ctx.check(self.ctx.lib.cgd_rn_dgrad(self.h, d_emb.data_ptr(), d_img.data_ptr(), self.ctx.stream()))
         self._keep_g = d_emb
         return d_img
 
@@ -261,7 +261,7 @@ class LpipsVGG(_Net):
         """ref (B,3,H,W) in [-1,1] (the init image); H, W multiples of 16."""
         ref = ref.contiguous().float()
         B, _, H, W = ref.shape
-        self.ctx.check(self.ctx.lib.cgd_lpips_set_reference(self.h, ref.data_ptr(), B, H, W, L.stream_ptr()))
+        self.ctx.check(self.ctx.lib.cgd_lpips_set_reference(self.h, ref.data_ptr(), B, H, W, self.ctx.stream()))
         self._ref = ref
         return self
 
@@ -274,7 +274,7 @@ class LpipsVGG(_Net):
         if loss is None:
             loss = th.empty(x.shape[0], device=x.device, dtype=th.float32)
         self.ctx.check(self.ctx.lib.cgd_lpips_loss_grad(self.h, x.data_ptr(), float(grad_scale), loss.data_ptr(), g.data_ptr(),
-                                                       int(bool(accumulate)), L.stream_ptr()))
+                                                       int(bool(accumulate)), self.ctx.stream()))
         self._keep = x
         return loss, g
 

@@ -34,7 +34,7 @@ class GuidedSampler:
         ctx, lib = self.ctx, self.ctx.lib
         B, _, H, W = x.shape
         dev = x.device
-        s = L.stream_ptr()
+        s = ctx.stream()
         native = isinstance(cond_fn, ClipGuidance)
         fac_index = cond_fn.fac_index() if native else None
         coef = self.tables.step_coef(i, fac_index)

@@ -159,9 +159,10 @@ class GaussianDiffusion:
     def ddim_sample_with_grad(self, model, x, t, clip_denoised=True, cond_fn=None, model_kwargs=None, eta=0.0, noise=None):
         with th.enable_grad():
             x = x.detach().requires_grad_()
-            out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
+            out_orig = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
+            out = out_orig
             if cond_fn is not None:
-                out = self.condition_score_with_grad(cond_fn, out, x, t, model_kwargs)
+                out = self.condition_score_with_grad(cond_fn, out_orig, x, t, model_kwargs)
         out["pred_xstart"] = out["pred_xstart"].detach()
         x = x.detach()
         eps = self._eps_from_xstart(x, t, out["pred_xstart"])
@@ -173,7 +174,10 @@ class GaussianDiffusion:
         mean_pred = out["pred_xstart"] * th.sqrt(ab_prev) + th.sqrt(1 - ab_prev - sigma ** 2) * eps
         nonzero = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
         sample = mean_pred + nonzero * sigma * noise
-        return {"sample": sample.detach(), "pred_xstart": out["pred_xstart"]}
+        # [3P] crowsonkb/guided-diffusion@fb47224 `ddim_sample_with_grad` yields the UNCONDITIONED prediction
+        # (`out_orig["pred_xstart"].detach()`); only the sample is built from the guidance-conditioned x0'.  (The plain
+        # `ddim_sample` returns the conditioned one.)  `condition_score_with_grad` works on a copy, so out_orig is intact.
+        return {"sample": sample.detach(), "pred_xstart": out_orig["pred_xstart"].detach()}
 
     # -- progressive loops ---------------------------------------------------------
     def _loop(self, step_fn, model, shape, noise, clip_denoised, cond_fn, model_kwargs, device, skip_timesteps,

@@ -147,7 +147,18 @@ def make_cond_fn(*, diffusion, clip_model, make_cutouts, target_embeds, weights,
             log["Init VGG Loss"] = init_l.item()
             loss = loss + init_l
         log["Total Loss"] = loss.item()
+        if state.get("diag"):
+            # parity tier T4: the legs of the closed-form chain the HIP path evaluates without autograd
+            # (SURVEY.md 8a-1), taken here by autograd on the very graph the reference differentiates.  Extra backward passes
+            # over a retained graph: they do not change `g`.
+            clip_leg = clip_l if not (init_tensor is not None and init_scale != 0) else clip_l + init_l
+            g_clip_in = th.autograd.grad(clip_leg, x_in, retain_graph=True)[0]
+            g_in = th.autograd.grad(loss, x_in, retain_graph=True)[0]
+            g_x0 = th.autograd.grad(loss, out["pred_xstart"], retain_graph=True)[0]
+            state["legs"] = {"g_clip_in": g_clip_in.detach(), "g_in": g_in.detach(), "g_x0": g_x0.detach()}
         g = -th.autograd.grad(loss, x)[0]
+        if state.get("diag"):
+            state["legs"]["g_raw"] = g.detach().clone()
         if use_magnitude:
             mag = g.square().mean().sqrt()
             log["Magnitude"] = mag.item()

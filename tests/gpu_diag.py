@@ -23,23 +23,27 @@ GROUPS = {
     "vit": [lambda: pc.check_vit("ViT-B/32", 0), lambda: pc.check_vit("ViT-B/32", 1)],
     "resnet": [lambda: pc.check_resnet("tiny", 0, config=(64, 64, (1, 1, 1, 1), 128, 32)),
                lambda: pc.check_resnet("tiny", 1, config=(64, 64, (1, 1, 1, 1), 128, 32)),
-               lambda: pc.check_resnet("RN50", 0), lambda: pc.check_resnet("RN50", 1),
+               lambda: pc.check_resnet("RN50", 1),
                lambda: pc.check_resnet("x4-tiny", 0, config=(96, 80, (1, 1, 1, 1), 64, 40)),
                lambda: pc.check_resnet("x16-tiny", 1, config=(64, 96, (1, 1, 1, 1), 64, 48)),
-               lambda: _sc().check_step("mini", 0, respacing="50", steps=2, B=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32))],
-    "dual": [lambda: _sc().check_step("mini", 1, respacing="50", steps=2, B=2, P=2, dual=True),
-             lambda: _sc().check_step("mini", 0, respacing="50", steps=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32), dual=True)],
+               lambda: _sc().check_step("mini", 1, steps=2, B=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32))],
+    "dual": [lambda: _sc().check_step("mini", 1, steps=2, B=2, P=2, dual=True),
+             lambda: _sc().check_step("mini", 1, steps=2, rn_cfg=(64, 64, (1, 1, 1, 1), 128, 32), dual=True)],
     "lpips": [lambda: pc.check_lpips(0), lambda: pc.check_lpips(1),
-              lambda: _sc().check_step("mini", 1, respacing="50", steps=2, B=2, init_scale=100.0)],
-    "unet64": [lambda: pc.check_unet("cfg64", 0), lambda: pc.check_unet("cfg64", 1), lambda: pc.check_unet("cfg64", 2)],
+              lambda: _sc().check_step("mini", 1, steps=2, B=2, init_scale=1000.0)],
+    "vit_other": [lambda: pc.check_vit("ViT-B/16", 1, N=2), lambda: pc.check_vit("ViT-L/14", 1, N=2)],
+    "unet64": [lambda: pc.check_unet("cfg64", 0), lambda: pc.check_unet("cfg64", 1)],
+    "unet128": [lambda: pc.check_unet("cfg128", 1)],
     "unet256": [lambda: pc.check_unet("cfg256", 1)],
-    "step": [lambda: _sc().check_step("mini", 0, respacing="4", steps=4),
-             lambda: _sc().check_step("mini", 1, respacing="4", steps=4),
-             lambda: _sc().check_step("mini", 1, ddim=True, respacing="4", steps=4),
-             lambda: _sc().check_step("mini", 1, respacing="50", steps=3, B=2, P=2, use_magnitude=True, sat_scale=30.0),
-             lambda: _sc().check_step("mini64", 1, respacing="25", schedule="cosine", steps=2, P=3, hw=(32, 48), scales=(5.0, 1e-5, 50.0),
-                                      use_magnitude=True),
-             lambda: _sc().check_step("mini", 1, respacing="50", steps=6, cutn=16, reduce_clip=True, progressive_cutout=True)],
+    "unet512": [lambda: pc.check_unet("cfg512", 1, timestep=417.5)],
+    "step": [lambda: _sc().check_step("mini", 0, steps=4),
+             lambda: _sc().check_step("mini", 1, steps=4),
+             lambda: _sc().check_step("mini", 1, ddim=True, steps=4),
+             lambda: _sc().check_step("mini", 1, steps=3, B=2, P=2, use_magnitude=True, sat_scale=3.0, counter_quirk=True),
+             lambda: _sc().check_step("mini64", 1, respacing="25", schedule="cosine", steps=2, P=3, hw=(32, 48), use_magnitude=True),
+             lambda: _sc().check_step("mini", 1, steps=6, cutn=16, reduce_clip=True, progressive_cutout=True, counter_quirk=True, t_first=10)],
+    "headline": [lambda: _sc().check_headline_step(1)],
+    "cfg5": [lambda: _sc().check_step("cfg256", 1, steps=1, hw=(256, 288), respacing="500", P=3, cutn=4)],
 }
 
 
@@ -67,7 +71,8 @@ def main():
                 r["group"] = gname
                 r["secs"] = round(dt, 2)
                 results.append(r)
-                print(f"{'OK  ' if r['ok'] else 'FAIL'} {r['name']:<70s} abs {r['err_abs']:.3e} rel {r['err_rel']:.3e} ref {r['ref_max']:.3e}",
+                print(f"{'OK  ' if r['ok'] else 'FAIL'} {r['name']:<86s} abs {r['err_abs']:.3e} rel {r['err_rel']:.3e} ref {r['ref_max']:.3e}"
+                      f" {r.get('criterion', '')}{'' if r.get('ok_strict', True) else ' (strict: no)'}{' VACUOUS' if r.get('vacuous') else ''}",
                       flush=True)
                 if "trace" in r:
                     print(r["trace"], flush=True)

@@ -2,7 +2,10 @@
 
 Each check returns a list of records {name, err_abs, err_rel, ref_max, ok}.  Used by tests/test_gpu_*.py
 (pytest -m gpu) and by tests/gpu_diag.py (one-shot report written to gpurun_out/).
-Tolerance: north_star's rtol 1e-3 / atol 1e-4 (fp32), applied as |a-b| <= atol*max(1,|ref|max) + rtol*|b|.
+Tolerance: north_star's rtol 1e-3 / atol 1e-4 (fp32), applied literally, |a-b| <= atol + rtol*|ref| per element (`rec`); test
+inputs are scaled so that outputs are O(1), and the seed of every backward pass so that the reference gradient has unit peak
+(backward passes are linear in the seed).  Exceptions carry a NAMED criterion and a reason in the record (`unit-peak`,
+`relu-flips`); the strict verdict is always reported beside it.
 """
 import math
 import os
@@ -16,33 +19,65 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 RTOL, ATOL = 1e-3, 1e-4
+MIN_PEAK = 100 * ATOL  # a reference tensor whose peak is below this passes on atol alone: such a record is flagged, not trusted
 DEV = "cuda"
 
 
-def rec(name, got, ref, rtol=RTOL, atol=ATOL):
+def rec(name, got, ref, rtol=RTOL, atol=ATOL, unit_peak=None, allow_small=False):
+    """One parity record.  The criterion is north_star's, literally: |got - ref| <= atol + rtol * |ref| for EVERY element
+    (`ok_strict`, criterion "strict") — no scaling of atol by the tensor's peak.
+
+    `unit_peak="<reason>"` selects the NAMED second criterion "unit-peak" for a tensor whose scale is not O(1) for the stated
+    reason: the same inequality after dividing both tensors by P = max|ref| (applied only when P > 1, so it is never looser than
+    strict for O(1) tensors), i.e. atol counted in units of the tensor's peak.  Both verdicts are always reported; `ok` is the
+    verdict of the criterion the caller named.  A reference whose peak is below 100 * atol would pass on atol alone: the record
+    is marked `vacuous` and fails unless the caller passes allow_small=True (exact-zero channels and the like)."""
     got = got.detach().double().cpu()
     ref = ref.detach().double().cpu()
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     refmax = ref.abs().max().item() if ref.numel() else 0.0
     diff = (got - ref).abs()
     err = diff.max().item() if ref.numel() else 0.0
-    tol = atol * max(1.0, refmax) + rtol * ref.abs()
-    ok = bool((diff <= tol).all().item()) and bool(th.isfinite(got).all().item())
-    return {"name": name, "err_abs": err, "err_rel": err / (refmax + 1e-30), "ref_max": refmax, "ok": ok}
+    finite = bool(th.isfinite(got).all().item())
+    ok_strict = finite and bool((diff <= atol + rtol * ref.abs()).all().item())
+    scale = max(1.0, refmax)
+    ok_unit = finite and bool((diff <= atol * scale + rtol * ref.abs()).all().item())
+    vacuous = refmax < MIN_PEAK and not allow_small
+    crit = "unit-peak" if unit_peak else "strict"
+    ok = (ok_unit if unit_peak else ok_strict) and not vacuous
+    out = {"name": name, "err_abs": err, "err_rel": err / (refmax + 1e-30), "ref_max": refmax, "ok_strict": ok_strict,
+           "criterion": crit, "ok": ok}
+    if unit_peak:
+        out["reason"] = unit_peak
+    if vacuous:
+        out["vacuous"] = True
+    return out
 
 
-def rec_l2(name, got, ref, tol):
-    """Relative L2 criterion for gradients of ReLU / max-pool networks.  Those gradients are discontinuous in the activations:
-    any two implementations whose activations differ in the last bits flip a few masks, which moves individual gradient entries
-    far more than rtol 1e-3 (the CPU oracle in fp32 against itself in fp64: max 4-6e-3 of the peak, L2 0.9-1.4e-3 on the CLIP
-    ResNet towers).  `err_rel` holds the L2 ratio, `err_abs` the max abs difference."""
+def rec_flips(name, got, ref, tol_l2, max_viol=1e-3):
+    """NAMED criterion "relu-flips" for gradients of ReLU / max-pool networks.  Those gradients are discontinuous in the
+    activations: any two implementations whose activations differ in the last bits flip a few masks, which moves individual
+    gradient entries far more than rtol 1e-3 (the CPU oracle in fp32 against itself in fp64: max 4-6e-3 of the peak, L2
+    0.9-1.4e-3 on the CLIP ResNet towers).  Passes when (a) the strict inequality holds for all but `max_viol` of the elements
+    and (b) the relative L2 error is below `tol_l2`.  `err_rel` holds the L2 ratio, `err_abs` the max abs difference; the strict
+    verdict is reported beside it."""
     got = got.detach().double().cpu()
     ref = ref.detach().double().cpu()
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    diff = (got - ref).abs()
+    viol = (diff > ATOL + RTOL * ref.abs()).double().mean().item()
     l2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
-    ok = l2 <= tol and bool(th.isfinite(got).all().item())
-    return {"name": name + f" [L2 <= {tol:g}]", "err_abs": (got - ref).abs().max().item(), "err_rel": l2, "ref_max": ref.abs().max().item(),
-            "ok": ok}
+    finite = bool(th.isfinite(got).all().item())
+    return {"name": name + f" [L2 <= {tol_l2:g}, strict on >= {1 - max_viol:.4f} of the elements]", "err_abs": diff.max().item(),
+            "err_rel": l2, "ref_max": ref.abs().max().item(), "ok_strict": finite and viol == 0.0, "criterion": "relu-flips",
+            "reason": "discontinuous gradient (ReLU / max-pool masks)", "viol_frac": viol,
+            "ok": finite and l2 <= tol_l2 and viol <= max_viol}
+
+
+def unit_seed(grad_ref):
+    """Backward passes are linear in their seed: returns the factor that brings the reference gradient to unit peak, so that
+    atol 1e-4 means 1e-4 of the gradient's peak whatever the gain of the random weights is."""
+    return 1.0 / max(grad_ref.detach().abs().max().item(), 1e-30)
 
 
 def _ctx(precision):
@@ -66,13 +101,15 @@ def check_gemm(precision):
         cases += [(800, 768, 768, 513, 1), (200, 96, 256, 513, 2), (128, 160, 64, 513, 1), (1000, 2304, 768, 513, 1),
                   (70, 32, 3072, 513, 5), (784, 768, 3072, 513, 0)]
     for (M, N, K, tile, sk) in cases:
+        # O(1) outputs: unit-variance product term (alpha = 1/sqrt(K)), small bias and residual
         A = th.randn(M, K, generator=g(1))
         B = th.randn(N, K, generator=g(2))
-        bias = th.randn(N, generator=g(3))
-        R = th.randn(M, N, generator=g(4))
-        ref = 0.5 * (A.double() @ B.double().T) + bias.double() + R.double()
-        got = ops.gemm(ctx, A.to(DEV), B.to(DEV), bias.to(DEV), R.to(DEV), alpha=0.5, force_tile=tile, splitk=sk)
-        out.append(rec(f"gemm[p{precision}] {M}x{N}x{K} tile{tile} sk{sk}", got, ref.float(), atol=ATOL * math.sqrt(K)))
+        bias = 0.3 * th.randn(N, generator=g(3))
+        R = 0.3 * th.randn(M, N, generator=g(4))
+        alpha = 1.0 / math.sqrt(K)
+        ref = alpha * (A.double() @ B.double().T) + bias.double() + R.double()
+        got = ops.gemm(ctx, A.to(DEV), B.to(DEV), bias.to(DEV), R.to(DEV), alpha=alpha, force_tile=tile, splitk=sk)
+        out.append(rec(f"gemm[p{precision}] {M}x{N}x{K} tile{tile} sk{sk}", got, ref.float()))
     return out
 
 
@@ -85,7 +122,7 @@ def check_conv(precision):
         Hs, Ws = (H // 2, W // 2) if ups else (H, W)
         x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
         w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)
-        b = th.randn(Co, generator=g(7))
+        b = 0.3 * th.randn(Co, generator=g(7))
         xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
         ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).float()
         wf, wd = ops.pack_conv3x3(w)
@@ -96,8 +133,9 @@ def check_conv(precision):
             dy = th.randn(Bn, Co, H, W, generator=g(8))
             xr = x.double().requires_grad_()
             (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
-            got = ops.conv3x3(ctx, dy.permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None)
-            out.append(rec(f"conv3x3 dgrad[p{precision}] {Ci}<-{Co}", got.permute(0, 3, 1, 2), xr.grad.float()))
+            sd = unit_seed(xr.grad)
+            got = ops.conv3x3(ctx, (dy * sd).permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None)
+            out.append(rec(f"conv3x3 dgrad[p{precision}] {Ci}<-{Co}", got.permute(0, 3, 1, 2), (xr.grad * sd).float()))
     # halo-staged conv kernel (tile code 512): fragment-packed bf16 weights, patch staging, split-K over channel chunks
     if precision != 0:
         # hconv2_kernel variants: bit 0: 0 = 8x16-pixel tile (4 wavefronts), 1 = 16x16 pixels (8 wavefronts);
@@ -110,8 +148,8 @@ def check_conv(precision):
                 Hs, Ws = (H // 2, W // 2) if ups else (H, W)
                 x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
                 w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)
-                b = th.randn(Co, generator=g(7))
-                r = th.randn(Bn, H, W, Co, generator=g(17))
+                b = 0.3 * th.randn(Co, generator=g(7))
+                r = 0.3 * th.randn(Bn, H, W, Co, generator=g(17))
                 xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
                 ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).float() + r.permute(0, 3, 1, 2)
                 wf, wd = ops.pack_conv3x3(w)
@@ -124,23 +162,26 @@ def check_conv(precision):
                     xr = x.double().requires_grad_()
                     (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
                     wdfrag = ops.pack_conv3x3_frag(ctx, w.to(DEV), dgrad=True)
-                    got = ops.conv3x3(ctx, dy.permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None, force_tile=512, splitk=sk, w_frag=wdfrag)
-                    out.append(rec(f"hconv v{var} dgrad[p{precision}] {H}x{W} {Ci}<-{Co} sk{sk}", got.permute(0, 3, 1, 2), xr.grad.float()))
+                    sd = unit_seed(xr.grad)
+                    got = ops.conv3x3(ctx, (dy * sd).permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None, force_tile=512, splitk=sk,
+                                      w_frag=wdfrag)
+                    out.append(rec(f"hconv v{var} dgrad[p{precision}] {H}x{W} {Ci}<-{Co} sk{sk}", got.permute(0, 3, 1, 2), (xr.grad * sd).float()))
         ctx.check(ctx.lib.cgd_set_hconv(ctx.h, 1 + 16 * 0, 256))  # back to the default variant
     # thin ends
     x = th.randn(2, 3, 16, 24, generator=g(9))
     w = th.randn(64, 3, 3, 3, generator=g(10)) / math.sqrt(27)
-    b = th.randn(64, generator=g(11))
+    b = 0.3 * th.randn(64, generator=g(11))
     wf, wd = ops.pack_conv3x3(w)
     got = ops.conv_in(ctx, x.to(DEV), wf.to(DEV), b.to(DEV), 64)
     out.append(rec("conv_in 3->64", got.permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1)))
     dy = th.randn(2, 64, 16, 24, generator=g(12))
     xr = x.clone().requires_grad_()
     (F.conv2d(xr, w, None, padding=1) * dy).sum().backward()
-    got = ops.conv_thin_out(ctx, dy.permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None, 3)
-    out.append(rec("conv_thin_out dgrad 64->3", got, xr.grad))
+    sd = unit_seed(xr.grad)
+    got = ops.conv_thin_out(ctx, (dy * sd).permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None, 3)
+    out.append(rec("conv_thin_out dgrad 64->3", got, xr.grad * sd))
     w6 = th.randn(6, 64, 3, 3, generator=g(13)) / math.sqrt(9 * 64)
-    b6 = th.randn(6, generator=g(14))
+    b6 = 0.3 * th.randn(6, generator=g(14))
     wf6, wd6 = ops.pack_conv3x3(w6)
     h = th.randn(2, 64, 16, 24, generator=g(15))
     got = ops.conv_thin_out(ctx, h.permute(0, 2, 3, 1).contiguous().to(DEV), wf6.to(DEV), b6.to(DEV), 6)
@@ -148,8 +189,9 @@ def check_conv(precision):
     d6 = th.randn(2, 6, 16, 24, generator=g(16))
     hr = h.clone().requires_grad_()
     (F.conv2d(hr, w6, None, padding=1) * d6).sum().backward()
-    got = ops.conv_in(ctx, d6.to(DEV), wd6.to(DEV), None, 64)
-    out.append(rec("conv_in dgrad 6->64", got.permute(0, 3, 1, 2), hr.grad))
+    sd = unit_seed(hr.grad)
+    got = ops.conv_in(ctx, (d6 * sd).to(DEV), wd6.to(DEV), None, 64)
+    out.append(rec("conv_in dgrad 6->64", got.permute(0, 3, 1, 2), hr.grad * sd))
     return out
 
 
@@ -177,8 +219,9 @@ def check_norm():
         (y * dz.double()).sum().backward()
         yd, scr = ops.groupnorm_fwd(ctx, x.to(DEV), gamma.to(DEV), beta.to(DEV), None if fl is None else fl.to(DEV), act=act)
         out.append(rec(f"groupnorm fwd B{B} HW{HW} C{Cc} film{int(film)} act{act}", yd, y.float()))
-        dx = ops.groupnorm_bwd(ctx, x.to(DEV), dz.to(DEV), scr, act=act)
-        out.append(rec(f"groupnorm bwd B{B} HW{HW} C{Cc} film{int(film)} act{act}", dx, xr.grad.float()))
+        sd = unit_seed(xr.grad)
+        dx = ops.groupnorm_bwd(ctx, x.to(DEV), (dz * sd).to(DEV), scr, act=act)
+        out.append(rec(f"groupnorm bwd B{B} HW{HW} C{Cc} film{int(film)} act{act}", dx, (xr.grad * sd).float()))
     for (rows, Cc) in [(50, 768), (7, 1024), (800, 768)]:
         x = th.randn(rows, Cc, generator=g(25)) * 1.5 + 0.3
         gamma = 1 + 0.1 * th.randn(Cc, generator=g(26))
@@ -189,7 +232,9 @@ def check_norm():
         (y * dy.double()).sum().backward()
         yd, st = ops.layernorm_fwd(ctx, x.to(DEV), gamma.to(DEV), beta.to(DEV))
         out.append(rec(f"layernorm fwd {rows}x{Cc}", yd, y.float()))
-        out.append(rec(f"layernorm bwd {rows}x{Cc}", ops.layernorm_bwd(ctx, x.to(DEV), dy.to(DEV), gamma.to(DEV), st), xr.grad.float()))
+        sd = unit_seed(xr.grad)
+        out.append(rec(f"layernorm bwd {rows}x{Cc}", ops.layernorm_bwd(ctx, x.to(DEV), (dy * sd).to(DEV), gamma.to(DEV), st),
+                       (xr.grad * sd).float()))
     return out
 
 
@@ -241,8 +286,9 @@ def check_attn(precision):
         at = ops.Attention(ctx, nb, heads, T, d, legacy, DEV)
         got = at.forward(qkv.to(DEV))
         out.append(rec(f"attn fwd[p{precision}] nb{nb} h{heads} T{T} d{d} legacy{legacy}", got, ref.float()))
-        dq = at.backward(qkv.to(DEV), dout.to(DEV))
-        out.append(rec(f"attn bwd[p{precision}] nb{nb} h{heads} T{T} d{d} legacy{legacy}", dq, qr.grad.float()))
+        sd = unit_seed(qr.grad)
+        dq = at.backward(qkv.to(DEV), (dout * sd).to(DEV))
+        out.append(rec(f"attn bwd[p{precision}] nb{nb} h{heads} T{T} d{d} legacy{legacy}", dq, (qr.grad * sd).float()))
     return out
 
 
@@ -264,6 +310,8 @@ def check_cutouts_loss():
         cut = og.clip_normalize(mk((xr + 1) / 2, coords=coords))
         dy = th.randn(cut.shape, generator=g(51)).double()
         (cut * dy).sum().backward()
+        dy = dy * unit_seed(xr.grad)
+        xr.grad.mul_(unit_seed(xr.grad))
         geo = []
         for (ox, oy, s) in coords:
             geo.append((oy, ox, min(s, H - oy), min(s, W - ox)))
@@ -322,14 +370,25 @@ UNET_CASES = {
                   use_new_attention_order=True),
     "cfg256": dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000,
                    num_head_channels=64),
+    # /root/reference/data/diffusion_model_flags.py:23-40: num_heads=4 => head dims 128 / 192 / 256 (batched-GEMM attention
+    # path), channel_mult (1,1,2,3,4) => 768-channel level
+    "cfg128": dict(image_size=128, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_heads=4,
+                   num_head_channels=-1),
+    # :59-78: channel_mult (0.5,1,1,2,2,4,4) => 128-channel 512x512 level; `rescale_timesteps` (fractional model timesteps)
+    "cfg512": dict(image_size=512, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000,
+                   num_head_channels=64),
 }
 
 
-def build_unet_pair(ctx, case, seed=1234):
+def build_unet_pair(ctx, case, seed=1234, head_scale=1.0):
     from cgd_amd import nets
     from oracle.unet import UNetModel, synthetic_init_
     kw = UNET_CASES[case]
     ref = synthetic_init_(UNetModel(**kw), seed=seed).eval()
+    if head_scale != 1.0:  # small eps-hat / variance head (tests/step_checks.py explains the tame scenario)
+        with th.no_grad():
+            ref.out[2].weight.mul_(head_scale)
+            ref.out[2].bias.mul_(head_scale)
     for p in ref.parameters():
         p.requires_grad_(False)
     dev = nets.UNet(ctx, **kw)
@@ -337,24 +396,25 @@ def build_unet_pair(ctx, case, seed=1234):
     return ref, dev
 
 
-def check_unet(case, precision, B=1, hw=None):
+def check_unet(case, precision, B=1, hw=None, timestep=417.0):
     ctx = _ctx(precision)
     ref, dev = build_unet_pair(ctx, case)
     kw = UNET_CASES[case]
     H, W = hw or (kw["image_size"], kw["image_size"])
     x = th.randn(B, 3, H, W, generator=g(60))
-    t = th.tensor([417.0] * B)
+    t = th.tensor([float(timestep)] * B)
     y = th.randint(0, kw["num_classes"], (B,), generator=g(61)) if kw.get("num_classes") else None
     gout = th.randn(B, 6, H, W, generator=g(62))
     gout[:, 3:] = 0  # the guidance only seeds the epsilon channels
     xr = x.clone().requires_grad_()
     o = ref(xr, t, y)
     (o * gout).sum().backward()
+    sd = unit_seed(xr.grad)
     od = dev.forward(x.to(DEV), t.to(DEV), None if y is None else y.to(DEV))
-    gx = dev.dgrad(gout.to(DEV))
+    gx = dev.dgrad((gout * sd).to(DEV))
     th.cuda.synchronize()
     tag = f"unet[{case} p{precision} B{B} {H}x{W}]"
-    return [rec(f"{tag} forward", od, o.detach()), rec(f"{tag} dgrad", gx, xr.grad)]
+    return [rec(f"{tag} forward", od, o.detach()), rec(f"{tag} dgrad", gx, xr.grad * sd)]
 
 
 def build_vit_pair(ctx, name="ViT-B/32", seed=4321):
@@ -401,11 +461,12 @@ def check_vit(name, precision, N=3):
     ir = img.clone().requires_grad_()
     e = ref.encode_image(ir)
     (e * de).sum().backward()
+    sd = unit_seed(ir.grad)
     ed = dev.encode_image(img.to(DEV))
-    di = dev.dgrad(de.to(DEV))
+    di = dev.dgrad((de * sd).to(DEV))
     th.cuda.synchronize()
     tag = f"vit[{name} p{precision} N{N}]"
-    return [rec(f"{tag} forward", ed, e.detach()), rec(f"{tag} dgrad", di, ir.grad)]
+    return [rec(f"{tag} forward", ed, e.detach()), rec(f"{tag} dgrad", di, ir.grad * sd)]
 
 
 def check_resnet(name, precision, N=2, config=None):
@@ -424,9 +485,11 @@ def check_resnet(name, precision, N=2, config=None):
     ir = img.double().requires_grad_()
     e = ref.encode_image(ir)
     (e * de.double()).sum().backward()
+    sd = unit_seed(ir.grad)
     ed = dev.encode_image(img.to(DEV))
-    di = dev.dgrad(de.to(DEV))
+    di = dev.dgrad((de * sd).to(DEV))
     th.cuda.synchronize()
     tag = f"resnet[{name if config is None else config} p{precision} N{N}]"
-    # forward: the usual tolerance; gradient: relative L2 (see rec_l2), 3e-3 with exact fp32 products, 2e-2 with bf16x3
-    return [rec(f"{tag} forward", ed, e.detach().float()), rec_l2(f"{tag} dgrad", di, ir.grad.float(), 3e-3 if precision == 0 else 2e-2)]
+    # forward: the literal tolerance; gradient: the named `relu-flips` criterion (see rec_flips).  ReLU towers run their
+    # contractions on exact-fp32 MFMA products whatever the context precision is (resnet.hip), so one tolerance serves both.
+    return [rec(f"{tag} forward", ed, e.detach().float()), rec_flips(f"{tag} dgrad", di, (ir.grad * sd).float(), 3e-3)]

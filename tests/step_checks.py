@@ -1,10 +1,27 @@
-"""Whole-step parity (SURVEY.md parity tier T4/T5): the native guided sampler against the CPU oracle's
+"""Whole-step parity (SURVEY.md parity tiers T4 / T5): the native guided sampler against the CPU oracle's
 `p_sample_loop_progressive` / `ddim_sample_loop_progressive` + autograd cond_fn, on the same seeded synthetic
-weights, with a replayed RNG tape (x_T, per-step noise, class ids, cutout coordinates)."""
+weights, with a replayed RNG tape (x_T, per-step noise, class ids, cutout coordinates).
+
+Compared per step, at north_star's literal tolerance (`parity_checks.rec`: |a-b| <= 1e-4 + 1e-3 |ref| per element):
+  * x_{t-1} (`sample`), the yielded x0-hat (`pred_xstart`), the loss scalars of the reference's log line;
+  * **g**, the guidance gradient cond_fn returns (before the magnitude clamp), and the legs of the closed-form chain that
+    replaces autograd, each against oracle autograd on the graph the reference differentiates:
+    `g_clip_in` = d(CLIP [+ LPIPS] loss)/d x_in, `g_direct` = (1-fac) G_in + sqrt(1/abar) G_x0, `seed6` = the UNet-dgrad seed
+    (-sqrt(1/abar-1) G_x0 on the epsilon channels, exact zeros on the variance channels), `g_unet` = UNet^T seed6.
+
+The scenario is the tame one a real checkpoint produces: the step starts MID-schedule from
+x_t = q_sample(x0*, t) — the reference's own init-image prologue (`skip_timesteps` + `init_image`, cgd.py:111-119,250-262) —
+and the synthetic UNet's output head is scaled down so that eps-hat is small: x0-hat = x0* + O(1), the CLIP / TV / range legs of
+g are of the same order and nothing explodes (at t = T-1, x0-hat = 157 (x - eps-hat) with weights that do not predict eps).
+"""
+import itertools
+
 import torch as th
 
 from tests import parity_checks as pc
 from tests.parity_checks import DEV, g, rec
+
+MINI_VIT = (64, 16, 128, 2, 2, 64)
 
 
 def make_tape(B, H, W, nsteps, num_classes, cutn, cut_size, cut_pow=1.0, seed=0):
@@ -18,123 +35,221 @@ def make_tape(B, H, W, nsteps, num_classes, cutn, cut_size, cut_pow=1.0, seed=0)
     return tape
 
 
-def check_step(case="mini", precision=1, ddim=False, steps=3, B=1, cutn=4, vit_cfg=(64, 16, 128, 2, 2, 64), P=1, hw=None,
-               respacing="50", schedule="linear", use_magnitude=False, sat_scale=0.0, scales=(1000.0, 150.0, 50.0), skip=0,
-               weights=None, init_scale=0.0, rn_cfg=None, dual=False, reduce_clip=False, progressive_cutout=False):
-    from cgd_amd import diffusion as dd
-    from cgd_amd import guidance as dg
-    from cgd_amd import lib, nets, sampler
-    from oracle import clip_vit as ocv
-    from oracle import diffusion as od
-    from oracle import guidance as og
+def default_scales(H, W):
+    """(clip_guidance_scale, tv_scale, range_scale): the reference defaults 1000 / 150 / 50 (cgd.py:26-28) at 256x256; the TV and
+    range gradients per pixel scale with 1/(3HW), so the small test images use proportionally smaller scales to keep g = O(0.1-1)
+    like at the headline shape."""
+    f = min(1.0, (H * W) / (256.0 * 256.0) * 8.0)
+    return (1000.0 * f, 150.0 * f, 50.0 * f)
 
-    ctx = lib.Context(0, precision)
-    kw = pc.UNET_CASES[case]
-    H, W = hw or (kw["image_size"], kw["image_size"])
-    ref_unet, dev_unet = pc.build_unet_pair(ctx, case)
-    # small CLIP tower so that the oracle finishes in seconds; the full ViT-B/32 has its own check
-    if rn_cfg is None:
-        res, patch, width, layers, heads, outd = vit_cfg
-        ref_clip = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
-        th.nn.Module.__init__(ref_clip)
-        ref_clip.visual = ocv.VisionTransformer(res, patch, width, layers, heads, outd)
-        ocv.synthetic_init_(ref_clip).eval()
-        dev_clip = nets.ClipImageTower(ctx, config=vit_cfg)
-    else:  # ModifiedResNet tower (RN50-style): (resolution, width, layers, out_dim, heads)
-        from oracle import clip_resnet as ocr
-        res, outd = rn_cfg[0], rn_cfg[3]
-        ref_clip = ocr.synthetic_init_(ocr.ClipResNetImageModel(config=rn_cfg)).eval()
-        dev_clip = nets.ClipResNetTower(ctx, config=rn_cfg)
-    for p in ref_clip.parameters():
-        p.requires_grad_(False)
-    dev_clip.load_clip_state_dict({k: v.to(DEV) for k, v in ref_clip.state_dict().items() if "num_batches_tracked" not in k})
-    # dual-CLIP (BASELINE config 5, build extension): a second, ViT tower with its own embedding width
-    ref_clip2 = dev_clip2 = None
-    if dual:
-        cfg2 = (32, 8, 64, 1, 1, 48)
-        ref_clip2 = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
-        th.nn.Module.__init__(ref_clip2)
-        ref_clip2.visual = ocv.VisionTransformer(*cfg2)
-        ocv.synthetic_init_(ref_clip2, seed=999).eval()
-        for p in ref_clip2.parameters():
+
+class Scenario:
+    """Everything both sides share: networks (oracle modules; the device loads their state dicts), tables, tape, targets."""
+
+    def __init__(self, case="mini", ddim=False, steps=3, B=1, cutn=4, vit_cfg=MINI_VIT, vit_name=None, P=1, hw=None, respacing="50",
+                 schedule="linear", use_magnitude=False, sat_scale=0.0, scales=None, weights=None, init_scale=0.0, rn_cfg=None,
+                 dual=False, reduce_clip=False, progressive_cutout=False, t_first=None, counter_quirk=False, head_scale=0.1,
+                 rescale_timesteps=False):
+        from oracle import clip_vit as ocv
+        from oracle import diffusion as od
+        from oracle import guidance as og
+        from oracle.unet import UNetModel, synthetic_init_
+        self.case, self.ddim, self.steps, self.B, self.cutn, self.P = case, ddim, steps, B, cutn, P
+        self.use_magnitude, self.sat_scale, self.init_scale = use_magnitude, sat_scale, init_scale
+        self.reduce_clip, self.progressive_cutout, self.dual, self.rn_cfg = reduce_clip, progressive_cutout, dual, rn_cfg
+        kw = self.kw = pc.UNET_CASES[case]
+        self.H, self.W = hw or (kw["image_size"], kw["image_size"])
+        self.scales = scales or default_scales(self.H, self.W)
+        self.ref_unet = synthetic_init_(UNetModel(**kw), seed=1234).eval()
+        with th.no_grad():  # small eps-hat / variance head, like a trained checkpoint mid-schedule (module docstring)
+            self.ref_unet.out[2].weight.mul_(head_scale)
+            self.ref_unet.out[2].bias.mul_(head_scale)
+        for p in self.ref_unet.parameters():
             p.requires_grad_(False)
-        dev_clip2 = nets.ClipImageTower(ctx, config=cfg2)
-        dev_clip2.load_clip_state_dict({k: v.to(DEV) for k, v in ref_clip2.state_dict().items()})
-
-    spec = ("ddim" + respacing) if ddim else respacing
-    rescale = False
-    o_diff = od.create_gaussian_diffusion(1000, schedule, spec, rescale)
-    d_tab = dd.create_gaussian_diffusion(1000, schedule, spec, rescale)
-    smp = sampler.GuidedSampler(ctx, d_tab)
-    N = o_diff.num_timesteps
-    tape = make_tape(B, H, W, steps, kw.get("num_classes"), cutn, res)
-    # reduce_clip / progressive_cutout (cgd.py:155-175): the closure counter starts at N-1 whatever skip_timesteps is; a skipped
-    # call consumes no tape entry and a guided one takes the first `cutn_k` boxes of its entry
-    gate = [dg.guidance_schedule(N, N - 1 - k, cutn, reduce_clip, progressive_cutout) for k in range(steps)]
-    tape["coords"] = [tape["coords"][k][:n_k] for k, (skipped, n_k) in enumerate(gate) if not skipped]
-    targets = th.randn(P, outd, generator=g(80))
-    targets2 = th.randn(P, 48, generator=g(81)) if dual else None
-    w = th.tensor(weights if weights is not None else [1.0, 0.5, -0.3][:P])
-    w = w / w.sum().abs()
-    cgs, tvs, rs = scales
-
-    # optional init image + LPIPS-VGG16 perceptual term (cgd.py:147-148,220-224); the init image is (1,3,H,W) and broadcasts
-    init_cpu, o_lp, d_lp = None, None, None
-    if init_scale:
-        from oracle import lpips_vgg as olp
-        init_cpu = th.tanh(th.randn(1, 3, H, W, generator=g(90)))
-        o_lp = olp.synthetic_init_(olp.LpipsVGG()).eval()
-        for p in o_lp.parameters():
+        self.vit_cfg, self.vit_name = vit_cfg, vit_name
+        if rn_cfg is not None:  # ModifiedResNet tower (RN50-style): (resolution, width, layers, out_dim, heads)
+            from oracle import clip_resnet as ocr
+            self.res, self.outd = rn_cfg[0], rn_cfg[3]
+            self.ref_clip = ocr.synthetic_init_(ocr.ClipResNetImageModel(config=rn_cfg)).eval()
+        elif vit_name is not None:  # a full CLIP tower (ViT-B/32 at the headline shape)
+            self.ref_clip = ocv.synthetic_init_(ocv.ClipImageModel(vit_name)).eval().float()
+            self.res, self.outd = ocv.VIT_CONFIGS[vit_name][0], ocv.VIT_CONFIGS[vit_name][5]
+        else:  # small CLIP tower so that the oracle finishes in seconds
+            self.res, self.outd = vit_cfg[0], vit_cfg[5]
+            self.ref_clip = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
+            th.nn.Module.__init__(self.ref_clip)
+            self.ref_clip.visual = ocv.VisionTransformer(*vit_cfg)
+            ocv.synthetic_init_(self.ref_clip).eval()
+        for p in self.ref_clip.parameters():
             p.requires_grad_(False)
-        d_lp = nets.LpipsVGG(ctx).load_state_dict({k: v.float().to(DEV) for k, v in o_lp.lpips_state_dict().items()})
+        self.ref_clip2, self.cfg2 = None, (32, 8, 64, 1, 1, 48)
+        if dual:  # dual-CLIP (BASELINE config 5, build extension): a second, ViT tower with its own embedding width
+            self.ref_clip2 = ocv.ClipImageModel.__new__(ocv.ClipImageModel)
+            th.nn.Module.__init__(self.ref_clip2)
+            self.ref_clip2.visual = ocv.VisionTransformer(*self.cfg2)
+            ocv.synthetic_init_(self.ref_clip2, seed=999).eval()
+            for p in self.ref_clip2.parameters():
+                p.requires_grad_(False)
+        self.spec = ("ddim" + respacing) if ddim else respacing
+        self.schedule, self.rescale = schedule, rescale_timesteps
+        self.o_diff = od.create_gaussian_diffusion(1000, schedule, self.spec, rescale_timesteps)
+        N = self.N = self.o_diff.num_timesteps
+        # first executed timestep: about a quarter into the schedule from the clean end (abar ~ 0.5 on the linear schedule)
+        self.t_first = t_first if t_first is not None else max(steps - 1, round(0.25 * (N - 1)))
+        assert steps <= self.t_first + 1
+        self.skip = N - 1 - self.t_first
+        # the reference's closure counter (cgd.py:149,265-267) starts at N-1 whatever skip_timesteps is (`counter_quirk`: the
+        # state of a user-requested skip); otherwise it holds t, the state of an unskipped run that has reached t_first
+        self.counter0 = N - 1 if counter_quirk else self.t_first
+        self.tape = make_tape(B, self.H, self.W, steps, kw.get("num_classes"), cutn, self.res)
+        self.x0_star = th.tanh(th.randn(1, 3, self.H, self.W, generator=g(91)))  # the init image of the q_sample prologue
+        # reduce_clip / progressive_cutout (cgd.py:155-175) look at the closure counter; a skipped call consumes no tape entry
+        # and a guided one takes the first `cutn_k` boxes of its entry
+        from cgd_amd import guidance as dg
+        self.gate = [dg.guidance_schedule(N, self.counter0 - k, cutn, reduce_clip, progressive_cutout) for k in range(steps)]
+        self.tape["coords"] = [self.tape["coords"][k][:n_k] for k, (skipped, n_k) in enumerate(self.gate) if not skipped]
+        self.targets = th.randn(P, self.outd, generator=g(80))
+        self.targets2 = th.randn(P, 48, generator=g(81)) if dual else None
+        w = th.tensor(weights if weights is not None else [1.0, 0.5, -0.3][:P])
+        self.w = w / w.sum().abs()
+        self.init_cpu, self.o_lp = None, None
+        if init_scale:  # LPIPS-VGG16 perceptual term against the init image (cgd.py:147-148,220-224); (1,3,H,W), broadcasts
+            from oracle import lpips_vgg as olp
+            self.init_cpu = self.x0_star
+            self.o_lp = olp.synthetic_init_(olp.LpipsVGG()).eval()
+            for p in self.o_lp.parameters():
+                p.requires_grad_(False)
+        self.og = og
 
-    # ---- oracle ----
-    mk = og.MakeCutouts(res, cutn)
-    o_models = [ref_clip, ref_clip2] if dual else ref_clip
-    o_targets = [targets, targets2] if dual else targets
-    o_cutters = [mk, og.MakeCutouts(32, cutn)] if dual else mk
-    o_cond, o_state = og.make_cond_fn(diffusion=o_diff, clip_model=o_models, make_cutouts=o_cutters, target_embeds=o_targets, weights=w,
-                                      num_cutouts=cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs, sat_scale=sat_scale,
-                                      use_magnitude=use_magnitude, coords_tape=tape["coords"], lpips_model=o_lp, init_tensor=init_cpu,
-                                      init_scale=init_scale, reduce_clip=reduce_clip, progressive_cutout=progressive_cutout)
-    mkw = {"y": th.zeros(B, dtype=th.long)} if kw.get("num_classes") else {}
-    loop = o_diff.ddim_sample_loop_progressive if ddim else o_diff.p_sample_loop_progressive
-    o_gen = loop(ref_unet, (B, 3, H, W), clip_denoised=False, cond_fn=o_cond, model_kwargs=dict(mkw), device="cpu",
-                 skip_timesteps=N - steps, randomize_class=bool(mkw), cond_fn_with_grad=True, tape=tape)
-    # NB skip_timesteps>0 engages the reference's `current_timestep` offset quirk: the closure
-    # counter still starts at N-1 while t starts at N-1-skip.
-    o_state["current_timestep"] = N - 1
-    o_out = []
-    for out in o_gen:
-        o_state["current_timestep"] -= 1
-        o_out.append((out["sample"].clone(), out["pred_xstart"].clone(), dict(o_state.get("log", {}))))
+    def tag(self, precision):
+        return (f"step[{self.case} p{precision} {'ddim' if self.ddim else 'p'} B{self.B} {self.H}x{self.W} t{self.t_first}"
+                f"{' mag' if self.use_magnitude else ''}{f' sat{self.sat_scale:g}' if self.sat_scale else ''}"
+                f"{f' init{self.init_scale:g}' if self.init_scale else ''}{' reduce' if self.reduce_clip else ''}"
+                f"{' progressive' if self.progressive_cutout else ''}{' rn' if self.rn_cfg else ''}{' dual' if self.dual else ''}]")
 
-    # ---- device ----
-    d_towers = [dev_clip, dev_clip2] if dual else dev_clip
-    d_targets = [targets.to(DEV), targets2.to(DEV)] if dual else targets.to(DEV)
-    guid = dg.ClipGuidance(ctx, dev_unet, d_towers, smp, d_targets, w, cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs,
-                           sat_scale=sat_scale, use_magnitude=use_magnitude, lpips=d_lp, reduce_clip=reduce_clip,
-                           progressive_cutout=progressive_cutout,
-                           init_tensor=None if init_cpu is None else init_cpu.to(DEV), init_scale=init_scale)
-    guid.coords_tape = tape["coords"]
-    smp.tape = tape
-    dmkw = {"y": th.zeros(B, dtype=th.long, device=DEV)} if kw.get("num_classes") else {}
-    dloop = smp.ddim_sample_loop_progressive if ddim else smp.p_sample_loop_progressive
-    d_gen = dloop(dev_unet, (B, 3, H, W), clip_denoised=False, cond_fn=guid, model_kwargs=dmkw, device=DEV, skip_timesteps=N - steps,
-                  randomize_class=bool(dmkw), cond_fn_with_grad=True)
-    guid.current_timestep = N - 1
+    # ---- oracle ----------------------------------------------------------------------------------------------------------------
+    def run_oracle(self):
+        """[(sample, pred_xstart, log, legs or None)] per step."""
+        og, B, H, W, N = self.og, self.B, self.H, self.W, self.N
+        mk = og.MakeCutouts(self.res, self.cutn)
+        o_models = [self.ref_clip, self.ref_clip2] if self.dual else self.ref_clip
+        o_targets = [self.targets, self.targets2] if self.dual else self.targets
+        o_cutters = [mk, og.MakeCutouts(32, self.cutn)] if self.dual else mk
+        cgs, tvs, rs = self.scales
+        o_cond, st = og.make_cond_fn(diffusion=self.o_diff, clip_model=o_models, make_cutouts=o_cutters, target_embeds=o_targets,
+                                     weights=self.w, num_cutouts=self.cutn, clip_guidance_scale=cgs, tv_scale=tvs, range_scale=rs,
+                                     sat_scale=self.sat_scale, use_magnitude=self.use_magnitude, coords_tape=self.tape["coords"],
+                                     lpips_model=self.o_lp, init_tensor=self.init_cpu, init_scale=self.init_scale,
+                                     reduce_clip=self.reduce_clip, progressive_cutout=self.progressive_cutout)
+        st["diag"] = True
+        mkw = {"y": th.zeros(B, dtype=th.long)} if self.kw.get("num_classes") else {}
+        loop = self.o_diff.ddim_sample_loop_progressive if self.ddim else self.o_diff.p_sample_loop_progressive
+        gen = loop(self.ref_unet, (B, 3, H, W), clip_denoised=False, cond_fn=o_cond, model_kwargs=dict(mkw), device="cpu",
+                   skip_timesteps=self.skip, init_image=self.x0_star.expand(B, -1, -1, -1), randomize_class=bool(mkw),
+                   cond_fn_with_grad=True, tape=self.tape)
+        st["current_timestep"] = self.counter0
+        out = []
+        for k, o in enumerate(itertools.islice(gen, self.steps)):
+            legs = None
+            if not self.gate[k][0]:
+                t = self.t_first - k
+                cur = st["current_timestep"]
+                fac = float(self.o_diff.sqrt_one_minus_alphas_cumprod[cur])
+                a = float(self.o_diff.sqrt_recip_alphas_cumprod[t])
+                b = float(self.o_diff.sqrt_recipm1_alphas_cumprod[t])
+                lg = st["legs"]
+                g_direct = (1 - fac) * lg["g_in"] + a * lg["g_x0"]
+                legs = {"g": lg["g_raw"], "g_clip_in": lg["g_clip_in"], "g_direct": g_direct, "seed_eps": -b * lg["g_x0"],
+                        "g_unet": -lg["g_raw"] - g_direct}  # g = -(g_direct + UNet^T seed): the UNet-dgrad leg on its own
+            st["current_timestep"] -= 1
+            out.append((o["sample"].clone(), o["pred_xstart"].clone(), dict(st.get("log", {})), legs))
+        return out
+
+    # ---- device ----------------------------------------------------------------------------------------------------------------
+    def run_device(self, precision):
+        """Generator of (out dict, guidance object) per step; the caller synchronises and reads the buffers of the step."""
+        from cgd_amd import diffusion as dd
+        from cgd_amd import guidance as dg
+        from cgd_amd import lib, nets, sampler
+        ctx = lib.Context(0, precision)
+        B, H, W = self.B, self.H, self.W
+        dev_unet = nets.UNet(ctx, **self.kw)
+        dev_unet.load_state_dict({k: v.to(DEV) for k, v in self.ref_unet.state_dict().items()})
+        if self.rn_cfg is not None:
+            dev_clip = nets.ClipResNetTower(ctx, config=self.rn_cfg)
+        elif self.vit_name is not None:
+            dev_clip = nets.ClipImageTower(ctx, self.vit_name)
+        else:
+            dev_clip = nets.ClipImageTower(ctx, config=self.vit_cfg)
+        dev_clip.load_clip_state_dict({k: v.to(DEV) for k, v in self.ref_clip.state_dict().items() if "num_batches_tracked" not in k})
+        dev_clip2 = None
+        if self.dual:
+            dev_clip2 = nets.ClipImageTower(ctx, config=self.cfg2)
+            dev_clip2.load_clip_state_dict({k: v.to(DEV) for k, v in self.ref_clip2.state_dict().items()})
+        d_lp = None
+        if self.init_scale:
+            d_lp = nets.LpipsVGG(ctx).load_state_dict({k: v.float().to(DEV) for k, v in self.o_lp.lpips_state_dict().items()})
+        d_tab = dd.create_gaussian_diffusion(1000, self.schedule, self.spec, self.rescale)
+        smp = sampler.GuidedSampler(ctx, d_tab)
+        cgs, tvs, rs = self.scales
+        d_towers = [dev_clip, dev_clip2] if self.dual else dev_clip
+        d_targets = [self.targets.to(DEV), self.targets2.to(DEV)] if self.dual else self.targets.to(DEV)
+        guid = dg.ClipGuidance(ctx, dev_unet, d_towers, smp, d_targets, self.w, self.cutn, clip_guidance_scale=cgs, tv_scale=tvs,
+                               range_scale=rs, sat_scale=self.sat_scale, use_magnitude=self.use_magnitude, lpips=d_lp,
+                               reduce_clip=self.reduce_clip, progressive_cutout=self.progressive_cutout,
+                               init_tensor=None if self.init_cpu is None else self.init_cpu.to(DEV), init_scale=self.init_scale)
+        guid.coords_tape = self.tape["coords"]
+        smp.tape = self.tape
+        dmkw = {"y": th.zeros(B, dtype=th.long, device=DEV)} if self.kw.get("num_classes") else {}
+        dloop = smp.ddim_sample_loop_progressive if self.ddim else smp.p_sample_loop_progressive
+        d_gen = dloop(dev_unet, (B, 3, H, W), clip_denoised=False, cond_fn=guid, model_kwargs=dmkw, device=DEV, skip_timesteps=self.skip,
+                      init_image=self.x0_star.expand(B, -1, -1, -1).to(DEV), randomize_class=bool(dmkw), cond_fn_with_grad=True)
+        guid.current_timestep = self.counter0
+        for out in itertools.islice(d_gen, self.steps):
+            th.cuda.synchronize()
+            legs = None
+            if guid.last_ran:
+                bufs = guid._buf
+                legs = {"g": bufs["g"].clone(), "g_clip_in": bufs["gclip"].clone(), "g_direct": bufs["gdir"].clone(),
+                        "seed_eps": bufs["seed6"][:, :3].clone(), "seed_var": bufs["seed6"][:, 3:].clone(),
+                        "g_unet": bufs["gunet"].clone()}
+            yield out, guid, legs
+            guid.current_timestep -= 1
+
+
+def compare(sc, precision, o_out, d_iter):
     recs = []
-    tag = (f"step[{case} p{precision} {'ddim' if ddim else 'p'} B{B} {H}x{W} mag{int(use_magnitude)} sat{sat_scale} init{init_scale}"
-           f"{' reduce' if reduce_clip else ''}{' progressive' if progressive_cutout else ''}]")
-    for k, out in enumerate(d_gen):
-        guid.current_timestep -= 1
-        th.cuda.synchronize()
-        o_s, o_x0, o_log = o_out[k]
+    tag = sc.tag(precision)
+    for k, (out, guid, d_legs) in enumerate(d_iter):
+        o_s, o_x0, o_log, o_legs = o_out[k]
         recs.append(rec(f"{tag} step{k} sample", out["sample"], o_s))
         recs.append(rec(f"{tag} step{k} pred_xstart", out["pred_xstart"], o_x0))
-        if gate[k][0]:  # guidance skipped on this step (the reference returns zeros_like(x)): no new scalars
+        if sc.gate[k][0]:  # guidance skipped on this step (the reference returns zeros_like(x)): no new scalars, no gradient
+            assert d_legs is None, "the device ran the guidance on a step the reference gates off"
             continue
+        for name in ("g", "g_clip_in", "g_direct", "seed_eps", "g_unet"):
+            recs.append(rec(f"{tag} step{k} {name}", d_legs[name], o_legs[name], allow_small=True))
+            # the same leg at unit peak (tighter than the literal criterion whenever the leg's peak is below 1: atol then is
+            # 1e-4 of the PEAK, so a small leg cannot pass on atol alone)
+            sd = pc.unit_seed(o_legs[name])
+            recs.append(rec(f"{tag} step{k} {name} (unit peak)", d_legs[name] * sd, o_legs[name] * sd))
+        recs.append(rec(f"{tag} step{k} seed_var == 0", d_legs["seed_var"], th.zeros_like(d_legs["seed_var"]).cpu(), allow_small=True))
         lg = guid.log()
-        for key in ("CLIP Loss", "TV Loss", "Range Loss", "Total Loss") + (("Init VGG Loss",) if init_scale else ()):
-            recs.append(rec(f"{tag} step{k} {key}", th.tensor([lg[key]]), th.tensor([o_log[key]])))
+        keys = ("CLIP Loss", "TV Loss", "Range Loss", "Total Loss") + (("Init VGG Loss",) if sc.init_scale else ()) \
+            + (("Saturation Loss",) if sc.sat_scale else ()) + (("Magnitude",) if sc.use_magnitude else ())
+        for key in keys:
+            recs.append(rec(f"{tag} step{k} {key}", th.tensor([lg[key]]), th.tensor([o_log[key]]), allow_small=True))
     return recs
+
+
+def check_step(case="mini", precision=1, **kw):
+    sc = Scenario(case, **kw)
+    return compare(sc, precision, sc.run_oracle(), sc.run_device(precision))
+
+
+def check_headline_step(precision=1, steps=1):
+    """One guided step at BASELINE configs[1]: 256x256 class-conditional UNet (554 M), respace 250, cutn 16, CLIP ViT-B/32,
+    clip_guidance_scale 1000 / tv 150 / range 50, randomize_class, p_sample — g, x0-hat and x_{t-1} at the literal tolerance.
+    (The CPU oracle takes ~10 s per step at this shape plus ~15 s to build the two networks.)"""
+    return check_step("cfg256", precision, vit_name="ViT-B/32", cutn=16, respacing="250", steps=steps, scales=(1000.0, 150.0, 50.0),
+                      head_scale=1.0)  # mid-schedule x0-hat is O(1) at this shape even with the full-scale synthetic head

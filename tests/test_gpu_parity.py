@@ -1,5 +1,7 @@
 """GPU parity tests (pytest -m gpu): every HIP kernel / network through the C ABI against the CPU oracle or a plain
-PyTorch fp64/fp32 reference of the same op, at north_star's tolerance rtol 1e-3 / atol 1e-4.
+PyTorch fp64/fp32 reference of the same op, at north_star's tolerance applied literally: |a-b| <= 1e-4 + 1e-3 |ref| per
+element (`parity_checks.rec`; inputs / backward seeds scaled so that outputs are O(1)).  The only named exception is the
+`relu-flips` criterion for the input gradient of ReLU towers (`parity_checks.rec_flips`).
 Precision modes: 0 = fp32 MFMA (exact products), 1 = bf16x3 split (the default the bench runs)."""
 import pytest
 
@@ -8,9 +10,11 @@ from tests import parity_checks as pc
 pytestmark = pytest.mark.gpu
 
 
-def _assert_all(recs):
+def _assert_all(recs, allowed=("strict",)):
     bad = [r for r in recs if not r["ok"]]
-    assert not bad, "; ".join(f"{r['name']}: abs {r['err_abs']:.3e} rel {r['err_rel']:.3e}" for r in bad)
+    assert not bad, "; ".join(f"{r['name']} [{r['criterion']}]: abs {r['err_abs']:.3e} rel {r['err_rel']:.3e} peak {r['ref_max']:.3e}"
+                              + (" VACUOUS" if r.get("vacuous") else "") for r in bad)
+    assert all(r["criterion"] in allowed for r in recs), [r["name"] for r in recs if r["criterion"] not in allowed]
 
 
 def test_native_library_is_loaded():
@@ -27,6 +31,7 @@ def test_gemm(precision):
 def test_gemm_bf16_single_product_is_bf16_accurate():
     recs = pc.check_gemm(2)  # reduced-precision speed mode: not parity mode, only sanity-bounded
     assert all(r["err_rel"] < 1e-2 for r in recs)
+    assert not all(r["ok_strict"] for r in recs), "a single bf16 product cannot meet the fp32 tolerance: the strict criterion is not biting"
 
 
 @pytest.mark.parametrize("precision", [0, 1])
@@ -65,6 +70,16 @@ def test_unet_256_checkpoint_shape():
     _assert_all(pc.check_unet("cfg256", 1))
 
 
+def test_unet_128_checkpoint_shape():
+    # num_heads=4: head dims 128 / 192 / 256 on the batched-GEMM attention path; 768-channel level (channel_mult 3)
+    _assert_all(pc.check_unet("cfg128", 1))
+
+
+def test_unet_512_checkpoint_shape():
+    # channel_mult 0.5: 128-channel level at 512x512; fractional timestep as `rescale_timesteps` produces (t * 1000 / T)
+    _assert_all(pc.check_unet("cfg512", 1, timestep=417.5))
+
+
 @pytest.mark.parametrize("precision", [0, 1])
 def test_clip_vit_b32(precision):
     _assert_all(pc.check_vit("ViT-B/32", precision))
@@ -85,6 +100,7 @@ def test_clip_vit_other_towers(name):
                                                    ("RN50", 1, None), ("x4-tiny", 0, (96, 80, (1, 1, 1, 1), 64, 40)),
                                                    ("x16-tiny", 1, (64, 96, (1, 1, 1, 1), 64, 48))])
 def test_clip_modified_resnet(name, precision, config):
-    # forward at rtol 1e-3 / atol 1e-4; the gradient of a ReLU tower by relative L2 (parity_checks.rec_l2 explains why);
+    # forward at the literal tolerance; the input gradient of a ReLU tower by the named `relu-flips` criterion
+    # (parity_checks.rec_flips explains why); the tower runs on exact-fp32 MFMA products in either context precision;
     # the x4 / x16 widths (80 / 96, stems 40 / 48) exercise the zero-padded channel layout
-    _assert_all(pc.check_resnet(name, precision, config=config))
+    _assert_all(pc.check_resnet(name, precision, config=config), allowed=("strict", "relu-flips"))

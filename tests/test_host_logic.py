@@ -205,8 +205,9 @@ def test_download_returns_target_full_path(tmp_path, monkeypatch):
     calls = []
 
     class Resp:
-        def __init__(self, fail):
+        def __init__(self, fail, length=None):
             self.fail = fail
+            self.headers = {} if length is None else {"Content-Length": str(length)}
 
         def __enter__(self):
             return self
@@ -224,9 +225,11 @@ def test_download_returns_target_full_path(tmp_path, monkeypatch):
 
     def fake_get(url, **kw):
         calls.append(url)
-        return Resp(fail="bad" in url)
+        # "short": the server announces more bytes than the connection delivers before it closes without an error
+        return Resp(fail="bad" in url, length=4096 if "short" in url else (14 if "sized" in url else None))
 
     monkeypatch.setattr(requests, "get", fake_get)
+    monkeypatch.setenv("CGD_DOWNLOAD_BACKOFF", "0")
     result = script_util.download("https://example.org/photon.png", "photon.png", root=str(tmp_path))
     expected = tmp_path / "photon.png"
     assert result == str(expected) and expected.exists() and expected.read_bytes() == b"\\x89PNGpayload"
@@ -234,6 +237,11 @@ def test_download_returns_target_full_path(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="Download failed after 2 attempts"):
         script_util.download("https://example.org/bad.png", "bad.png", root=str(tmp_path), max_retries=2)
     assert calls.count("https://example.org/bad.png") == 2 and not (tmp_path / "bad.png").exists() and not (tmp_path / "bad.tmp").exists()
+    # truncated body (reference script_util.py:246-250): never renamed into the cache, retried, then reported
+    with pytest.raises(RuntimeError, match="Download failed after 2 attempts.*incomplete"):
+        script_util.download("https://example.org/short.pt", "short.pt", root=str(tmp_path), max_retries=2)
+    assert calls.count("https://example.org/short.pt") == 2 and not (tmp_path / "short.pt").exists() and not (tmp_path / "short.tmp").exists()
+    assert script_util.download("https://example.org/sized.pt", "sized.pt", root=str(tmp_path)) == str(tmp_path / "sized.pt")
     # checkpoint lookup: an existing file is returned as is, a missing one is requested from the table's url
     monkeypatch.delenv("CGD_SYNTHETIC_WEIGHTS", raising=False)
     (tmp_path / "256x256_diffusion.pt").write_bytes(b"x")
@@ -316,7 +324,7 @@ def test_generator_body_with_fake_device_objects(tmp_path, monkeypatch, capsys):
     class FakeGuidance:
         def __init__(self, ctx, unet, towers, diffusion, target_embeds, weights, num_cutouts, **kw):
             events.append(("guidance", [tuple(e.shape) for e in target_embeds], weights.tolist(), num_cutouts, kw["reduce_clip"]))
-            self.scalars, self.current_timestep, self.n = th.zeros(8), None, 0
+            self.scalars, self.current_timestep, self.n, self.last_ran = th.zeros(8), None, 0, True
 
         def snapshot(self):
             self.n += 1
@@ -407,7 +415,7 @@ def test_guidance_call_sequence_with_a_recording_library(monkeypatch):
                 return 32 if name == "cgd_guidance_part_blocks" else 0
             return fn
 
-    ctx = types.SimpleNamespace(lib=FakeLib(), h=1, check=lambda rc: None)
+    ctx = types.SimpleNamespace(lib=FakeLib(), h=1, check=lambda rc: None, stream=lambda: 0)
 
     class Tower:
         def __init__(self, name, res, patch, dim):
@@ -476,7 +484,7 @@ def test_native_step_orders_noise_draw_before_guidance(monkeypatch):
                 return 0
             return fn
 
-    ctx = types.SimpleNamespace(lib=FakeLib(), h=1, check=lambda rc: None, device=0)
+    ctx = types.SimpleNamespace(lib=FakeLib(), h=1, check=lambda rc: None, device=0, stream=lambda: 0)
     smp = sampler.GuidedSampler(ctx, dd.create_gaussian_diffusion(1000, "linear", "10", False))
     guid = object.__new__(dg.ClipGuidance)
     guid.use_magnitude, guid.scalars, guid.current_timestep = True, th.zeros(8), 9
