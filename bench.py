@@ -1,72 +1,71 @@
 #!/usr/bin/env python
 """Headline benchmark: diffusion steps/sec (UNet fwd + CLIP fwd + losses + backward to x_t + sampler update).
 
-Workload (BASELINE.json configs[1]): 256x256 class-conditional ADM UNet (554 M params), respace 250, cutn 16,
-batch 1, CLIP ViT-B/32, clip_guidance_scale 1000 / tv 150 / range 50, randomize_class, synthetic seeded weights
-(no checkpoints / network on the bench box).  One "step" = one guided p_sample step of one sample.
-N GPUs run N independent samples (1 per GPU, no per-step collective; one RCCL broadcast of the packed weights at init).
+Default workload = BASELINE.json configs[1] (`--config 2`): 256x256 class-conditional ADM UNet (554 M params), respace 250,
+cutn 16, batch 1 per GPU, CLIP ViT-B/32, clip_guidance_scale 1000 / tv 150 / range 50, randomize_class, p_sample; synthetic seeded
+weights (no checkpoints / network on the bench box).  One "step" = one guided sampling step of one sample.  `--config 3|4|5`
+time the other BASELINE configurations per GPU (1 sample per GPU is the sharding unit).
 
-Prints ONE JSON line (see the driver contract) with two extra objects:
-  roofline     : dominant kernel = the halo-staged MFMA 3x3 conv (`hconv2_kernel`, ~41% of the step): algorithmic FLOP of its
-                 launches in the timed region / their summed HIP-event duration (events recorded by the library on the launch
-                 stream), against the dense bf16 MFMA peak (2.5 PF/s).  bf16x3 issues 3 MFMA products per algorithmic product
-                 (`mfma_issue_frac` = 3 x frac).  `traffic` = HBM bytes/launch from the committed PMC passes (profiles/).
-  cpu_baseline : the CPU oracle (plain PyTorch fp32 port of the reference path) timed on the host cores (rank 0, N=1).
+What is timed: the PRODUCT sampling loop — `GuidedSampler.p_sample_loop_progressive` (or the DDIM loop) driven exactly like the
+drop-in generator drives it (`cgd/cgd.py`): class draw, UNet forward, cutout draw + upload, CLIP, losses, CLIP / UNet dgrad,
+noise draw, update — with every step consuming the previous step's `out["sample"]` (a real trajectory, not per-step marginals).
+Synthetic weights do not predict epsilon, so a chain started at t = T-1 diverges (x0-hat = 157 (x - eps-hat)); the chain
+therefore starts MID-schedule from x_t = q_sample(x0*, t) through the reference's own init-image prologue (`skip_timesteps` +
+`init_image`) and walks down to t = 0; K > chain length starts another chain (one tiny elementwise prologue per chain).  Per-step
+work does not depend on t.  Config 4 is the reference's own skip-500 init-image run and needs no such device.
+
+N GPUs: `python bench.py --gpus N` spawns N ranks itself (one process per GPU, RCCL), or runs as one rank under
+`torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Independent samples, one per GPU; ONE RCCL
+broadcast of the packed weights at start-up, no per-step collective.  Timing: barrier + synchronize on both sides of exactly K
+steps, max over ranks.
+
+Prints ONE JSON line (driver contract) with three extra objects:
+  roofline     : dominant kernel = the halo-staged MFMA 3x3 conv (`hconv2_kernel`): algorithmic FLOP of its launches / their summed
+                 HIP-event duration (events recorded by the library on the launch stream, in a separate UNTIMED pass after the
+                 timed region), against the dense bf16 MFMA peak (2.5 PF/s).  bf16x3 issues 3 MFMA products per algorithmic
+                 product (`mfma_issue_frac` = 3 x frac).  `traffic` = HBM bytes/launch from the committed PMC passes (profiles/).
+  hbm          : GroupNorm(+FiLM+SiLU) forward / backward ops, the HBM-bound kernels north_star names: algorithmic bytes (fwd: read
+                 x + write y; bwd: read x, dz [, residual] + write dx) / summed HIP-event duration, against 8 TB/s.
+  cpu_baseline : the CPU oracle (plain PyTorch fp32 port of the reference path) timed on the host cores (rank 0, N = 1 only).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch as th  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-UNET_256 = dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64)
-FLOP_PER_STEP = 4.775e12  # UNet 2*(1119.8+1125.9) GMAC + CLIP 16*2*(4.409+4.455) GMAC
-# mean algorithmic HBM bytes of a halo-conv launch in this workload: 4 B * M * (Cin + Cout) activations + 4 B * 9 * Cin * Cout packed
-# weights, averaged over the 136 launches of a step (tests/plan_dump.py; checked by tests/test_flop_accounting.py)
+U256 = dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64)
+U512 = dict(image_size=512, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64)
+# mean algorithmic HBM bytes of a halo-conv launch in config 2: 4 B * M * (Cin + Cout) activations + 4 B * 9 * Cin * Cout packed
+# weights, averaged over the 136 launches of a step (bench/plan_dump.py; checked by tests/test_flop_accounting.py)
 HCONV_ALGO_BYTES_PER_LAUNCH = 55.27e6
+METRIC = "diffusion steps/sec (UNet+CLIP+grad) at 256x256 cutn=16"
+
+# BASELINE.json configs[1..4]; tflop = algorithmic TFLOP per sample-step (SURVEY.md 8d / BASELINE.md section 2).
+# start = respaced index of the first executed timestep (see the module docstring); quirk = the reference's closure counter
+# starts at N-1 although t starts lower (a user-requested skip_timesteps, cgd.py:149,265-267)
+CONFIGS = {
+    2: dict(unet=U256, hw=(256, 256), spec="250", ddim=False, cutn=16, towers=["ViT-B/32"], P=1, lpips=False, tflop=4.775, start=125,
+            quirk=False, what="BASELINE configs[1]: 256x256 class-cond UNet (554M), respace 250, cutn 16, batch 1/GPU, CLIP ViT-B/32, "
+                              "cgs 1000 tv 150 range 50, randomize_class, p_sample"),
+    3: dict(unet=U256, hw=(256, 256), spec="ddim250", ddim=True, cutn=32, towers=["ViT-B/16"], P=1, lpips=False, tflop=6.785, start=125,
+            quirk=False, what="BASELINE configs[2]: 256x256, ddim250, cutn 32, ViT-B/16, one of the 4 samples/prompts per GPU"),
+    4: dict(unet=U512, hw=(512, 512), spec="1000", ddim=False, cutn=64, towers=["ViT-B/32"], P=1, lpips=True, tflop=9.6, start=499,
+            quirk=True, what="BASELINE configs[3]: 512x512, respace 1000, skip 500, cutn 64, ViT-B/32, init image + LPIPS-VGG16 "
+                             "init_scale 1000, 1 sample per GPU"),
+    5: dict(unet=U256, hw=(256, 288), spec="500", ddim=False, cutn=16, towers=["RN50", "ViT-L/14"], P=3, lpips=False, tflop=10.7,
+            start=250, quirk=False, what="BASELINE configs[4]: 256x288, respace 500, 3 weighted prompts (one negative), RN50 + "
+                                         "ViT-L/14 dual-CLIP, cutn 16, 1 sample per GPU"),
+}
 
 
-def build_device(ctx, rank, world, precision, clip_name="ViT-B/32"):
-    from cgd_amd import diffusion as dd
-    from cgd_amd import guidance as dg
-    from cgd_amd import nets, sampler, shard, synthetic
-    dev = f"cuda:{ctx.device}"
-    unet = nets.UNet(ctx, **UNET_256)
-    clip = nets.ClipImageTower(ctx, clip_name)
-    for net, seed in ((unet, 1234), (clip, 4321)):
-        specs = net.param_specs()
-        names = [n for n, _ in specs]
-        # the single collective of the whole job: rank 0 materialises the weights, one RCCL broadcast over xGMI
-        flat = shard.broadcast_flat(lambda: synthetic.flat_pack(synthetic.synthetic_state_dict(net, seed=seed, device=dev), names),
-                                    sum(n for _, n in specs), dev)
-        net.load_state_dict(synthetic.flat_unpack(flat, specs))
-        del flat
-    tables = dd.create_gaussian_diffusion(1000, "linear", "250", False)
-    smp = sampler.GuidedSampler(ctx, tables)
-    gt = th.Generator().manual_seed(99)
-    targets = th.randn(1, clip.out_dim, generator=gt).to(dev)
-    guid = dg.ClipGuidance(ctx, unet, clip, smp, targets, [1.0], 16, clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0)
-    return unet, clip, smp, guid
-
-
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (tests/run_profile.sh ->
-    profiles/pmc_traffic.json: FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE); None when not collected."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f)["kernels"][kernel]
-        return rec["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
-
-
+# ---------------------------------------------------------------------------------------------------------------------------------
 def usable_cores(cap=64):
     """Cores this process may really use: affinity mask and cgroup quota, not os.cpu_count() (a container that sees 256
     logical CPUs but owns 8 would oversubscribe the OpenMP pool by 32x)."""
@@ -80,9 +79,8 @@ def usable_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline_subprocess(timeout_s=300):
+def cpu_baseline_subprocess(timeout_s=420):
     """Runs cpu_baseline() in a child with a hard time limit so that a slow host can never stall the GPU number."""
-    import subprocess
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True,
                              timeout=timeout_s)
@@ -91,61 +89,166 @@ def cpu_baseline_subprocess(timeout_s=300):
                 return json.loads(line)
         return {"error": "no result", "stderr": out.stderr[-300:]}
     except subprocess.TimeoutExpired:
-        return {"error": f"CPU oracle did not finish 1+2 steps within {timeout_s} s on {usable_cores()} cores", "kind": "port",
+        return {"error": f"CPU oracle did not finish 1+3 steps within {timeout_s} s on {usable_cores()} cores", "kind": "port",
                 "cores": usable_cores()}
 
 
-def cpu_baseline(steps=2, warmup=1):
-    """CPU oracle = plain-PyTorch fp32 restatement of the reference's --device cpu path, same workload."""
+def cpu_baseline(steps=3, warmup=1):
+    """CPU oracle = plain-PyTorch fp32 restatement of the reference's --device cpu path, config 2, the same chained mid-schedule
+    trajectory the GPU leg runs (>= 3 timed steps after 1 warm-up, all usable host cores)."""
+    import itertools
+
+    import torch as th
     from oracle import clip_vit as ocv
     from oracle import diffusion as od
     from oracle import guidance as og
     from oracle import unet as ou
     cores = usable_cores()
     th.set_num_threads(cores)
-    unet = ou.synthetic_init_(ou.UNetModel(**UNET_256)).eval()
+    unet = ou.synthetic_init_(ou.UNetModel(**U256)).eval()
+    with th.no_grad():
+        unet.out[2].weight.mul_(0.1)
+        unet.out[2].bias.mul_(0.1)
     clip = ocv.synthetic_init_(ocv.ClipImageModel("ViT-B/32")).eval().float()
     for p in list(unet.parameters()) + list(clip.parameters()):
         p.requires_grad_(False)
     diff = od.create_gaussian_diffusion(1000, "linear", "250", False)
     targets = th.randn(1, 512, generator=th.Generator().manual_seed(99))
-    mk = og.MakeCutouts(224, 16)
-    cond, state = og.make_cond_fn(diffusion=diff, clip_model=clip, make_cutouts=mk, target_embeds=targets, weights=th.tensor([1.0]),
-                                  num_cutouts=16)
+    cond, state = og.make_cond_fn(diffusion=diff, clip_model=clip, make_cutouts=og.MakeCutouts(224, 16), target_embeds=targets,
+                                  weights=th.tensor([1.0]), num_cutouts=16)
     th.manual_seed(0)
-    N = diff.num_timesteps
+    N, start = diff.num_timesteps, CONFIGS[2]["start"]
     x0_star = th.tanh(th.randn(1, 3, 256, 256))
-    state["current_timestep"] = N - 1
+    gen = diff.p_sample_loop_progressive(unet, (1, 3, 256, 256), clip_denoised=False, cond_fn=cond, model_kwargs={"y": th.zeros(1, dtype=th.long)},
+                                         device="cpu", skip_timesteps=N - 1 - start, init_image=x0_star, randomize_class=True,
+                                         cond_fn_with_grad=True)
+    state["current_timestep"] = start
     t0 = None
-    for k in range(warmup + steps):
-        i = N - 1 - k
-        x = float(diff.sqrt_alphas_cumprod[i]) * x0_star + float(diff.sqrt_one_minus_alphas_cumprod[i]) * th.randn(1, 3, 256, 256)
-        if k == warmup:
-            t0 = time.perf_counter()
-        with th.no_grad():
-            diff.p_sample_with_grad(unet, x, th.tensor([i]), clip_denoised=False, cond_fn=cond, model_kwargs={"y": th.randint(0, 1000, (1,))})
+    for k, _ in enumerate(itertools.islice(gen, warmup + steps)):
         state["current_timestep"] -= 1
+        if k == warmup - 1:
+            t0 = time.perf_counter()
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "diffusion steps/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} full guided steps of the same 256x256/cutn16/ViT-B/32 workload after {warmup} warm-up, torch fp32, {cores} threads"}
+            "sample": f"{steps} chained guided steps of the same 256x256/cutn16/ViT-B/32 workload after {warmup} warm-up, torch fp32, "
+                      f"{cores} threads"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: one process per GPU (RANK = LOCAL_RANK = 0..N-1, rendezvous on 127.0.0.1).
+    Rank 0's stdout (the JSON line) is this process's stdout; a failing rank fails the run."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit(f"bench.py: ranks exited with {rcs}")
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (bench/run_profile.sh ->
+    profiles/pmc_traffic.json: FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE); None when not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def build_device(ctx, cfg, dev):
+    import torch as th
+    from cgd_amd import diffusion as dd
+    from cgd_amd import guidance as dg
+    from cgd_amd import nets, sampler, shard, synthetic
+
+    def load(net, make_sd):
+        # the single collective of the whole job: rank 0 materialises the weights, ONE RCCL broadcast over xGMI per network
+        return shard.load_broadcast(net, make_sd, dev)
+
+    unet = nets.UNet(ctx, **cfg["unet"])
+    load(unet, lambda: synthetic.synthetic_state_dict(unet, seed=1234, device=dev))
+    towers = []
+    for name in cfg["towers"]:
+        if name in nets.VIT_CONFIGS:
+            t = nets.ClipImageTower(ctx, name)
+            load(t, lambda t=t: synthetic.synthetic_state_dict(t, seed=4321, device=dev))
+        else:
+            t = nets.ClipResNetTower(ctx, name)
+            load(t, lambda t=t: synthetic.resnet_state_dict(t, seed=2468, device=dev))
+        towers.append(t)
+    tables = dd.create_gaussian_diffusion(1000, "linear", cfg["spec"], cfg["unet"]["image_size"] == 512)  # 512: rescale_timesteps
+    smp = sampler.GuidedSampler(ctx, tables)
+    g = th.Generator().manual_seed(99)
+    targets = [th.randn(cfg["P"], t.out_dim, generator=g).to(dev) for t in towers]
+    w = th.tensor([1.0, 0.5, -0.3][:cfg["P"]])
+    w = w / w.sum().abs()
+    H, W = cfg["hw"]
+    x0_star = th.tanh(th.randn(1, 3, H, W, device=dev))
+    lp = None
+    if cfg["lpips"]:
+        lp = nets.LpipsVGG(ctx).load_state_dict(synthetic.lpips_state_dict(device=dev))
+    guid = dg.ClipGuidance(ctx, unet, towers, smp, targets, w, cfg["cutn"], clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0,
+                           lpips=lp, init_tensor=x0_star if lp is not None else None, init_scale=1000.0 if lp is not None else 0.0)
+    return unet, towers, smp, guid, x0_star
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = headline)")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the untimed HIP-event pass (roofline / hbm objects)")
+    ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+
+    import torch as th
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("CGD_BENCH_DRYRUN"):
+        # test knob (tests/test_distributed_gloo.py, no GPU): the launcher / rendezvous / broadcast / max-over-ranks plumbing of
+        # the N > 1 path over gloo with NO device work; prints the contract's JSON line with value null
+        dist.init_process_group("gloo")
+        from cgd_amd import shard
+        flat = shard.broadcast_flat(lambda: th.arange(1000, dtype=th.float32), 1000, "cpu")
+        dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        dist.barrier()
+        tm = th.tensor([time.perf_counter() - t0], dtype=th.float64)
+        got = [th.zeros_like(tm) for _ in range(world)]
+        dist.all_gather(got, tm)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "diffusion steps/sec", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "data": "dry-run (no GPU work)", "config": {
+                                  "world_size_checked": dist.get_world_size(), "ranks_reporting": len(got),
+                                  "weights_checksum": float(flat.sum().item()), "max_over_ranks_s": tm.item()}}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # CGD_BENCH_DEVICE / CGD_BENCH_BACKEND: test knobs only (exercise the N > 1 flow on a 1-GPU box: every rank on one device, gloo)
     local = int(os.environ.get("CGD_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     th.cuda.set_device(local)
@@ -156,83 +259,97 @@ def main():
             dist.init_process_group("nccl", device_id=th.device(dev))  # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(os.environ["CGD_BENCH_BACKEND"])
+        assert dist.get_world_size() == args.gpus
 
     import cgd_amd  # noqa: F401
     from cgd_amd import lib
+    cfg = CONFIGS[args.config]
     ctx = lib.Context(local, args.precision)
-    unet, clip, smp, guid = build_device(ctx, rank, world, args.precision)
-
-    total = args.warmup + args.steps
-    assert total <= smp.num_timesteps
-    N = smp.num_timesteps
+    unet, towers, smp, guid, x0_star = build_device(ctx, cfg, dev)
+    N, start = smp.num_timesteps, cfg["start"]
+    H, W = cfg["hw"]
     th.manual_seed(1000 + rank)
-    # Synthetic inputs.  Random weights do not predict epsilon, so chaining samples through 20+ steps diverges
-    # (pred_xstart = sqrt(1/abar)*x feeds back through the tv/range terms).  Every step therefore gets the marginal a real
-    # trajectory has at its timestep, x_t = sqrt(abar_t) x0* + sqrt(1-abar_t) eps, walking down the schedule from t = N-1;
-    # the per-step work (UNet fwd, cutouts, CLIP fwd, losses, CLIP+UNet dgrad, p_sample update, class/noise/cutout draws)
-    # is exactly the sampling loop's body (`GuidedSampler._step`).
-    x0_star = th.tanh(th.randn(1, 3, 256, 256, device=dev))
-    xs = [float(smp.tables.sqrt_alphas_cumprod[N - 1 - k]) * x0_star
-          + float(smp.tables.sqrt_one_minus_alphas_cumprod[N - 1 - k]) * th.randn(1, 3, 256, 256, device=dev) for k in range(total)]
-    mkw = {"y": th.zeros(1, dtype=th.long, device=dev)}
-    guid.current_timestep = N - 1
-    bufs = {}
+    loop = smp.ddim_sample_loop_progressive if cfg["ddim"] else smp.p_sample_loop_progressive
 
-    def one_step(k):
-        mkw["y"] = th.randint(0, 1000, (1,), device=dev)  # randomize_class (loop prologue of the reference sampler)
-        with th.no_grad():
-            out = smp._step(unet, xs[k], N - 1 - k, guid, mkw, None, 0, bufs)
-        guid.current_timestep -= 1
-        return out
+    def trajectory():
+        """Endless stream of guided steps: chains of start+1 steps, each step consuming the previous step's sample."""
+        while True:
+            gen = loop(unet, (1, 3, H, W), clip_denoised=False, cond_fn=guid, model_kwargs={"y": th.zeros(1, dtype=th.long, device=dev)},
+                       device=dev, skip_timesteps=N - 1 - start, init_image=x0_star, randomize_class=True, cond_fn_with_grad=True)
+            guid.current_timestep = N - 1 if cfg["quirk"] else start  # the generator's closure counter (cgd.py:265-267)
+            for out in gen:
+                guid.current_timestep -= 1
+                yield out
 
     def sync():
         if world > 1:
             dist.barrier()
         th.cuda.synchronize()
 
-    for k in range(args.warmup):
-        one_step(k)
-    prof = not args.no_profile
-    if prof:
-        ctx.check(ctx.lib.cgd_profile(ctx.h, 1))
+    steps = trajectory()
+    for _ in range(args.warmup):
+        next(steps)
     sync()
     t0 = time.perf_counter()
-    for k in range(args.warmup, total):
-        out = one_step(k)
+    for _ in range(args.steps):
+        out = next(steps)
     sync()
     dt = time.perf_counter() - t0
-    roof = None
-    if prof:
-        buf = (C.c_double * 6)()
+    finite = bool(th.isfinite(out["sample"]).all().item())
+    peak = float(out["sample"].abs().max().item())
+
+    roof = hbm = None
+    if not args.no_profile and rank == 0:
+        # separate, UNTIMED pass: per-launch HIP events perturb what they measure, so they stay out of the timed region
+        ctx.check(ctx.lib.cgd_profile(ctx.h, 1))
+        th.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(args.profile_steps):
+            next(steps)
+        buf = (C.c_double * 9)()
         ctx.check(ctx.lib.cgd_profile_read(ctx.h, buf))
+        dtp = time.perf_counter() - tp
         ctx.check(ctx.lib.cgd_profile(ctx.h, 0))
-        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n = list(buf)
-        ach = h_flop / (h_ms * 1e-3) / 1e12 if h_ms > 0 else 0.0
+        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n, gn_ms, gn_bytes, gn_n = list(buf)
+        ps = args.profile_steps
         nprod = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
-        roof = {"bound": "mfma", "kernel": f"hconv2_kernel<{args.precision}> (halo-staged 3x3 conv, hconv.hip)", "achieved": round(ach, 2),
-                "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": pmc_traffic("hconv2_kernel"),
-                "algorithmic_bytes_per_launch": HCONV_ALGO_BYTES_PER_LAUNCH,
-                "launches_per_step": h_n / args.steps, "avg_launch_us": round(h_ms * 1e3 / max(h_n, 1), 2),
-                "flop_per_launch": h_flop / max(h_n, 1), "kernel_time_share": round(h_ms * 1e-3 / dt, 4),
-                "mfma_products_per_flop": nprod, "mfma_issue_frac": round(nprod * ach / 2500.0, 4),
-                "other_mfma_kernel": {"kernel": "igemm_kernel / hgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / args.steps,
-                                      "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
-                                      "kernel_time_share": round(ig_ms * 1e-3 / dt, 4)}}
-        if h_n == 0:  # exact-fp32 mode: the halo kernel is bf16-only, every contraction runs in igemm_kernel on v_mfma_f32_32x32x2_f32
+        if h_n > 0:
+            ach = h_flop / (h_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": f"hconv2_kernel<{args.precision}> (halo-staged 3x3 conv, hconv.hip)", "achieved": round(ach, 2),
+                    "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                    "traffic": pmc_traffic("hconv2_kernel") if args.config == 2 else None,
+                    "algorithmic_bytes_per_launch": HCONV_ALGO_BYTES_PER_LAUNCH if args.config == 2 else None,
+                    "launches_per_step": h_n / ps, "avg_launch_us": round(h_ms * 1e3 / h_n, 2), "flop_per_launch": h_flop / h_n,
+                    "kernel_time_share": round(h_ms * 1e-3 / dtp, 4), "mfma_products_per_flop": nprod,
+                    "mfma_issue_frac": round(nprod * ach / 2500.0, 4), "measured_in": f"untimed pass of {ps} steps after the timed region",
+                    "other_mfma_kernel": {"kernel": "igemm_kernel / hgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / ps,
+                                          "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
+                                          "ms_per_step": round(ig_ms / ps, 3), "kernel_time_share": round(ig_ms * 1e-3 / dtp, 4)}}
+        else:  # exact-fp32 mode: the halo kernel is bf16-only, every contraction runs in igemm_kernel on v_mfma_f32_32x32x2_f32
             ach = ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12
             roof = {"bound": "mfma", "kernel": "igemm_kernel<f32> (implicit GEMM, gemm.hip)", "achieved": round(ach, 2), "peak": 157.3,
-                    "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None, "launches_per_step": ig_n / args.steps,
+                    "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None, "launches_per_step": ig_n / ps,
                     "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2), "flop_per_launch": ig_flop / max(ig_n, 1),
-                    "kernel_time_share": round(ig_ms * 1e-3 / dt, 4), "mfma_products_per_flop": 1, "mfma_issue_frac": round(ach / 157.3, 4)}
-    assert th.isfinite(out["sample"]).all().item(), "non-finite sample"
-    tmax = th.tensor([dt], device=dev, dtype=th.float64)
+                    "kernel_time_share": round(ig_ms * 1e-3 / dtp, 4), "mfma_products_per_flop": 1, "mfma_issue_frac": round(ach / 157.3, 4)}
+        if gn_n > 0:
+            gbs = gn_bytes / (gn_ms * 1e-3) / 1e9
+            hbm = {"bound": "hbm", "kernel": "GroupNorm32(+FiLM+SiLU) forward / backward ops (norm.hip; all launches of a norm)",
+                   "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                   "algorithmic_gbytes_per_step": round(gn_bytes / ps / 1e9, 3), "ms_per_step": round(gn_ms / ps, 3), "ops_per_step": gn_n / ps,
+                   "kernel_time_share": round(gn_ms * 1e-3 / dtp, 4)}
+    assert finite, "non-finite sample"
+    tmax = th.tensor([dt], device=dev if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl" else "cpu", dtype=th.float64)
+    per_rank = [dt]
     if world > 1:
+        gathered = [th.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(gathered, tmax)
+        per_rank = [float(t.item()) for t in gathered]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = tmax.item()
 
     if rank == 0:
         res = {
-            "metric": "diffusion steps/sec (UNet+CLIP+grad) at 256x256 cutn=16",
+            "metric": METRIC if args.config == 2 else f"diffusion steps/sec (UNet+CLIP+grad), BASELINE config {args.config}",
             "value": round(world * args.steps / tmax, 4),
             "unit": "diffusion steps/sec",
             "n_gpus": world,
@@ -244,15 +361,20 @@ def main():
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, fp32 accumulate, fp32 storage)", "bf16": "bf16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 256x256 class-cond UNet (554M), respace 250, cutn 16, batch 1/GPU, CLIP ViT-B/32, "
-                                   "cgs 1000 tv 150 range 50, randomize_class, p_sample",
-                       "global_batch": world, "parallelism": f"{world} independent samples (1/GPU), weights broadcast once over RCCL",
-                       "tflop_per_step": FLOP_PER_STEP / 1e12,
-                       "achieved_tflops_whole_step": round(FLOP_PER_STEP * args.steps / tmax / 1e12, 2)},
+            "config": {"workload": cfg["what"], "global_batch": world,
+                       "parallelism": f"{world} independent samples (1/GPU), weights broadcast once over RCCL, no per-step collective",
+                       "world_size_checked": dist.get_world_size() if world > 1 else 1,
+                       "ms_per_step_per_rank": [round(t / args.steps * 1e3, 3) for t in per_rank],
+                       "trajectory": f"chained: every step consumes the previous step's sample; chains of {start + 1} steps from "
+                                     f"x_t = q_sample(x0*, t={start}) down to t = 0 (init-image prologue, skip_timesteps {N - 1 - start})",
+                       "timed_seconds": round(tmax, 3), "last_sample_peak": round(peak, 3),
+                       "tflop_per_step": cfg["tflop"], "achieved_tflops_whole_step": round(cfg["tflop"] * args.steps / tmax, 2)},
         }
         if roof:
             res["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if hbm:
+            res["hbm"] = hbm
+        if world == 1 and not args.no_cpu_baseline and args.config == 2:
             try:
                 res["cpu_baseline"] = cpu_baseline_subprocess()
             except Exception as e:  # never lose the GPU number to a host-side problem

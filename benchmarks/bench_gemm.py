@@ -1,5 +1,5 @@
 """Micro-benchmark of the dense GEMM kernels on the ViT / UNet 1x1 shapes: igemm (auto tile) vs hgemm (tile code 513).
-Usage: python tests/bench_gemm.py [min_chunks ...]"""
+Usage: python benchmarks/bench_gemm.py [min_chunks ...]"""
 import os
 import sys
 

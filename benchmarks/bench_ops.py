@@ -1,5 +1,5 @@
 """Micro-benchmark of the MFMA implicit-GEMM conv kernel on the UNet's layer shapes, per tile variant.
-Usage: python tests/bench_ops.py [tag] [precision]   -> gpurun_out/ops_<tag>.json + table on stdout."""
+Usage: python benchmarks/bench_ops.py [tag] [precision]   -> gpurun_out/ops_<tag>.json + table on stdout."""
 import json
 import os
 import sys

@@ -1,7 +1,7 @@
 """End-to-end rate of the drop-in generator WITH per-step PNG output (the reference CLI default --save_frequency 1), 256x256,
 respace 250, cutn 16, ViT-B/32, synthetic weights: frames per second between the 5th and the last yielded item.
 Not the headline benchmark (bench.py excludes PNG writes); it documents the pipelined output path of cgd/cgd.py.
-Usage: CGD_SYNTHETIC_WEIGHTS=1 python tests/bench_output_path.py [items]"""
+Usage: CGD_SYNTHETIC_WEIGHTS=1 python benchmarks/bench_output_path.py [items]"""
 import json
 import os
 import sys

@@ -1,5 +1,5 @@
 """One-shot GPU parity report: runs every check of tests/parity_checks.py, keeps going after failures and writes
-gpurun_out/diag_<tag>.json + a readable table on stdout.  Usage: python tests/gpu_diag.py [tag] [group ...]"""
+gpurun_out/diag_<tag>.json + a readable table on stdout.  Usage: python benchmarks/gpu_diag.py [tag] [group ...]"""
 import json
 import os
 import sys

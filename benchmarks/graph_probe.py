@@ -1,5 +1,5 @@
 """Probe: does replaying the UNet forward+dgrad from a captured HIP graph shrink the inter-kernel gaps?
-Usage (GPU box): python tests/graph_probe.py"""
+Usage (GPU box): python benchmarks/graph_probe.py"""
 import os
 import sys
 import time

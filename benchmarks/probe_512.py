@@ -1,5 +1,5 @@
 """Device-only probe of BASELINE config 4's UNet (512x512, channel_mult (0.5,1,1,2,2,4,4)) and config 5's 256x288 input:
-forward + dgrad run, outputs finite, ms per call.  Usage: python tests/probe_512.py"""
+forward + dgrad run, outputs finite, ms per call.  Usage: python benchmarks/probe_512.py"""
 import os
 import sys
 import time

@@ -1,4 +1,4 @@
-"""Runs a few hconv2 launches on UNet layer shapes (for rocprofv3 --pmc passes).  Usage: python tests/probe_hconv.py"""
+"""Runs a few hconv2 launches on UNet layer shapes (for rocprofv3 --pmc passes).  Usage: python benchmarks/probe_hconv.py"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 """Clock / power while the halo conv kernel runs back to back (is the kernel power-limited?).
 Samples `rocm-smi --showclocks --showpower` from a thread while one UNet layer shape is launched in a loop.
-Usage: python tests/probe_power.py [seconds per shape]"""
+Usage: python benchmarks/probe_power.py [seconds per shape]"""
 import os
 import re
 import subprocess

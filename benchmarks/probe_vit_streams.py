@@ -1,5 +1,5 @@
 """Probe: CLIP ViT-B/32 forward + dgrad over 16 cutouts in one stream vs two halves on two HIP streams (two contexts: each has its own
-split-K workspace).  Usage: python tests/probe_vit_streams.py"""
+split-K workspace).  Usage: python benchmarks/probe_vit_streams.py"""
 import os
 import sys
 import time

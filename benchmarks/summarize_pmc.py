@@ -1,5 +1,5 @@
 """Mean PMC counter values per (kernel, grid size) from rocprofv3 counter_collection CSVs under <root>/*/.
-Usage: python tests/summarize_pmc.py <root> [kernel-name substring]"""
+Usage: python benchmarks/summarize_pmc.py <root> [kernel-name substring]"""
 import csv
 import glob
 import os

@@ -1,4 +1,4 @@
-"""Reduce the rocprofv3 CSV outputs of tests/run_profile.sh to one text summary (kernel-time table + per-kernel PMC means)."""
+"""Reduce the rocprofv3 CSV outputs of benchmarks/run_profile.sh to one text summary (kernel-time table + per-kernel PMC means)."""
 import csv
 import glob
 import os
@@ -63,7 +63,7 @@ def traffic_json(root, out_path):
     import json
     fetch, write = pmc(root, "pmc_fetch"), pmc(root, "pmc_write")
     ks = {short(r["Name"]): r for r in kernel_stats(root)}
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, tests/run_profile.sh",
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, benchmarks/run_profile.sh",
            "correction": "hbm_bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024", "kernels": {}}
     for k in fetch:
         f = fetch[k].get("FETCH_SIZE")

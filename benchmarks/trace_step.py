@@ -1,5 +1,5 @@
 """Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV of bench.py (steady-state step = between the last two
-sample_update_kernel launches).  Usage: python tests/trace_step.py <kernel_trace.csv> [top_n]"""
+sample_update_kernel launches).  Usage: python benchmarks/trace_step.py <kernel_trace.csv> [top_n]"""
 import collections
 import csv
 import sys

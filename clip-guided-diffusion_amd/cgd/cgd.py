@@ -12,6 +12,7 @@ from pathlib import Path
 import torch as th
 from tqdm.auto import tqdm
 
+from cgd_amd import shard
 from cgd_amd.guidance import ClipGuidance
 
 from . import clip_util, script_util
@@ -90,9 +91,17 @@ def clip_guided_diffusion(image_size=128, num_cutouts=16, prompts=[], image_prom
         pil = Image.open(script_util.fetch(init_image)).convert("RGB").resize((image_size, image_size))
         init_tensor = th.from_numpy(np.array(pil)).float().div(255).permute(2, 0, 1).to(device).unsqueeze(0).mul(2).sub(1)
 
+    # Multi-GPU (cgd_amd.launch: one process per GPU, torch.distributed initialised): the batch is sharded by samples, one (or
+    # a contiguous block) per rank; every rank draws the GLOBAL random tensors from the same seed and keeps its rows, so the
+    # frames are those of the single-process batched run.  No per-step collective.
+    rank, nranks = shard.world()
+    mine = shard.rank_samples(batch_size) if nranks > 1 else list(range(batch_size))
+    local_batch = len(mine)
+    if local_batch == 0:
+        return  # more ranks than samples: nothing to do here
     model_kwargs = {}
     if class_cond:
-        model_kwargs["y"] = th.zeros([batch_size], device=device, dtype=th.long)
+        model_kwargs["y"] = th.zeros([local_batch], device=device, dtype=th.long)
 
     gd_model, diffusion = script_util.load_guided_diffusion(
         checkpoint_path=diffusion_path, image_size=image_size, class_cond=class_cond, diffusion_steps=diffusion_steps,
@@ -110,10 +119,12 @@ def clip_guided_diffusion(image_size=128, num_cutouts=16, prompts=[], image_prom
         # "initialized lazily as it can use a bit of VRAM" (reference cgd.py:146-148): only with an init image and a non-zero scale
         lpips=script_util.load_lpips(gd_model.ctx, checkpoints_dir, device) if (init_tensor is not None and init_scale != 0) else None,
         init_tensor=init_tensor, init_scale=init_scale)
+    if nranks > 1:
+        cond_fn.shard = diffusion.shard = (mine, batch_size)
 
     loop = diffusion.ddim_sample_loop_progressive if timestep_respacing.startswith("ddim") else diffusion.p_sample_loop_progressive
     try:
-        samples = loop(gd_model, (batch_size, 3, image_size + height_offset, image_size + width_offset), clip_denoised=False,
+        samples = loop(gd_model, (local_batch, 3, image_size + height_offset, image_size + width_offset), clip_denoised=False,
                        model_kwargs=model_kwargs, cond_fn=cond_fn, progress=progress, skip_timesteps=skip_timesteps, init_image=init_tensor,
                        randomize_class=randomize_class, cond_fn_with_grad=True)
         cond_fn.current_timestep = diffusion.num_timesteps - 1
@@ -140,8 +151,8 @@ def clip_guided_diffusion(image_size=128, num_cutouts=16, prompts=[], image_prom
                     wandb_run.log(log)
             if frames is not None:
                 arr = frames.get().numpy()
-                for batch_idx in range(arr.shape[0]):
-                    yield batch_idx, script_util.write_image(arr[batch_idx], prefix_path, prompts, step, batch_idx)
+                for local_idx, batch_idx in enumerate(mine):  # batch_idx: index in the GLOBAL batch (output directory <idx:02>)
+                    yield batch_idx, script_util.write_image(arr[local_idx], prefix_path, prompts, step, batch_idx)
 
         previous = None
         pending = enqueue_steps()
@@ -259,7 +270,8 @@ def main():
         import subprocess
         if shutil.which("ffmpeg") is None:
             raise RuntimeError("--save-as-gif/--save-as-video need ffmpeg on PATH")
-        for batch_idx in range(args.batch_size):
+        _, nranks = shard.world()
+        for batch_idx in (shard.rank_samples(args.batch_size) if nranks > 1 else range(args.batch_size)):
             # file names and encoder settings of the reference (script_util.py:104-214): <frames_dir>_<batch_idx:02>.gif|.mp4
             frames_dir = script_util.clean_and_combine_prompts(args.prefix, kwargs["prompts"], batch_idx)
             pattern = f"{frames_dir}/%04d.png"

@@ -12,6 +12,7 @@ from functools import lru_cache
 import torch as th
 
 from cgd_amd import nets as _nets
+from cgd_amd import shard as _shard
 from cgd_amd import synthetic as _synthetic
 from cgd_amd.guidance import CLIP_MEAN, CLIP_STD, MakeCutouts  # noqa: F401
 
@@ -137,7 +138,8 @@ def load_clip(model_name="ViT-B/32", device="cpu"):
             tower = _nets.ClipImageTower(ctx, config=_vit_config_from_state_dict(sd))
         else:
             tower = _nets.ClipResNetTower(ctx, config=_rn_config_from_state_dict(sd))
-        tower.load_clip_state_dict({k: v.float() for k, v in sd.items() if k.startswith("visual.")})
+        _shard.load_broadcast(tower, lambda: {k: v.float() for k, v in sd.items() if k.startswith("visual.")}, f"cuda:{ctx.device}",
+                              prefix="visual.")
         text_model = None
         try:
             import clip  # optional, setup-time only
@@ -148,10 +150,12 @@ def load_clip(model_name="ViT-B/32", device="cpu"):
     if script_util.synthetic_weights_enabled():
         if model_name in _nets.VIT_CONFIGS:
             tower = _nets.ClipImageTower(ctx, model_name)
-            tower.load_state_dict(_synthetic.synthetic_state_dict(tower, seed=4321, device=f"cuda:{ctx.device}"))
+            _shard.load_broadcast(tower, lambda: _synthetic.synthetic_state_dict(tower, seed=4321, device=f"cuda:{ctx.device}"),
+                                  f"cuda:{ctx.device}")
         elif model_name in _nets.RN_CONFIGS:
             tower = _nets.ClipResNetTower(ctx, model_name)
-            tower.load_state_dict(_synthetic.resnet_state_dict(tower, seed=2468, device=f"cuda:{ctx.device}"))
+            _shard.load_broadcast(tower, lambda: _synthetic.resnet_state_dict(tower, seed=2468, device=f"cuda:{ctx.device}"),
+                                  f"cuda:{ctx.device}")
         else:
             raise NotImplementedError(f"{model_name}: supported towers are {sorted(_nets.VIT_CONFIGS) + sorted(_nets.RN_CONFIGS)}")
         return ClipModel(tower, None, model_name), tower.input_resolution

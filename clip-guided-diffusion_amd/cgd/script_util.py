@@ -17,6 +17,7 @@ import torch as th
 from cgd_amd import diffusion as _diffusion
 from cgd_amd import lib as _lib
 from cgd_amd import nets as _nets
+from cgd_amd import shard as _shard
 from cgd_amd import sampler as _sampler
 from cgd_amd import synthetic as _synthetic
 
@@ -180,10 +181,12 @@ def load_guided_diffusion(checkpoint_path: str, image_size: int, class_cond: boo
     cfg = model_config(image_size, class_cond, diffusion_steps, timestep_respacing, use_fp16, noise_schedule, dropout)
     ctx = get_context(device)
     model = _nets.UNet(ctx, **unet_kwargs(cfg))
+    # multi-GPU runs (cgd_amd.launch): rank 0 reads / draws the weights, one RCCL broadcast hands them to the other ranks
+    dev = f"cuda:{ctx.device}"
     if os.path.isfile(checkpoint_path):
-        model.load_state_dict(th.load(checkpoint_path, map_location="cpu"))
+        _shard.load_broadcast(model, lambda: th.load(checkpoint_path, map_location="cpu"), dev)
     elif synthetic_weights_enabled():
-        model.load_state_dict(_synthetic.synthetic_state_dict(model, seed=1234, device=f"cuda:{ctx.device}"))
+        _shard.load_broadcast(model, lambda: _synthetic.synthetic_state_dict(model, seed=1234, device=dev), dev)
     else:
         raise FileNotFoundError(f"{checkpoint_path} not found (set CGD_SYNTHETIC_WEIGHTS=1 for seeded random weights)")
     steps = cfg["diffusion_steps"]

@@ -96,14 +96,14 @@ int cgd_profile(cgd_ctx* ctx, int enable) {
   return 0;
 }
 
-// out[0..2] = igemm_kernel launches (with their split-K reduce): summed time (ms), algorithmic FLOP, launches;
-// out[3..5] = the same for hconv2_kernel launches alone.  Resets the records.
+// out[3k .. 3k+2] = {summed time (ms), algorithmic work, launches} of kind k (common.h: 0 GEMM kernels with their split-K reduce
+// [FLOP], 1 hconv2_kernel alone [FLOP], 2 GroupNorm forward / backward ops [bytes]).  Resets the records.
 int cgd_profile_read(cgd_ctx* ctx, double* out) {
   CGD_NEED_CTX(ctx);
   if (!out) CGD_FAIL(ctx, "cgd_profile_read: out is null");
   CGD_HIP(ctx, hipDeviceSynchronize());
   CGD_TRY(cgd_prof_fold(ctx, 0));
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < CGD_PROF_KINDS; ++k) {
     out[3 * k + 0] = ctx->prof_ms[k];
     out[3 * k + 1] = ctx->prof_flops[k];
     out[3 * k + 2] = ctx->prof_n[k];
@@ -130,6 +130,34 @@ int cgd_prof_fold(cgd_ctx* ctx, size_t keep_last) {
   }
   ctx->prof_recs.erase(ctx->prof_recs.begin(), ctx->prof_recs.begin() + n);
   return 0;
+}
+
+int cgd_prof_begin(cgd_ctx* ctx, ProfRec* pr, int kind, double work, hipStream_t s) {
+  pr->live = false;
+  if (!ctx->prof_on) return 0;
+  // bound the number of live events: retire all but the newest 1024 records (they completed long ago)
+  if (ctx->prof_recs.size() >= 3072) CGD_TRY(cgd_prof_fold(ctx, 1024));
+  for (hipEvent_t* e : {&pr->a, &pr->b}) {
+    if (!ctx->prof_pool.empty()) {
+      *e = ctx->prof_pool.back();
+      ctx->prof_pool.pop_back();
+    } else {
+      CGD_HIP(ctx, hipEventCreate(e));
+    }
+  }
+  pr->flops = work;
+  pr->kind = kind;
+  pr->live = true;
+  CGD_HIP(ctx, hipEventRecord(pr->a, s));
+  return 0;
+}
+int cgd_prof_stamp(cgd_ctx* ctx, ProfRec* pr, hipStream_t s) {
+  if (pr->live) CGD_HIP(ctx, hipEventRecord(pr->b, s));
+  return 0;
+}
+void cgd_prof_push(cgd_ctx* ctx, ProfRec* pr) {
+  if (pr->live) ctx->prof_recs.push_back(*pr);
+  pr->live = false;
 }
 
 extern "C" {

@@ -13,10 +13,15 @@
 // 2: single bf16 product (fp32 accumulate)
 enum { CGD_PREC_F32 = 0, CGD_PREC_BF16X3 = 1, CGD_PREC_BF16 = 2 };
 
+// kinds of profiled launches (bench.py): MFMA GEMM kernels (igemm / hgemm incl. their split-K reduce), the halo conv kernel alone
+// (the dominant kernel of the step), GroupNorm forward / backward (all launches of one norm; `work` = algorithmic HBM bytes)
+enum { CGD_PROF_GEMM = 0, CGD_PROF_HCONV = 1, CGD_PROF_GN = 2, CGD_PROF_KINDS = 3 };
+
 struct ProfRec {
-  hipEvent_t a, b;
-  double flops;
-  int kind;  // 0: igemm_kernel (+ its split-K reduce), 1: hconv2_kernel alone (the dominant kernel of the step)
+  hipEvent_t a = nullptr, b = nullptr;
+  double flops = 0.0;  // algorithmic work: FLOP for the MFMA kinds, bytes for CGD_PROF_GN
+  int kind = 0;
+  bool live = false;
 };
 
 struct FragEntry {  // fragment-order copy of a persistent weight (hgemm.hip)
@@ -47,7 +52,7 @@ struct cgd_ctx {
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
-  double prof_ms[2] = {0.0, 0.0}, prof_flops[2] = {0.0, 0.0}, prof_n[2] = {0.0, 0.0};  // folded totals per ProfRec::kind
+  double prof_ms[CGD_PROF_KINDS] = {}, prof_flops[CGD_PROF_KINDS] = {}, prof_n[CGD_PROF_KINDS] = {};  // folded totals per kind
 };
 
 // RAII: exact-fp32 MFMA products (v_mfma_f32_32x32x2_f32) for the duration of a pass, whatever the context precision is.
@@ -76,6 +81,10 @@ struct DeviceScope {
 
 // fold the oldest records (all but `keep_last`) into the running totals and recycle their events
 int cgd_prof_fold(cgd_ctx* ctx, size_t keep_last);
+// measurement only (no-ops unless cgd_profile(ctx, 1)): begin records event a on `s`, stamp records event b, push files the record
+int cgd_prof_begin(cgd_ctx* ctx, ProfRec* pr, int kind, double work, hipStream_t s);
+int cgd_prof_stamp(cgd_ctx* ctx, ProfRec* pr, hipStream_t s);
+void cgd_prof_push(cgd_ctx* ctx, ProfRec* pr);
 
 #define CGD_HIP(ctx, expr)                                                                   \
   do {                                                                                       \

@@ -485,27 +485,10 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   const bool use_h = kernel == 1, use_g = kernel == 2;
   if (p.splitk > 1) p.ws = ctx->ws;
   ProfRec pr;
-  if (ctx->prof_on) {
-    // bound the number of live events: retire all but the newest 1024 records (they completed long ago)
-    if (ctx->prof_recs.size() >= 3072) CGD_TRY(cgd_prof_fold(ctx, 1024));
-    auto get = [&](hipEvent_t* e) -> int {
-      if (!ctx->prof_pool.empty()) {
-        *e = ctx->prof_pool.back();
-        ctx->prof_pool.pop_back();
-        return 0;
-      }
-      CGD_HIP(ctx, hipEventCreate(e));
-      return 0;
-    };
-    CGD_TRY(get(&pr.a));
-    CGD_TRY(get(&pr.b));
-    pr.flops = 2.0 * p.M * p.N * p.K * p.nbatch;
-    pr.kind = use_h ? 1 : 0;
-    CGD_HIP(ctx, hipEventRecord(pr.a, s));
-  }
+  CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? CGD_PROF_HCONV : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));
   if (use_h) {
     CGD_TRY(cgd_launch_hconv(ctx, p, s));
-    if (ctx->prof_on) CGD_HIP(ctx, hipEventRecord(pr.b, s));  // the halo conv kernel alone, without its split-K reduce
+    CGD_TRY(cgd_prof_stamp(ctx, &pr, s));  // the halo conv kernel alone, without its split-K reduce
   } else if (use_g) {
     CGD_TRY(cgd_launch_hgemm(ctx, p, s));
   } else {
@@ -521,10 +504,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.ws, p.splitk, p.M, p.N, p.C, p.ldc, p.bias, p.R,
                        p.ldr, p.alpha);
   }
-  if (ctx->prof_on) {
-    if (!use_h) CGD_HIP(ctx, hipEventRecord(pr.b, s));
-    ctx->prof_recs.push_back(pr);
-  }
+  if (!use_h) CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
+  cgd_prof_push(ctx, &pr);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -904,11 +904,15 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  ProfRec pr;  // algorithmic HBM bytes of a GroupNorm forward: one read of x, one write of y
+  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, 8.0 * B * HW * C, s));
   if (HW <= GN_SMALL_HW) {
     if (act)
       launch_gn_small_fwd<1>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s);
     else
       launch_gn_small_fwd<0>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s);
+    CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
+    cgd_prof_push(ctx, &pr);
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
@@ -919,6 +923,8 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
     hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
   else
     hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+  CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
+  cgd_prof_push(ctx, &pr);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -928,11 +934,15 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  ProfRec pr;  // algorithmic HBM bytes of a GroupNorm backward: read x and dz (and the residual gradient `add`), write dx
+  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (add ? 16.0 : 12.0) * B * HW * C, s));
   if (HW <= GN_SMALL_HW) {
     if (act)
       launch_gn_small_bwd<1>(x, ldx, dz, lddz, dx, lddx, add, ldadd, B, HW, C, stats, coef, s);
     else
       launch_gn_small_bwd<0>(x, ldx, dz, lddz, dx, lddx, add, ldadd, B, HW, C, stats, coef, s);
+    CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
+    cgd_prof_push(ctx, &pr);
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
@@ -949,6 +959,8 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
     hipLaunchKernelGGL((gn_bwd_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C,
                        chunk, coef, bcoef);
   }
+  CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
+  cgd_prof_push(ctx, &pr);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -169,6 +169,7 @@ class ClipGuidance:
         self.coords_tape = None  # optional replay of cutout coordinates (tests)
         self.calls = 0
         self.last_ran = False    # did the last call evaluate the guidance (False on a --reduce-clip gated step)?
+        self.shard = None        # (indices of the global batch on this rank, global batch size): rows of the B x P weight matrix
         self._wm = {}
         self._buf = {}
 
@@ -178,6 +179,32 @@ class ClipGuidance:
         if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
             t = self._buf[name] = th.empty(shape, device=device, dtype=dtype)
         return t
+
+    def _upload_geometry(self, geo, dev):
+        """Crop table of this step -> device: written into one of four pinned staging rows and copied asynchronously (a
+        pageable-memory `th.tensor(...).to(dev)` stalls the enqueueing thread on every step).  A slot is reused only after the
+        copy that last read it has completed (event; already signalled in steady state)."""
+        n = len(geo)
+        if th.device(dev).type != "cuda":  # host-logic tests drive this class with a recording library and CPU tensors
+            return th.as_tensor(geo, dtype=th.int32).view(n, 4).to(dev)
+        ring = self._buf.get("_geo_ring")
+        if ring is None or ring["host"].shape[1] < n or ring["dev"].device != dev:
+            cap = max(n, 64)
+            ring = self._buf["_geo_ring"] = {"host": th.empty((4, cap, 4), dtype=th.int32).pin_memory(),
+                                             "dev": th.empty((4, cap, 4), dtype=th.int32, device=dev),
+                                             "done": [None] * 4, "next": 0}
+        k = ring["next"]
+        ring["next"] = (k + 1) % 4
+        if ring["done"][k] is not None:
+            ring["done"][k].synchronize()
+        host = ring["host"][k, :n]
+        host.copy_(th.as_tensor(geo, dtype=th.int32).view(n, 4))
+        out = ring["dev"][k, :n]
+        out.copy_(host, non_blocking=True)
+        ev = th.cuda.Event()
+        ev.record(th.cuda.current_stream(dev))
+        ring["done"][k] = ev
+        return out
 
     def schedule(self):
         """Returns (skip_guidance, current_cutn) per cgd.py:155-175."""
@@ -206,11 +233,15 @@ class ClipGuidance:
         self.calls += 1
         self.make_cutouts.last_coords = coords
         cutn = len(coords)
-        geo = th.tensor(crop_geometry(coords, H, W), dtype=th.int32).to(dev, non_blocking=True)
+        geo = self._upload_geometry(crop_geometry(coords, H, W), dev)
         N = cutn * B
         wm = self._wm.get(B)
         if wm is None:
-            wm = self._wm[B] = prompt_weight_matrix(self.weights.cpu(), B, dev)
+            if self.shard is None:
+                wm = prompt_weight_matrix(self.weights.cpu(), B, dev)
+            else:  # the B <-> P broadcast rule is decided on the GLOBAL batch (sample b <-> prompt b when B == P)
+                wm = prompt_weight_matrix(self.weights.cpu(), self.shard[1], dev)[self.shard[0]].contiguous()
+            self._wm[B] = wm
         gclip = self._b("gclip", (B, 3, H, W), dev)
         acc = 0
         if self.lpips is not None:

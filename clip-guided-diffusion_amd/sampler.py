@@ -24,10 +24,21 @@ class GuidedSampler:
         self.num_timesteps = tables.num_timesteps
         self.sqrt_one_minus_alphas_cumprod = tables.sqrt_one_minus_alphas_cumprod
         self.timestep_map = tables.timestep_map
-        self.tape = None  # optional {'x_T','noise':[...],'y':[...]} replay (tests / multi-GPU slicing)
+        self.tape = None  # optional {'x_T','noise':[...],'y':[...]} replay (tests)
+        # multi-GPU sharding: (indices of the global batch this rank owns, global batch size).  Every rank draws
+        # the GLOBAL (B,3,H,W) tensors from the same seed, exactly like the batched reference run, and keeps its slice: the
+        # samples are bit-for-bit those of the batched run, and there is no per-step collective.
+        self.shard = None
 
     def step_coef(self, i, fac_index=None):
         return self.tables.step_coef(i, fac_index)
+
+    def _draw_like(self, x):
+        """randn_like(x); with sharding the global batch is drawn and this rank's rows are kept."""
+        if self.shard is None:
+            return th.randn_like(x)
+        idx, gb = self.shard
+        return th.randn((gb,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)[idx].contiguous()
 
     # ---- one step -------------------------------------------------------------------------------------
     def _step(self, model, x, i, cond_fn, model_kwargs, noise, mode, bufs):
@@ -38,7 +49,12 @@ class GuidedSampler:
         native = isinstance(cond_fn, ClipGuidance)
         fac_index = cond_fn.fac_index() if native else None
         coef = self.tables.step_coef(i, fac_index)
-        ts = th.full((B,), self.tables.model_timestep(i), device=dev, dtype=th.float32)
+        # model timesteps of the whole schedule live on the device (one row per step, B columns): no per-step fill kernel
+        tt = bufs.get("_ts")
+        if tt is None or tt.shape[1] != B or tt.device != dev:
+            tt = bufs["_ts"] = th.tensor([float(self.tables.model_timestep(k)) for k in range(self.num_timesteps)], dtype=th.float32,
+                                         device=dev).view(-1, 1).repeat(1, B).contiguous()
+        ts = tt[i]
         y = model_kwargs.get("y") if model_kwargs else None
 
         def buf(name, shape):
@@ -54,7 +70,7 @@ class GuidedSampler:
             ctx.check(lib.cgd_pmv_blend(ctx.h, x.data_ptr(), out6.data_ptr(), x0.data_ptr(), mean.data_ptr(), logvar.data_ptr(),
                                         xin.data_ptr(), B, H, W, coef, s))
             if noise is None:
-                noise = th.randn_like(x)  # drawn before cond_fn, as in p_sample_with_grad
+                noise = self._draw_like(x)  # drawn before cond_fn, as in p_sample_with_grad
             g = cond_fn.native(x, x0, xin, coef) if native else None
             scal = cond_fn.scalars if (native and g is not None and cond_fn.use_magnitude) else None
             ctx.check(lib.cgd_sample_update(ctx.h, x.data_ptr(), x0.data_ptr(), mean.data_ptr(), logvar.data_ptr(), L.ptr(g),
@@ -70,7 +86,7 @@ class GuidedSampler:
                 p0 = coef.sqrt_recip * xr - coef.sqrt_recipm1 * eps
                 mu = coef.coef1 * p0 + coef.coef2 * xr
                 if noise is None:
-                    noise = th.randn_like(x)
+                    noise = self._draw_like(x)
                 t_idx = th.full((B,), i, device=dev, dtype=th.long)
                 p = {"mean": mu, "variance": th.exp(lv), "log_variance": lv, "pred_xstart": p0}
                 g = cond_fn(xr, t_idx, p, **(model_kwargs or {}))
@@ -94,6 +110,10 @@ class GuidedSampler:
             img = noise.to(device).float()
         elif tape is not None:
             img = tape["x_T"].to(device).float()
+        elif self.shard is not None:
+            idx, gb = self.shard
+            assert shape[0] == len(idx), "shape[0] must be this rank's share of the global batch"
+            img = th.randn(gb, *shape[1:], device=device)[idx]
         else:
             img = th.randn(*shape, device=device)
         if skip_timesteps and init_image is None:
@@ -114,6 +134,8 @@ class GuidedSampler:
             if randomize_class and "y" in model_kwargs:
                 if tape is not None:
                     model_kwargs["y"] = tape["y"][n].to(device)
+                elif self.shard is not None:
+                    model_kwargs["y"] = th.randint(0, model.num_classes, (self.shard[1],), device=device)[self.shard[0]]
                 else:
                     model_kwargs["y"] = th.randint(0, model.num_classes, model_kwargs["y"].shape, device=device)
             step_noise = tape["noise"][n].to(device).float().contiguous() if tape is not None else None

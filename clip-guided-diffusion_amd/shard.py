@@ -26,6 +26,31 @@ def broadcast_flat(make_flat, numel, device, src=0, dtype=th.float32):
     return flat
 
 
+def flat_pack(sd, names):
+    return th.cat([sd[n].reshape(-1).float() for n in names])
+
+
+def flat_unpack(flat, specs):
+    out, off = {}, 0
+    for name, numel in specs:
+        out[name] = flat[off:off + numel]
+        off += numel
+    return out
+
+
+def load_broadcast(net, make_state_dict, device, prefix=""):
+    """Load a network handle (nets._Net) on every rank from ONE materialisation of its state dict: rank 0 calls
+    `make_state_dict()` (reads the checkpoint / draws the synthetic weights), packs the parameters the handle asks for into one
+    flat fp32 vector and broadcasts it over RCCL/xGMI; the other ranks never touch the disk.  Single-process: a plain load."""
+    rank, n = world()
+    if n == 1:
+        return net.load_state_dict(make_state_dict(), prefix)
+    specs = net.param_specs()
+    names = [prefix + name for name, _ in specs]
+    flat = broadcast_flat(lambda: flat_pack(make_state_dict(), names), sum(k for _, k in specs), device)
+    return net.load_state_dict(flat_unpack(flat, [(prefix + name, k) for name, k in specs]), prefix)
+
+
 def rank_samples(global_batch, rank=None, nranks=None):
     """Indices of the global batch owned by a rank (contiguous blocks; 1 sample per GPU when global_batch == world)."""
     r, n = world()

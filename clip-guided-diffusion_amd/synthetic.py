@@ -5,6 +5,8 @@ zero-initialised layers get small non-zero values so that no gradient path is de
 """
 import torch as th
 
+from .shard import flat_pack, flat_unpack  # noqa: F401  (re-exported for the callers that pack synthetic weights)
+
 
 def synthetic_state_dict(net, seed=1234, device="cuda", std=0.02):
     g = th.Generator(device=device).manual_seed(seed)
@@ -25,18 +27,6 @@ def synthetic_state_dict(net, seed=1234, device="cuda", std=0.02):
             t = t * 0.05
         sd[name] = t
     return sd
-
-
-def flat_pack(sd, names):
-    return th.cat([sd[n].reshape(-1).float() for n in names])
-
-
-def flat_unpack(flat, specs):
-    out, off = {}, 0
-    for name, numel in specs:
-        out[name] = flat[off:off + numel]
-        off += numel
-    return out
 
 
 def lpips_state_dict(seed=777, device="cpu"):

@@ -40,11 +40,12 @@ const char* cgd_version(void);
 int cgd_set_tiles(cgd_ctx* ctx, int large_tile, int small_tile);
 /* tuning knob: weight GEMM kernel (hgemm.hip): mode 0 off / 1 auto, smallest M, 64-column chunks per split-K slice (0 = keep) */
 int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks);
-/* HIP-event timing of every MFMA GEMM/conv launch on its own stream (measurement only; bench.py roofline leg).
- * cgd_profile_read: out[0..2] = igemm_kernel / hgemm_kernel launches incl. their split-K reduce {summed ms, algorithmic FLOP,
- * launches}, out[3..5] = the same for hconv2_kernel launches alone (the dominant kernel); synchronises the device and resets. */
+/* HIP-event timing of the profiled launches on their own stream (measurement only; bench.py roofline / hbm legs).
+ * cgd_profile_read: out[3k .. 3k+2] = {summed ms, algorithmic work, launches} of kind k: 0 = igemm_kernel / hgemm_kernel launches
+ * incl. their split-K reduce [FLOP], 1 = hconv2_kernel launches alone (the dominant kernel) [FLOP], 2 = GroupNorm forward /
+ * backward ops, all launches of one norm [algorithmic HBM bytes]; synchronises the device and resets. */
 int cgd_profile(cgd_ctx* ctx, int enable);
-int cgd_profile_read(cgd_ctx* ctx, double* out6);
+int cgd_profile_read(cgd_ctx* ctx, double* out9);
 
 /* ---- UNet epsilon/sigma predictor: replaces guided_diffusion.unet.UNetModel built at
  *      /root/reference/cgd/script_util.py:316 from /root/reference/data/diffusion_model_flags.py ---- */

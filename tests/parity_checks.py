@@ -54,7 +54,7 @@ def rec(name, got, ref, rtol=RTOL, atol=ATOL, unit_peak=None, allow_small=False)
     return out
 
 
-def rec_flips(name, got, ref, tol_l2, max_viol=1e-3):
+def rec_flips(name, got, ref, tol_l2=3e-3, max_viol=1e-2):
     """NAMED criterion "relu-flips" for gradients of ReLU / max-pool networks.  Those gradients are discontinuous in the
     activations: any two implementations whose activations differ in the last bits flip a few masks, which moves individual
     gradient entries far more than rtol 1e-3 (the CPU oracle in fp32 against itself in fp64: max 4-6e-3 of the peak, L2
@@ -442,14 +442,15 @@ def check_lpips(precision):
         x = (ref + 0.3 * th.randn(B, 3, H, W, generator=g(71))).clamp(-1.2, 1.2)
         xr = x.double().requires_grad_()
         val = orc(xr, ref.double()).flatten()
-        (val.sum() * 7.0).backward()
+        val.sum().backward()
+        gs = unit_seed(xr.grad)  # the gradient is linear in grad_scale: judged at unit peak
         dev_net.set_reference(ref.to(DEV))
-        loss, gx = dev_net.loss_grad(x.to(DEV), grad_scale=7.0)
+        loss, gx = dev_net.loss_grad(x.to(DEV), grad_scale=gs)
         out.append(rec(f"lpips loss[p{precision}] B{B} {H}x{W}", loss, val.float()))
-        out.append(rec(f"lpips grad[p{precision}] B{B} {H}x{W}", gx, xr.grad.float()))
+        out.append(rec(f"lpips grad[p{precision}] B{B} {H}x{W}", gx, (xr.grad * gs).float()))
         base = th.randn(B, 3, H, W, generator=g(72))
-        _, gacc = dev_net.loss_grad(x.to(DEV), grad_scale=7.0, g=base.to(DEV).clone(), accumulate=True)
-        out.append(rec(f"lpips grad accumulate[p{precision}] B{B} {H}x{W}", gacc, xr.grad.float() + base))
+        _, gacc = dev_net.loss_grad(x.to(DEV), grad_scale=gs, g=base.to(DEV).clone(), accumulate=True)
+        out.append(rec(f"lpips grad accumulate[p{precision}] B{B} {H}x{W}", gacc, (xr.grad * gs).float() + base))
     return out
 
 

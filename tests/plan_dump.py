@@ -60,7 +60,7 @@ def step_plan(cutn=16):
     handle = lib.load()
     rows = []
     with th.device("meta"):
-        unet = ou.UNetModel(**bench.UNET_256).eval()
+        unet = ou.UNetModel(**bench.U256).eval()
         u = record_shapes(unet, th.empty(1, 3, 256, 256), th.zeros(1), th.zeros(1, dtype=th.long))
         clip = ocv.ClipImageModel("ViT-B/32").eval()
         v = record_shapes(clip, th.empty(cutn, 3, 224, 224), call=lambda n, x: n.encode_image(x))

@@ -60,6 +60,28 @@ def test_weight_broadcast_and_tape_sharding_world2():
     assert g1 is None and abs(g0[0] - t0) < 1e-6 and abs(g0[1] - t1) < 1e-6
 
 
+def test_bench_py_gpus_n_spawns_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start 2 ranks itself (one process per GPU), rendezvous, broadcast the
+    weights once and report n_gpus 2 with the max over ranks.  No GPU here: CGD_BENCH_DRYRUN runs the launcher / collective
+    plumbing over gloo without device work (the GPU flow of the same code path is tests/test_gpu_step.py)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CGD_BENCH_DRYRUN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, out.stdout  # exactly one JSON line: rank 0's
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["config"]["world_size_checked"] == 2 and res["config"]["ranks_reporting"] == 2
+    assert res["config"]["weights_checksum"] == 499500.0 and res["config"]["max_over_ranks_s"] >= 0.02
+    # a launcher that disagrees with --gpus is an error, not a silent 1-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
 def test_rank_samples_partition():
     import cgd_amd  # noqa: F401
     from cgd_amd import shard
@@ -110,3 +132,53 @@ def test_one_sample_per_rank_reproduces_the_batched_run():
     coupled = run(tape, B, use_magnitude=True)
     alone0 = run(shard.slice_tape(tape, [0]), 1, use_magnitude=True)
     assert (alone0[-1] - coupled[-1][[0]]).abs().max().item() > 1e-3 * coupled[-1][[0]].abs().max().item()
+
+
+def test_sampler_sharded_draws_are_rows_of_the_global_draws(monkeypatch):
+    """cgd_amd.sampler with `shard = (rows, global_batch)`: x_T, the per-step noise and the class ids of a rank are the rank's rows
+    of the tensors a single-process batched run draws from the same seed (CPU tensors, the step itself stubbed out)."""
+    sys.path.insert(0, ROOT)
+    import types
+    import cgd_amd  # noqa: F401
+    from cgd_amd import diffusion as dd
+    from cgd_amd import sampler
+    tables = dd.create_gaussian_diffusion(1000, "linear", "10")
+
+    def run(shard, nb):
+        smp = sampler.GuidedSampler(types.SimpleNamespace(device=0), tables)
+        smp.shard = shard
+        seen = []
+
+        def fake_step(model, x, i, cond_fn, model_kwargs, noise, mode, bufs):
+            seen.append((x.clone(), smp._draw_like(x), model_kwargs["y"].clone()))
+            return {"sample": x * 0.5, "pred_xstart": x}
+
+        smp._step = fake_step
+        th.manual_seed(11)
+        model = types.SimpleNamespace(num_classes=1000)
+        gen = smp.p_sample_loop_progressive(model, (nb, 3, 4, 4), clip_denoised=False, cond_fn=None, model_kwargs={"y": th.zeros(nb, dtype=th.long)},
+                                            device="cpu", randomize_class=True)
+        for _ in zip(range(3), gen):
+            pass
+        return seen
+
+    full = run(None, 4)
+    for rows in ([0], [2, 3]):
+        part = run((rows, 4), len(rows))
+        assert th.equal(part[0][0], full[0][0][rows])                       # x_T
+        for k in range(3):
+            assert th.equal(part[k][1], full[k][1][rows]), k                  # per-step noise
+            assert th.equal(part[k][2], full[k][2][rows]), k                  # class ids
+
+
+def test_prompt_weight_rows_follow_the_global_batch():
+    """B == P > 1 scores sample b against prompt b only (cgd.py:196-200): a rank that owns sample 2 of a global batch of 4 must use
+    row 2 of the 4 x 4 weight matrix although its local batch is 1."""
+    sys.path.insert(0, ROOT)
+    import cgd_amd  # noqa: F401
+    from cgd_amd import guidance as dg
+    w = th.tensor([0.4, 0.3, 0.2, 0.1])
+    full = dg.prompt_weight_matrix(w, 4, "cpu")
+    assert th.equal(full, th.eye(4) * w.sum())
+    assert th.equal(full[[2]], th.tensor([[0.0, 0.0, 1.0, 0.0]]) * w.sum())
+    assert th.equal(dg.prompt_weight_matrix(w, 1, "cpu"), w.view(1, 4))     # what a naive per-rank B = 1 would have used instead

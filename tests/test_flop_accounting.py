@@ -1,4 +1,4 @@
-"""The algorithmic work that bench.py / tests/bench_configs.py price their rates with (FLOP = 2 * (MAC_fwd + MAC_dgrad),
+"""The algorithmic work that bench.py (`--config 2..5`) prices their rates with (FLOP = 2 * (MAC_fwd + MAC_dgrad),
 MAC_dgrad = MAC_fwd + the attention matmuls once more, no weight gradients, no elementwise work) re-derived from the oracle networks
 with torch's FlopCounterMode on the meta device (no arithmetic is executed)."""
 import os
@@ -38,20 +38,20 @@ def vit_macs(name):
 
 def test_headline_flop_per_step_matches_the_oracle_networks():
     import bench
-    u_fwd, u_att = unet_macs(bench.UNET_256, 256, 256)
+    u_fwd, u_att = unet_macs(bench.U256, 256, 256)
     assert u_fwd == pytest.approx(1119.8, abs=0.1) and u_att == pytest.approx(6.09, abs=0.01)
     v_fwd, v_att = vit_macs("ViT-B/32")
     assert v_fwd == pytest.approx(4.409, abs=0.001)
     u_dgrad, v_dgrad = u_fwd + u_att, v_fwd + v_att  # attention backward: 4 matmuls instead of 2, everything else 1:1
     assert u_dgrad == pytest.approx(1125.9, abs=0.1) and v_dgrad == pytest.approx(4.455, abs=0.002)
     flop = 2e9 * (u_fwd + u_dgrad) + 16 * 2e9 * (v_fwd + v_dgrad)
-    assert flop == pytest.approx(bench.FLOP_PER_STEP, rel=1e-3)  # 4.775 TFLOP per guided step (BASELINE config 2)
+    assert flop == pytest.approx(bench.CONFIGS[2]["tflop"] * 1e12, rel=1e-3)  # 4.775 TFLOP per guided step (BASELINE config 2)
 
 
 def test_flop_per_step_of_the_other_configs():
     from oracle import clip_resnet as ocr
     from oracle import lpips_vgg as olp
-    from tests import bench_configs as bc
+    import bench as bc
     u256 = sum(unet_macs(bc.U256, 256, 256)) + unet_macs(bc.U256, 256, 256)[0]          # fwd + dgrad
     # config 3: 32 cutouts through ViT-B/16
     v16 = vit_macs("ViT-B/16")
