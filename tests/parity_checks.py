@@ -54,24 +54,25 @@ def rec(name, got, ref, rtol=RTOL, atol=ATOL, unit_peak=None, allow_small=False)
     return out
 
 
-def rec_flips(name, got, ref, tol_l2=3e-3, max_viol=1e-2):
+def rec_flips(name, got, ref, tol_l2=3e-3, tol_max=3e-2):
     """NAMED criterion "relu-flips" for gradients of ReLU / max-pool networks.  Those gradients are discontinuous in the
-    activations: any two implementations whose activations differ in the last bits flip a few masks, which moves individual
-    gradient entries far more than rtol 1e-3 (the CPU oracle in fp32 against itself in fp64: max 4-6e-3 of the peak, L2
-    0.9-1.4e-3 on the CLIP ResNet towers).  Passes when (a) the strict inequality holds for all but `max_viol` of the elements
-    and (b) the relative L2 error is below `tol_l2`.  `err_rel` holds the L2 ratio, `err_abs` the max abs difference; the strict
-    verdict is reported beside it."""
+    activations: any two implementations whose activations differ in the last bits flip a few masks, and every flipped unit
+    moves the gradient over its whole receptive field by far more than rtol 1e-3 (the CPU oracle in fp32 against itself in fp64:
+    max 4-6e-3 of the peak, L2 0.9-1.4e-3 on the CLIP ResNet towers).  Passes when the relative L2 error is below `tol_l2` AND
+    the largest deviation is below `tol_max` of the reference peak.  `err_rel` holds the L2 ratio, `err_abs` the max abs
+    difference; the strict verdict and the fraction of elements that violate it are reported beside it."""
     got = got.detach().double().cpu()
     ref = ref.detach().double().cpu()
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     diff = (got - ref).abs()
     viol = (diff > ATOL + RTOL * ref.abs()).double().mean().item()
     l2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    peak = ref.abs().max().item()
     finite = bool(th.isfinite(got).all().item())
-    return {"name": name + f" [L2 <= {tol_l2:g}, strict on >= {1 - max_viol:.4f} of the elements]", "err_abs": diff.max().item(),
-            "err_rel": l2, "ref_max": ref.abs().max().item(), "ok_strict": finite and viol == 0.0, "criterion": "relu-flips",
+    return {"name": name + f" [L2 <= {tol_l2:g}, max <= {tol_max:g} of the peak]", "err_abs": diff.max().item(), "err_rel": l2,
+            "ref_max": peak, "ok_strict": finite and viol == 0.0, "criterion": "relu-flips",
             "reason": "discontinuous gradient (ReLU / max-pool masks)", "viol_frac": viol,
-            "ok": finite and l2 <= tol_l2 and viol <= max_viol}
+            "ok": finite and l2 <= tol_l2 and diff.max().item() <= tol_max * peak}
 
 
 def unit_seed(grad_ref):
