@@ -29,6 +29,18 @@ def main():
         b = byk[k]
         b[0] += d
         b[1] += 1
+    # idle time charged to the kernel that FOLLOWS the gap (the dependent launch that could not start earlier)
+    gaps = collections.defaultdict(lambda: [0, 0])
+    for a_, b_ in zip(step[:-1], step[1:]):
+        gdur = int(b_["Start_Timestamp"]) - int(a_["End_Timestamp"])
+        if gdur > 0:
+            gk = gaps[short(b_["Kernel_Name"])]
+            gk[0] += gdur
+            gk[1] += 1
+    print(f"idle between kernels {sum(v[0] for v in gaps.values()) / 1e6:.2f} ms")
+    print("-- gap before kernel (top 15)")
+    for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:15]:
+        print(f"{k:<52s}{v[1]:>5d}{v[0] / 1e3:>10.1f} us{v[0] / v[1] / 1e3:>9.2f}")
     print("-- by kernel")
     for k, v in sorted(byk.items(), key=lambda kv: -kv[1][0])[:30]:
         print(f"{k:<52s}{v[1]:>5d}{v[0] / 1e3:>10.1f} us{v[0] / v[1] / 1e3:>9.1f}")

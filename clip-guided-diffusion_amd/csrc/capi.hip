@@ -35,6 +35,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
       return -4;
     }
   }
+  if (const char* e = getenv("CGD_DEFER")) ctx->defer_mode = atoi(e);  // tuning knob (A/B runs)
   ctx->ws_bytes = (size_t)256 << 20;
   if (hipMalloc((void**)&ctx->ws, ctx->ws_bytes) != hipSuccess) {
     delete ctx;

@@ -24,6 +24,27 @@ struct ProfRec {
   bool live = false;
 };
 
+// A tensor whose value still lies in split-K slices of the shared workspace:
+//   v[m][n] = alpha * sum_k ws[k * stride + m * N + n] (+ bias[n]) (+ R[m * ldr + n]).
+// Instead of a separate reduce kernel, the NEXT kernel on the stream that reads the tensor sums the slices in its first sweep
+// (GroupNorm statistics / small-map GroupNorm / LayerNorm kernels), writes the finished tensor where later kernels expect it
+// and carries on: one launch and one read+write pass of the tensor less per split-K contraction.
+struct SplitSrc {
+  const float* ws = nullptr;
+  const float* bias = nullptr;
+  const float* R = nullptr;
+  long stride = 0;
+  int n = 0;  // number of slices; 0 = plain tensor
+  int N = 0, ldr = 0;
+  float alpha = 1.f;
+};
+struct PendingReduce {  // a deferred reduction (GemmParams::defer) that has not been consumed yet
+  bool valid = false;
+  SplitSrc src;
+  float* C = nullptr;
+  int ldc = 0, M = 0;
+};
+
 struct FragEntry {  // fragment-order copy of a persistent weight (hgemm.hip)
   const float* w;
   int N, K, ldw;
@@ -45,6 +66,9 @@ struct cgd_ctx {
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   int hgemm_mode = 1, hgemm_min_m = 512, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
                                                                 // igemm's finer tiles win), chunks per split-K slice
+  PendingReduce pending;                                       // see SplitSrc
+  int defer_mode = 1;  // deferred split-K reductions: 0 never, 1 when the consumer is a many-workgroup kernel (GroupNorm on > 32x32
+                       // maps), 2 also for the single-launch small-map GroupNorm (32 workgroups: slower, kept for A/B runs)
   std::vector<FragEntry> frag_cache;                           // packed weights, keyed by pointer; cleared by finalize / set_param / destroy
   void* frag_tmp = nullptr;                                    // packed copy of a non-persistent B operand (forced hgemm, tests)
   size_t frag_tmp_bytes = 0;
@@ -133,7 +157,13 @@ struct GemmParams {
   int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel
   int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
+  int defer = 0;       // 1: if the launch splits K, leave the slices in the workspace (ctx->pending): the caller guarantees that the
+                       // next kernel reading C is one that consumes a SplitSrc (cgd_take_pending); anything else flushes first
 };
+
+// deferred split-K reductions: run the reduce kernel for a pending one (no-op otherwise) / hand it to a consumer of tensor `x`
+int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s);
+bool cgd_take_pending(cgd_ctx* ctx, const float* x, long rows, int cols, SplitSrc* out);
 
 // ---- halo-staged conv (hconv.hip) ---------------------------------------------------------------------
 size_t cgd_hconv_packed_floats(int Co, int Ci);
@@ -153,6 +183,6 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s);
 
 // thin direct convs for the 3-channel ends of the UNet
 int cgd_launch_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w /*[Cout][3][3][Cin] (co,ky,kx,ci)*/, const float* bias,
-                       float* y_nhwc, int Bn, int H, int W, int Cin, int Cout, hipStream_t s);
+                       float* y_nhwc, int Bn, int H, int W, int Cin, int Cout, hipStream_t s, int ldy = 0 /*row stride, 0 = Cout*/);
 int cgd_launch_conv_thin_out(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w /*[Cout][9*Cin]*/, const float* bias,
                              float* y_nchw, int Bn, int H, int W, int Cin, int Cout, hipStream_t s);

@@ -8,7 +8,7 @@ namespace {
 // conv_in: NCHW input with CIN <= 8 channels -> NHWC output, weights [Cout][ky][kx][CIN].
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, float* __restrict__ y, int Bn, int H,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int ldy, int Bn, int H,
                                                       int W, int Cout, int pix_per_block) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];  // [9*CIN][Cout]
   const int KK = 9 * CIN;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
         }
       }
     }
-    *(float4*)(y + pix * Cout + q * 4) = acc;
+    *(float4*)(y + pix * ldy + q * 4) = acc;
   }
 }
 
@@ -179,11 +179,13 @@ __global__ __launch_bounds__(256) void thin_gather_kernel(const float* __restric
 }  // namespace
 
 int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int Bn, int H, int W, int Cin,
-                       int Cout, hipStream_t s) {
+                       int Cout, hipStream_t s, int ldy) {
+  if (ldy <= 0) ldy = Cout;
   if (Cout % 4 || Cout / 4 > 256) CGD_FAIL(ctx, "conv_in: Cout must be a multiple of 4 and <= 1024");
   const int ppb = 64;
   const long npix = (long)Bn * H * W;
   if (Cin != 3 && Cin != 6) CGD_FAIL(ctx, "conv_in: Cin must be 3 or 6");
+  CGD_TRY(cgd_flush_pending(ctx, s));  // the im2col scratch below lives in the split-K workspace
   {
     // MFMA route: scratch (im2col + padded weights) lives in the split-K workspace, so the GEMM must not split
     const int KP = Cin == 3 ? 32 : 64;
@@ -200,7 +202,7 @@ int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float
       GemmParams g;
       g.A = a; g.lda = KP;
       g.B = wp; g.ldb = KP;
-      g.C = y; g.ldc = Cout;
+      g.C = y; g.ldc = ldy;
       g.bias = bias;
       g.M = (int)npix; g.N = Cout; g.K = KP;
       g.no_split = 1;
@@ -212,9 +214,9 @@ int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float
   const size_t sh = (size_t)9 * Cin * Cout * sizeof(float);
   dim3 grid(cdiv(npix, ppb));
   if (Cin == 3)
-    hipLaunchKernelGGL((conv_in_kernel<3>), grid, dim3(256), sh, s, x, w, bias, y, Bn, H, W, Cout, ppb);
+    hipLaunchKernelGGL((conv_in_kernel<3>), grid, dim3(256), sh, s, x, w, bias, y, ldy, Bn, H, W, Cout, ppb);
   else if (Cin == 6)
-    hipLaunchKernelGGL((conv_in_kernel<6>), grid, dim3(256), sh, s, x, w, bias, y, Bn, H, W, Cout, ppb);
+    hipLaunchKernelGGL((conv_in_kernel<6>), grid, dim3(256), sh, s, x, w, bias, y, ldy, Bn, H, W, Cout, ppb);
   else
     CGD_FAIL(ctx, "conv_in: Cin must be 3 or 6");
   CGD_HIP(ctx, hipGetLastError());
@@ -226,6 +228,7 @@ int cgd_launch_conv_thin_out(cgd_ctx* ctx, const float* x, int ldx, const float*
   const int ppb = 64;
   const long npix = (long)Bn * H * W;
   if (Cout != 3 && Cout != 6) CGD_FAIL(ctx, "conv_thin_out: Cout must be 3 or 6");
+  CGD_TRY(cgd_flush_pending(ctx, s));  // the per-tap scratch below lives in the split-K workspace
   if (!(Cin & 3) && !(ldx & 3) && !((uintptr_t)x & 15)) {
     const int NP = Cout == 3 ? 32 : 64;
     const size_t t_floats = (size_t)npix * NP, w_floats = (size_t)NP * Cin;

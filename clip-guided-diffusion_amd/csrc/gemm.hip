@@ -478,8 +478,29 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   return 0;
 }
 
+int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s) {
+  if (!ctx->pending.valid) return 0;
+  const PendingReduce& q = ctx->pending;
+  const long total = (long)q.M * q.src.N;
+  const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, q.src.ws, q.src.n, q.M, q.src.N, q.C, q.ldc, q.src.bias,
+                     q.src.R, q.src.ldr, q.src.alpha);
+  ctx->pending.valid = false;
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+bool cgd_take_pending(cgd_ctx* ctx, const float* x, long rows, int cols, SplitSrc* out) {
+  PendingReduce& q = ctx->pending;
+  if (!q.valid || q.C != x || q.M != rows || q.src.N != cols) return false;
+  *out = q.src;
+  q.valid = false;
+  return true;
+}
+
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return 0;
+  CGD_TRY(cgd_flush_pending(ctx, s));  // a deferred reduction nobody consumed: its slices are about to be overwritten
   int tile = 0, kernel = 0;
   CGD_TRY(cgd_plan_gemm(ctx, p, &tile, &kernel));
   const bool use_h = kernel == 1, use_g = kernel == 2;
@@ -499,10 +520,12 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     }
   }
   if (p.splitk > 1) {
-    const long total = (long)p.M * p.N;
-    const int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.ws, p.splitk, p.M, p.N, p.C, p.ldc, p.bias, p.R,
-                       p.ldr, p.alpha);
+    PendingReduce& q = ctx->pending;
+    q.valid = true;
+    q.src.ws = p.ws; q.src.bias = p.bias; q.src.R = p.R; q.src.stride = (long)p.M * p.N; q.src.n = p.splitk; q.src.N = p.N;
+    q.src.ldr = p.ldr; q.src.alpha = p.alpha;
+    q.C = p.C; q.ldc = p.ldc; q.M = p.M;
+    if (!(p.defer && ctx->defer_mode)) CGD_TRY(cgd_flush_pending(ctx, s));
   }
   if (!use_h) CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
   cgd_prof_push(ctx, &pr);

@@ -9,9 +9,11 @@ size_t cgd_gn_scratch_floats(int B, int HW, int C);
 // `scratch` (cgd_gn_scratch_floats) keeps the statistics and folded coefficients for the backward pass.
 int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma,
                       const float* beta, const float* film, int ldfilm, int act, float eps, float* scratch, hipStream_t s);
-// dx = dGN/dx (dz) (+ add);  needs the forward's scratch.
+// dx = dGN/dx (dz) (+ add) (+ add2);  needs the forward's scratch.  add / add2: residual-path and skip-connection gradients
+// that meet at this tensor (both optional, own row strides).
 int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add,
-                      int ldadd, int B, int HW, int C, int act, float* scratch, hipStream_t s);
+                      int ldadd, int B, int HW, int C, int act, float* scratch, hipStream_t s, const float* add2 = nullptr,
+                      int ldadd2 = 0);
 int cgd_launch_ln_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int rows, int C, const float* gamma,
                       const float* beta, float eps, float* stats, hipStream_t s);
 int cgd_launch_ln_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, const float* add,

@@ -32,9 +32,39 @@ __device__ __forceinline__ float dsilu_f(float u) {
   return s * (1.f + u * (1.f - s));
 }
 
+// ---- tensors that still lie in split-K slices (common.h SplitSrc): summed in the same order as splitk_reduce_kernel ----------
+__device__ __forceinline__ float4 split_load4(const SplitSrc& s, long row, int col) {
+  const float* p = s.ws + row * s.N + col;
+  float4 a = *(const float4*)p;
+  for (int k = 1; k < s.n; ++k) {
+    const float4 v = *(const float4*)(p + (long)k * s.stride);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  a.x *= s.alpha; a.y *= s.alpha; a.z *= s.alpha; a.w *= s.alpha;
+  if (s.bias) {
+    const float4 bv = *(const float4*)(s.bias + col);
+    a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+  }
+  if (s.R) {
+    const float4 rv = *(const float4*)(s.R + row * s.ldr + col);
+    a.x += rv.x; a.y += rv.y; a.z += rv.z; a.w += rv.w;
+  }
+  return a;
+}
+__device__ __forceinline__ float split_load1(const SplitSrc& s, long row, int col) {
+  const float* p = s.ws + row * s.N + col;
+  float a = *p;
+  for (int k = 1; k < s.n; ++k) a += p[(long)k * s.stride];
+  a *= s.alpha;
+  if (s.bias) a += s.bias[col];
+  if (s.R) a += s.R[row * s.ldr + col];
+  return a;
+}
+
 // ---- forward statistics: per (b, chunk, group) -> (mean, M2) ------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __restrict__ x, int ldx, int HW, int C, int chunk,
-                                                               float* __restrict__ part /*[B][nchunk][32][2]*/) {
+// `src.n > 0`: x still lies in split-K slices; this sweep sums them and writes the finished tensor to x (xw) as it goes
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* x, float* xw, int ldx, int HW, int C, int chunk,
+                                                               float* __restrict__ part /*[B][nchunk][32][2]*/, const SplitSrc src) {
   __shared__ float lds_s[1024 * 4], lds_ss[1024 * 4], lds_k[1024 * 4];  // up to 4096 channels
   __shared__ float red_s[256 * 4], red_ss[256 * 4];
   const ColMap m = col_map(C);
@@ -46,7 +76,16 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __re
   for (int j = 0; j < MAXJ; ++j) {
     const int q = m.q0 + j * m.TQ;
     if (q >= m.cq) break;
-    float4 k4 = *(const float4*)(xb + (long)p0 * ldx + q * 4);
+    // shift for the sums: any value common to the threads of a column works.  From the slices WITHOUT the residual: R may alias
+    // the output (skip-conv result accumulated in place) and is overwritten by whichever thread finishes that element first
+    float4 k4;
+    if (src.n) {
+      SplitSrc s0 = src;
+      s0.R = nullptr;
+      k4 = split_load4(s0, (long)b * HW + p0, q * 4);
+    } else {
+      k4 = *(const float4*)(xb + (long)p0 * ldx + q * 4);
+    }
     float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
     if (m.active) {
       // 4 independent loads in flight per thread: these kernels are latency-, not bandwidth-limited per wavefront
@@ -54,8 +93,13 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __re
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int p = pb + u * m.rows;
-          v[u] = *(const float4*)(xb + (long)(p < p1 ? p : pb) * ldx + q * 4);
+          const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
+          if (src.n) {
+            v[u] = split_load4(src, (long)b * HW + pc, q * 4);
+            if (p < p1) *(float4*)(xw + ((long)b * HW + pc) * ldx + q * 4) = v[u];
+          } else {
+            v[u] = *(const float4*)(xb + (long)pc * ldx + q * 4);
+          }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -216,10 +260,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 
 // ---- backward ------------------------------------------------------------------------------------------------
 // du = dz * act'(u), u = x*a+b.  per (b, chunk, group): P1 = sum_c gcoef_c * sum du ; P2 = sum_c gcoef_c * sum du*(x-mean)
+// `src.n > 0`: dz still lies in split-K slices; summed here and written to dz (dzw) for the apply pass
 template <int ACT>
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz,
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, int ldx, const float* dz, float* dzw,
                                                              int lddz, int HW, int C, int chunk, const float* __restrict__ coef,
-                                                             float* __restrict__ part /*[B][nchunk][32][2]*/) {
+                                                             float* __restrict__ part /*[B][nchunk][32][2]*/, const SplitSrc src) {
   __shared__ float lds_1[1024 * 4], lds_2[1024 * 4];
   __shared__ float red_1[256 * 4], red_2[256 * 4];
   const ColMap m = col_map(C);
@@ -241,7 +286,12 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
        for (int u = 0; u < 4; ++u) {
          const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
          vv[u] = *(const float4*)(xb + (long)pc * ldx + q * 4);
-         dd[u] = *(const float4*)(db + (long)pc * lddz + q * 4);
+         if (src.n) {
+           dd[u] = split_load4(src, (long)b * HW + pc, q * 4);
+           if (p < p1) *(float4*)(dzw + ((long)b * HW + pc) * lddz + q * 4) = dd[u];
+         } else {
+           dd[u] = *(const float4*)(db + (long)pc * lddz + q * 4);
+         }
        }
 #pragma unroll
        for (int u = 0; u < 4; ++u) {
@@ -326,8 +376,8 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_kernel(const float* __restric
 template <int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz,
                                                            int lddz, float* __restrict__ dx, int lddx, const float* __restrict__ add,
-                                                           int ldadd, int HW, int C, int chunk, const float* __restrict__ coef,
-                                                           const float* __restrict__ bcoef) {
+                                                           int ldadd, const float* __restrict__ add2, int ldadd2, int HW, int C, int chunk,
+                                                           const float* __restrict__ coef, const float* __restrict__ bcoef) {
   const ColMap m = col_map(C);
   if (!m.active) return;
   const int b = blockIdx.y;
@@ -336,6 +386,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const float* db = dz + ((long)b * HW) * lddz;
   float* ob = dx + ((long)b * HW) * lddx;
   const float* ab = add ? add + ((long)b * HW) * ldadd : nullptr;
+  const float* ab2 = add2 ? add2 + ((long)b * HW) * ldadd2 : nullptr;
   for (int j = 0; j < MAXJ; ++j) {
     const int q = m.q0 + j * m.TQ;
     if (q >= m.cq) break;
@@ -351,6 +402,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
        vv[u] = *(const float4*)(xb + (long)pc * ldx + q * 4);
        dd[u] = *(const float4*)(db + (long)pc * lddz + q * 4);
        if (ab) aa[u] = *(const float4*)(ab + (long)pc * ldadd + q * 4);
+       if (ab2) {
+         const float4 a2 = *(const float4*)(ab2 + (long)pc * ldadd2 + q * 4);
+         if (ab) { aa[u].x += a2.x; aa[u].y += a2.y; aa[u].z += a2.z; aa[u].w += a2.w; } else aa[u] = a2;
+       }
      }
 #pragma unroll
      for (int u = 0; u < 4; ++u) {
@@ -369,7 +424,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       o.y = d.y * b1.x - (v.y - c1.w) * b1.y - b1.z;
       o.z = d.z * b2.x - (v.z - c2.w) * b2.y - b2.z;
       o.w = d.w * b3.x - (v.w - c3.w) * b3.y - b3.z;
-      if (ab) {
+      if (ab || ab2) {
         const float4 a = aa[u];
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
       }
@@ -563,12 +618,23 @@ __device__ __forceinline__ void vset(typename VecT<VEC>::T& v, int i, float x) {
   if constexpr (VEC == 1) v = x; else v[i] = x;
 }
 
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::T split_load(const SplitSrc& s, long row, int col) {
+  if constexpr (VEC == 1) {
+    return split_load1(s, row, col);
+  } else {
+    const float4 a = split_load4(s, row, col);
+    return typename VecT<4>::T{a.x, a.y, a.z, a.w};
+  }
+}
+
 // CACHE: the group slab fits the block's registers (<= 8 vectors per thread): x is read ONCE, all loads are issued up front
+// `src.n > 0`: x still lies in split-K slices: summed at load time and written to x (xw) for the later consumers
 template <int ACT, int VEC, bool CACHE>
-__global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int HW,
+__global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* x, float* xw, int ldx, float* __restrict__ y, int ldy, int HW,
                                                              int C, int lg, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ film, int ldfilm, float eps,
-                                                             float* __restrict__ stats, float* __restrict__ coef) {
+                                                             float* __restrict__ stats, float* __restrict__ coef, const SplitSrc src) {
   typedef typename VecT<VEC>::T V;
   __shared__ float red[GS_NT / 64];
   __shared__ float ca[128], cb[128];
@@ -576,15 +642,32 @@ __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __rest
   const int q = threadIdx.x & ((1 << lg) - 1), r = threadIdx.x >> lg, rows = GS_NT >> lg;
   const bool act_q = q < cq;
   const float* xg = x + (long)b * HW * ldx + g * cpg + q * VEC;
+  float* xwg = xw + (long)b * HW * ldx + g * cpg + q * VEC;
   float* yg = y + (long)b * HW * ldy + g * cpg + q * VEC;
-  const float k0 = x[(long)b * HW * ldx + g * cpg];
+  const long row0 = (long)b * HW;
+  const int col = g * cpg + q * VEC;
+  float k0;  // shift for the sums, common to the workgroup (see gn_stats_partial_kernel: never through the aliasable residual)
+  if (src.n) {
+    SplitSrc s0 = src;
+    s0.R = nullptr;
+    k0 = split_load1(s0, row0, g * cpg);
+  } else {
+    k0 = x[(long)b * HW * ldx + g * cpg];
+  }
   float s = 0.f, ss = 0.f;
   V vc[CACHE ? 8 : 1];
   if constexpr (CACHE) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int p = r + it * rows;
-      if (act_q && p < HW) vc[it] = *(const V*)(xg + (long)p * ldx);
+      if (act_q && p < HW) {
+        if (src.n) {
+          vc[it] = split_load<VEC>(src, row0 + p, col);
+          *(V*)(xwg + (long)p * ldx) = vc[it];
+        } else {
+          vc[it] = *(const V*)(xg + (long)p * ldx);
+        }
+      }
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -602,8 +685,13 @@ __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __rest
       V v[GS_U];
 #pragma unroll
       for (int u = 0; u < GS_U; ++u) {
-        const int p = p0 + u * rows;
-        v[u] = *(const V*)(xg + (long)(p < HW ? p : r) * ldx);
+        const int p = p0 + u * rows, pc = p < HW ? p : r;
+        if (src.n) {
+          v[u] = split_load<VEC>(src, row0 + pc, col);
+          if (p < HW) *(V*)(xwg + (long)pc * ldx) = v[u];  // the apply loop below re-reads what this thread wrote
+        } else {
+          v[u] = *(const V*)(xg + (long)pc * ldx);
+        }
       }
 #pragma unroll
       for (int u = 0; u < GS_U; ++u) {
@@ -691,9 +779,10 @@ __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* __rest
 }
 
 template <int ACT, int VEC, bool CACHE>
-__global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int lddz,
-                                                             float* dx, int lddx, const float* add, int ldadd, int HW, int C, int lg,
-                                                             const float* __restrict__ stats, const float* __restrict__ coef) {
+__global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __restrict__ x, int ldx, const float* dz, float* dzw, int lddz,
+                                                             float* dx, int lddx, const float* add, int ldadd, const float* add2, int ldadd2,
+                                                             int HW, int C, int lg, const float* __restrict__ stats,
+                                                             const float* __restrict__ coef, const SplitSrc src) {
   typedef typename VecT<VEC>::T V;
   __shared__ float red[GS_NT / 64];
   const int g = blockIdx.x, b = blockIdx.y, cpg = C / 32, cq = cpg / VEC, n = HW * cpg;
@@ -702,8 +791,12 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
   const int qc = act_q ? q : 0;
   const float* xg = x + (long)b * HW * ldx + g * cpg + qc * VEC;
   const float* dg = dz + (long)b * HW * lddz + g * cpg + qc * VEC;
+  float* dwg = dzw + (long)b * HW * lddz + g * cpg + qc * VEC;
+  const long row0 = (long)b * HW;
+  const int col = g * cpg + qc * VEC;
   float* og = dx + (long)b * HW * lddx + g * cpg + qc * VEC;
   const float* ag = add ? add + (long)b * HW * ldadd + g * cpg + qc * VEC : nullptr;
+  const float* ag2 = add2 ? add2 + (long)b * HW * ldadd2 + g * cpg + qc * VEC : nullptr;
   const float mean = stats[((long)b * 32 + g) * 2], rstd = stats[((long)b * 32 + g) * 2 + 1];
   float a[VEC], bb[VEC], gc[VEC];
 #pragma unroll
@@ -721,7 +814,7 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
       const int p = r + it * rows;
       if (act_q && p < HW) {
         xc[it] = *(const V*)(xg + (long)p * ldx);
-        dc[it] = *(const V*)(dg + (long)p * lddz);
+        dc[it] = src.n ? split_load<VEC>(src, row0 + p, col) : *(const V*)(dg + (long)p * lddz);  // register-resident: never written
       }
     }
 #pragma unroll
@@ -747,7 +840,12 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
       for (int u = 0; u < GS_U; ++u) {
         const int p = p0 + u * rows, pc = p < HW ? p : r;
         xv[u] = *(const V*)(xg + (long)pc * ldx);
-        dv[u] = *(const V*)(dg + (long)pc * lddz);
+        if (src.n) {
+          dv[u] = split_load<VEC>(src, row0 + pc, col);
+          if (p < HW) *(V*)(dwg + (long)pc * lddz) = dv[u];  // the second loop re-reads what this thread wrote
+        } else {
+          dv[u] = *(const V*)(dg + (long)pc * lddz);
+        }
       }
 #pragma unroll
       for (int u = 0; u < GS_U; ++u) {
@@ -775,6 +873,10 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
     for (int it = 0; it < 4; ++it) {
       const int p = r + it * rows;
       if (ag && p < HW) av[it] = *(const V*)(ag + (long)p * ldadd);
+      if (ag2 && p < HW) {
+        const V a2 = *(const V*)(ag2 + (long)p * ldadd2);
+        if (ag) av[it] += a2; else av[it] = a2;
+      }
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -784,7 +886,7 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           float t = vget<VEC>(dc[it], e) * rstd - (vget<VEC>(xc[it], e) - mean) * a2 - a3;
-          if (ag) t += vget<VEC>(av[it], e);
+          if (ag || ag2) t += vget<VEC>(av[it], e);
           vset<VEC>(o, e, t);
         }
         *(V*)(og + (long)p * lddx) = o;
@@ -800,6 +902,10 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
       xv[u] = *(const V*)(xg + (long)pc * ldx);
       dv[u] = *(const V*)(dg + (long)pc * lddz);
       if (ag) av[u] = *(const V*)(ag + (long)pc * ldadd);
+      if (ag2) {
+        const V a2 = *(const V*)(ag2 + (long)pc * ldadd2);
+        if (ag) av[u] += a2; else av[u] = a2;
+      }
     }
 #pragma unroll
     for (int u = 0; u < GS_U; ++u) {
@@ -812,7 +918,7 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
           float du = vget<VEC>(dv[u], e);
           if (ACT == 1) du *= dsilu_f(xe * a[e] + bb[e]);
           float t = du * gc[e] * rstd - (xe - mean) * a2 - a3;
-          if (ag) t += vget<VEC>(av[u], e);
+          if (ag || ag2) t += vget<VEC>(av[u], e);
           vset<VEC>(o, e, t);
         }
         *(V*)(og + (long)p * lddx) = o;
@@ -823,14 +929,14 @@ __global__ __launch_bounds__(GS_NT) void gn_small_bwd_kernel(const float* __rest
 
 template <int ACT>
 void launch_gn_small_fwd(const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma, const float* beta,
-                         const float* film, int ldfilm, float eps, float* stats, float* coef, hipStream_t s) {
+                         const float* film, int ldfilm, float eps, float* stats, float* coef, hipStream_t s, const SplitSrc& src) {
   const int cpg = C / 32;
-  const bool v4 = !(cpg & 3) && !(ldx & 3) && !(ldy & 3);
+  const bool v4 = !(cpg & 3) && !(ldx & 3) && !(ldy & 3) && !(src.n && ((src.N | src.ldr) & 3));
   const int cq = v4 ? cpg / 4 : cpg;
   int lg = 0;
   while ((1 << lg) < cq) ++lg;
   const bool cache = (long)HW <= 8L * (GS_NT >> lg) && !getenv("CGD_GN_NOCACHE");  // <= 8 vectors per thread: single read
-#define GN_SF(V_, C_) hipLaunchKernelGGL((gn_small_fwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps, stats, coef)
+#define GN_SF(V_, C_) hipLaunchKernelGGL((gn_small_fwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, (float*)x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps, stats, coef, src)
   if (v4) {
     if (cache) GN_SF(4, true); else GN_SF(4, false);
   } else {
@@ -840,15 +946,16 @@ void launch_gn_small_fwd(const float* x, int ldx, float* y, int ldy, int B, int 
 }
 
 template <int ACT>
-void launch_gn_small_bwd(const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add, int ldadd, int B, int HW,
-                         int C, const float* stats, const float* coef, hipStream_t s) {
+void launch_gn_small_bwd(const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add, int ldadd,
+                         const float* add2, int ldadd2, int B, int HW, int C, const float* stats, const float* coef, hipStream_t s,
+                         const SplitSrc& src) {
   const int cpg = C / 32;
-  const bool v4 = !(cpg & 3) && !(ldx & 3) && !(lddz & 3) && !(lddx & 3) && !(ldadd & 3);
+  const bool v4 = !(cpg & 3) && !(ldx & 3) && !(lddz & 3) && !(lddx & 3) && !(ldadd & 3) && !(ldadd2 & 3) && !(src.n && ((src.N | src.ldr) & 3));
   const int cq = v4 ? cpg / 4 : cpg;
   int lg = 0;
   while ((1 << lg) < cq) ++lg;
   const bool cache = (long)HW <= 4L * (GS_NT >> lg) && !getenv("CGD_GN_NOCACHE");  // <= 4 vectors of x and of dz per thread
-#define GN_SB(V_, C_) hipLaunchKernelGGL((gn_small_bwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C, lg, stats, coef)
+#define GN_SB(V_, C_) hipLaunchKernelGGL((gn_small_bwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, (float*)dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, HW, C, lg, stats, coef, src)
   if (v4) {
     if (cache) GN_SB(4, true); else GN_SB(4, false);
   } else {
@@ -904,19 +1011,28 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  // x may still lie in split-K slices (a deferred reduction of the conv that produced it): this op's first sweep sums them
+  SplitSrc src;
+  if (!((HW > GN_SMALL_HW || ctx->defer_mode >= 2) && cgd_take_pending(ctx, x, (long)B * HW, C, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
+  if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.ws & 15) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15)) && HW > GN_SMALL_HW) {
+    // the large path reads float4 only: finish the reduction the plain way
+    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)x; ctx->pending.ldc = ldx; ctx->pending.M = B * HW;
+    CGD_TRY(cgd_flush_pending(ctx, s));
+    src = SplitSrc();
+  }
   ProfRec pr;  // algorithmic HBM bytes of a GroupNorm forward: one read of x, one write of y
   CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, 8.0 * B * HW * C, s));
   if (HW <= GN_SMALL_HW) {
     if (act)
-      launch_gn_small_fwd<1>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s);
+      launch_gn_small_fwd<1>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s, src);
     else
-      launch_gn_small_fwd<0>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s);
+      launch_gn_small_fwd<0>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s, src);
     CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
     cgd_prof_push(ctx, &pr);
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ldx, HW, C, chunk, part);
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, (float*)x, ldx, HW, C, chunk, part, src);
   hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats, gamma, beta, film,
                      ldfilm, coef);
   if (act)
@@ -930,34 +1046,41 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
 }
 
 int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add,
-                      int ldadd, int B, int HW, int C, int act, float* scratch, hipStream_t s) {
+                      int ldadd, int B, int HW, int C, int act, float* scratch, hipStream_t s, const float* add2, int ldadd2) {
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  SplitSrc src;  // dz may still lie in split-K slices (the dgrad conv that produced it deferred its reduction)
+  if (!((HW > GN_SMALL_HW || ctx->defer_mode >= 2) && cgd_take_pending(ctx, dz, (long)B * HW, C, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
+  if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.ws & 15) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15)) && HW > GN_SMALL_HW) {
+    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)dz; ctx->pending.ldc = lddz; ctx->pending.M = B * HW;
+    CGD_TRY(cgd_flush_pending(ctx, s));
+    src = SplitSrc();
+  }
   ProfRec pr;  // algorithmic HBM bytes of a GroupNorm backward: read x and dz (and the residual gradient `add`), write dx
-  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (add ? 16.0 : 12.0) * B * HW * C, s));
+  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (12.0 + (add ? 4.0 : 0.0) + (add2 ? 4.0 : 0.0)) * B * HW * C, s));
   if (HW <= GN_SMALL_HW) {
     if (act)
-      launch_gn_small_bwd<1>(x, ldx, dz, lddz, dx, lddx, add, ldadd, B, HW, C, stats, coef, s);
+      launch_gn_small_bwd<1>(x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, B, HW, C, stats, coef, s, src);
     else
-      launch_gn_small_bwd<0>(x, ldx, dz, lddz, dx, lddx, add, ldadd, B, HW, C, stats, coef, s);
+      launch_gn_small_bwd<0>(x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, B, HW, C, stats, coef, s, src);
     CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
     cgd_prof_push(ctx, &pr);
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
   if (act) {
-    hipLaunchKernelGGL((gn_bwd_partial_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, HW, C, chunk, coef, part);
+    hipLaunchKernelGGL((gn_bwd_partial_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
   } else {
-    hipLaunchKernelGGL((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, HW, C, chunk, coef, part);
+    hipLaunchKernelGGL((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
   }
   hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
   if (act) {
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C,
-                       chunk, coef, bcoef);
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
+                       HW, C, chunk, coef, bcoef);
   } else {
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, HW, C,
-                       chunk, coef, bcoef);
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
+                       HW, C, chunk, coef, bcoef);
   }
   CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
   cgd_prof_push(ctx, &pr);

@@ -47,6 +47,10 @@ namespace {
 struct UNet;
 
 struct Module {
+  // Optional output target: when set (p != null) the module writes its result there (row stride dst.ld) instead of into a
+  // buffer of its own.  The UNet points the producers of every skip-concat input at their channel slice of the concat buffer,
+  // so torch.cat([h, skip]) costs no copy (36 concat / split copies per step before).
+  TV dst;
   virtual ~Module() {}
   virtual int fwd(UNet& u, TV x, int B, int& H, int& W, TV* out, hipStream_t s) = 0;
   virtual int bwd(UNet& u, TV dout, TV* din, hipStream_t s) = 0;
@@ -64,6 +68,7 @@ struct ResBlock : Module {
   // runtime
   int B = 0, H = 0, W = 0, Ho = 0, Wo = 0;
   TV x;
+  TV add_skip;  // backward: gradient of the skip connection that consumed this block's INPUT (the split half of a later concat)
   DevBuf h1, h1p, xr, h2, h3, out, s1, s2;
   DevBuf d3, d2, d1, d1f, dx;
   int fwd(UNet& u, TV x, int B, int& H, int& W, TV* out, hipStream_t s) override;
@@ -89,6 +94,7 @@ struct UNet : NetBase {
   std::vector<std::unique_ptr<Module>> mid;
   std::vector<std::vector<std::unique_ptr<Module>>> out_blocks;
   std::vector<int> in_chans;  // channels of every hs entry
+  std::vector<int> in_ds;     // downsampling factor of every hs entry
   std::vector<ResBlock*> resblocks;
   // packed stem / head weights
   float *stem_wf = 0, *stem_wd = 0, *head_wf = 0, *head_wd = 0;
@@ -124,7 +130,9 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   CGD_TRY(u.ensure(h1, npi * cin));
   CGD_TRY(u.ensure(h2, npo * cout));
   CGD_TRY(u.ensure(h3, npo * cout));
-  CGD_TRY(u.ensure(out, npo * cout));
+  if (!dst.p) CGD_TRY(u.ensure(out, npo * cout));
+  float* const outp = dst.p ? dst.p : out.p;
+  const int ldo = dst.p ? dst.ld : cout;
   // in_layers: GN -> SiLU
   CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, h1.p, cin, B, H * W, cin, g1, b1, nullptr, 0, 1, 1e-5f, s1.p, s));
   const float* conv_in = h1.p;
@@ -148,6 +156,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   GemmParams c1;
   c1.A = conv_in; c1.lda = cin; c1.B = cw1f; c1.Bpk = cw1fp; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
   c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
+  c1.defer = 1;  // a split-K launch leaves its slices for the GroupNorm right below (SplitSrc)
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
   // out_layers: GN * (1+scale) + shift -> SiLU -> conv2 (+ skip)
   CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, h3.p, cout, B, Ho * Wo, cout, g2, b2, u.emb_all.p + emb_off, (int)u.emb_total, 1, 1e-5f,
@@ -156,19 +165,20 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   int ldr = skip_ld;
   if (skip_conv) {
     GemmParams sk;
-    sk.A = skip_src; sk.lda = skip_ld; sk.B = skw; sk.ldb = cin; sk.C = out.p; sk.ldc = cout; sk.bias = skb;
+    sk.A = skip_src; sk.lda = skip_ld; sk.B = skw; sk.ldb = cin; sk.C = outp; sk.ldc = ldo; sk.bias = skb;
     sk.M = (int)npo; sk.N = cout; sk.K = cin;
     sk.weight = 1;
-  CGD_TRY(cgd_launch_gemm(ctx, sk, s));
-    R = out.p;
-    ldr = cout;
+    CGD_TRY(cgd_launch_gemm(ctx, sk, s));
+    R = outp;
+    ldr = ldo;
   }
   GemmParams c2;
-  c2.A = h3.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.ldb = 9 * cout; c2.C = out.p; c2.ldc = cout; c2.bias = cb2; c2.R = R; c2.ldr = ldr;
+  c2.A = h3.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2; c2.R = R; c2.ldr = ldr;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
+  c2.defer = 1;  // the next module starts with a GroupNorm of this tensor (or the launcher flushes: concat inputs, the head)
   CGD_TRY(cgd_launch_gemm(ctx, c2, s));
   Hh = Ho; Ww = Wo;
-  *o = TV{out.p, cout, cout};
+  *o = TV{outp, ldo, cout};
   return 0;
 }
 
@@ -179,34 +189,23 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   CGD_TRY(u.ensure(d2, npo * cout));
   CGD_TRY(u.ensure(d1, npo * cin));
   CGD_TRY(u.ensure(dx, npi * cin));
-  // conv2 dgrad
+  // conv2 dgrad (a split-K launch leaves its slices for the GroupNorm backward right below)
   GemmParams c2;
   c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
+  c2.defer = 1;
   CGD_TRY(cgd_launch_gemm(ctx, c2, s));
   // GN2 + FiLM + SiLU backward
   CGD_TRY(cgd_launch_gn_bwd(ctx, h2.p, cout, d3.p, cout, d2.p, cout, nullptr, 0, B, Ho * Wo, cout, 1, s2.p, s));
-  // conv1 dgrad (at the conv's own resolution)
-  GemmParams c1;
-  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
-  c1.M = (int)npo; c1.N = cin; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cout;
-  CGD_TRY(cgd_launch_gemm(ctx, c1, s));
-  // skip path first into dx, then GN1 backward accumulates on top
-  const float* dh1 = d1.p;
+  // skip path into dx first (GN1's backward accumulates on top of it further down)
   const float* add = nullptr;
   int ldadd = 0;
   if (down) {
-    // h_upd = x_upd = AvgPool2d(2): adjoint = nearest upsample * 0.25
-    CGD_TRY(u.ensure(d1f, npi * cin));
-    CGD_TRY(cgd_launch_upsample2x(ctx, d1.p, cin, d1f.p, cin, nullptr, 0, B, H, W, cin, 0.25f, s));
-    dh1 = d1f.p;
+    // x_upd = AvgPool2d(2): adjoint = nearest upsample * 0.25
     CGD_TRY(cgd_launch_upsample2x(ctx, dout.p, dout.ld, dx.p, cin, nullptr, 0, B, H, W, cin, 0.25f, s));  // identity skip
     add = dx.p; ldadd = cin;
   } else if (up) {
     // nearest upsample adjoint = 2x2 sum
-    CGD_TRY(u.ensure(d1f, npi * cin));
-    CGD_TRY(cgd_launch_pool2x2(ctx, d1.p, cin, d1f.p, cin, nullptr, 0, B, H, W, cin, 1.f, s));
-    dh1 = d1f.p;
     CGD_TRY(cgd_launch_pool2x2(ctx, dout.p, dout.ld, dx.p, cin, nullptr, 0, B, H, W, cin, 1.f, s));
     add = dx.p; ldadd = cin;
   } else if (skip_conv) {
@@ -214,12 +213,29 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
     sk.A = dout.p; sk.lda = dout.ld; sk.B = skwT; sk.ldb = cout; sk.C = dx.p; sk.ldc = cin;
     sk.M = (int)npo; sk.N = cin; sk.K = cout;
     sk.weight = 1;
-  CGD_TRY(cgd_launch_gemm(ctx, sk, s));
+    CGD_TRY(cgd_launch_gemm(ctx, sk, s));
     add = dx.p; ldadd = cin;
   } else {
     add = dout.p; ldadd = dout.ld;
   }
-  CGD_TRY(cgd_launch_gn_bwd(ctx, x.p, x.ld, dh1, cin, dx.p, cin, add, ldadd, B, H * W, cin, 1, s1.p, s));
+  // conv1 dgrad (at the conv's own resolution)
+  GemmParams c1;
+  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
+  c1.M = (int)npo; c1.N = cin; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cout;
+  c1.defer = (up || down) ? 0 : 1;  // plain blocks: GN1's backward below consumes the slices; resampling blocks read d1 first
+  CGD_TRY(cgd_launch_gemm(ctx, c1, s));
+  const float* dh1 = d1.p;
+  if (down) {
+    CGD_TRY(u.ensure(d1f, npi * cin));
+    CGD_TRY(cgd_launch_upsample2x(ctx, d1.p, cin, d1f.p, cin, nullptr, 0, B, H, W, cin, 0.25f, s));
+    dh1 = d1f.p;
+  } else if (up) {
+    CGD_TRY(u.ensure(d1f, npi * cin));
+    CGD_TRY(cgd_launch_pool2x2(ctx, d1.p, cin, d1f.p, cin, nullptr, 0, B, H, W, cin, 1.f, s));
+    dh1 = d1f.p;
+  }
+  // + the gradient of the skip connection that read this block's input (fused here instead of a separate add pass)
+  CGD_TRY(cgd_launch_gn_bwd(ctx, x.p, x.ld, dh1, cin, dx.p, cin, add, ldadd, B, H * W, cin, 1, s1.p, s, add_skip.p, add_skip.ld));
   *din = TV{dx.p, cin, cin};
   return 0;
 }
@@ -234,7 +250,9 @@ int AttnBlock::fwd(UNet& u, TV xin, int Bn, int& H, int& W, TV* o, hipStream_t s
   CGD_TRY(u.ensure(n, rows * C));
   CGD_TRY(u.ensure(qkv, rows * 3 * C));
   CGD_TRY(u.ensure(a, rows * C));
-  CGD_TRY(u.ensure(out, rows * C));
+  if (!dst.p) CGD_TRY(u.ensure(out, rows * C));
+  float* const outp = dst.p ? dst.p : out.p;
+  const int ldo = dst.p ? dst.ld : C;
   CGD_TRY(u.ensure(qkvT, (size_t)B * 3 * C * Tp));
   CGD_TRY(u.ensure(P, (size_t)B * heads * T * Tp));
   CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, n.p, C, B, T, C, g, b, nullptr, 0, 0, 1e-5f, sc.p, s));
@@ -246,11 +264,12 @@ int AttnBlock::fwd(UNet& u, TV xin, int Bn, int& H, int& W, TV* o, hipStream_t s
   AttnBufs bf{qkvT.p, P.p, nullptr, nullptr, nullptr};
   CGD_TRY(cgd_attn_fwd(ctx, sh, qkv.p, 3 * C, a.p, C, bf, s));
   GemmParams p;
-  p.A = a.p; p.lda = C; p.B = pw; p.ldb = C; p.C = out.p; p.ldc = C; p.bias = pb; p.R = x.p; p.ldr = x.ld; p.M = (int)rows; p.N = C;
+  p.A = a.p; p.lda = C; p.B = pw; p.ldb = C; p.C = outp; p.ldc = ldo; p.bias = pb; p.R = x.p; p.ldr = x.ld; p.M = (int)rows; p.N = C;
   p.K = C;
   p.weight = 1;
+  p.defer = 1;  // next: the GroupNorm of the following module
   CGD_TRY(cgd_launch_gemm(ctx, p, s));
-  *o = TV{out.p, C, C};
+  *o = TV{outp, ldo, C};
   return 0;
 }
 
@@ -275,6 +294,7 @@ int AttnBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   GemmParams q;
   q.A = dqkv.p; q.lda = 3 * C; q.B = qkvwT; q.ldb = 3 * C; q.C = dn.p; q.ldc = C; q.M = (int)rows; q.N = C; q.K = 3 * C;
   q.weight = 1;
+  q.defer = 1;  // consumed by the GroupNorm backward right below
   CGD_TRY(cgd_launch_gemm(ctx, q, s));
   CGD_TRY(cgd_launch_gn_bwd(ctx, x.p, x.ld, dn.p, C, dx.p, C, dout.p, dout.ld, B, T, C, 0, sc.p, s));
   *din = TV{dx.p, C, C};
@@ -338,6 +358,7 @@ int UNet::build() {
   add_param("input_blocks.0.0.bias", ch);
   in_blocks.emplace_back();
   in_chans.push_back(ch);
+  in_ds.push_back(1);
   int ds = 1, idx = 1;
   for (int level = 0; level < cfg.n_mult; ++level) {
     const int co = (int)(cfg.channel_mult[level] * mc);
@@ -349,6 +370,7 @@ int UNet::build() {
       if (is_att(ds)) blk.push_back(make_att(pre + ".1", ch));
       in_blocks.push_back(std::move(blk));
       in_chans.push_back(ch);
+      in_ds.push_back(ds);
       ++idx;
     }
     if (level != cfg.n_mult - 1) {
@@ -358,6 +380,7 @@ int UNet::build() {
       in_chans.push_back(ch);
       ++idx;
       ds *= 2;
+      in_ds.push_back(ds);
     }
   }
   mid.push_back(make_rb("middle_block.0", ch, ch, false, false));
@@ -504,11 +527,34 @@ int UNet::forward(const float* x, const float* t, const int64_t* y, float* out, 
   g3.A = e2s.p; g3.lda = ted; g3.B = emb_w_all; g3.ldb = ted; g3.C = emb_all.p; g3.ldc = (int)emb_total; g3.bias = emb_b_all;
   g3.M = B; g3.N = (int)emb_total; g3.K = ted;
   CGD_TRY(cgd_launch_gemm(ctx, g3, s));
-  // ---- stem ----
-  CGD_TRY(ensure(h0, (size_t)B * H * W * ch0));
-  CGD_TRY(cgd_launch_conv_in(ctx, x, stem_wf, P("input_blocks.0.0.bias"), h0.p, B, H, W, cfg.in_channels, ch0, s));
+  // ---- skip-concat buffers: output block k reads cat([h, hs[n-1-k]]) = cats[k] ([pixels][c1 + skip channels]).  The producers
+  //      of the two halves (the previous output-side module / the input-side block or the stem) write straight into their
+  //      channel slice, so no concat copy exists.
+  const int n_in = (int)in_blocks.size();
+  cat_in.assign(out_blocks.size(), TV{});
+  cat_c1.assign(out_blocks.size(), 0);
+  cat_hw.assign(out_blocks.size(), {0, 0});
+  for (size_t k = 0; k < out_blocks.size(); ++k) {
+    const int i = n_in - 1 - (int)k;
+    const ResBlock* rb = static_cast<const ResBlock*>(out_blocks[k][0].get());
+    const int ct = rb->cin, c1 = ct - in_chans[i];
+    const int hk = H / in_ds[i], wk = W / in_ds[i];
+    CGD_TRY(ensure(cats[k], (size_t)B * hk * wk * ct));
+    cat_in[k] = TV{cats[k].p, ct, ct};
+    cat_c1[k] = c1;
+    cat_hw[k] = {hk, wk};
+    Module* skip_src = i == 0 ? nullptr : in_blocks[i].back().get();        // i == 0: the stem conv
+    if (skip_src) skip_src->dst = TV{cats[k].p + c1, ct, in_chans[i]};
+    Module* h_src = k == 0 ? mid.back().get() : out_blocks[k - 1].back().get();
+    h_src->dst = TV{cats[k].p, ct, c1};
+  }
+  // ---- stem (its output is the skip half of the LAST concat) ----
+  const size_t klast = out_blocks.size() - 1;
+  float* const h0p = cats[klast].p + cat_c1[klast];
+  const int h0ld = cat_in[klast].ld;
+  CGD_TRY(cgd_launch_conv_in(ctx, x, stem_wf, P("input_blocks.0.0.bias"), h0p, B, H, W, cfg.in_channels, ch0, s, h0ld));
   hs.clear(); hs_hw.clear();
-  TV h{h0.p, ch0, ch0};
+  TV h{h0p, h0ld, ch0};
   int ch = H, cw = W;
   hs.push_back(h); hs_hw.push_back({ch, cw});
   for (size_t i = 1; i < in_blocks.size(); ++i) {
@@ -516,18 +562,9 @@ int UNet::forward(const float* x, const float* t, const int64_t* y, float* out, 
     hs.push_back(h); hs_hw.push_back({ch, cw});
   }
   for (auto& m : mid) CGD_TRY(m->fwd(*this, h, B, ch, cw, &h, s));
-  cat_in.clear(); cat_c1.clear(); cat_hw.clear();
-  size_t top = hs.size();
   for (size_t k = 0; k < out_blocks.size(); ++k) {
-    const TV sk = hs[--top];
-    const int ct = h.C + sk.C;
-    const long np = (long)B * ch * cw;
-    CGD_TRY(ensure(cats[k], (size_t)np * ct));
-    CGD_TRY(cgd_launch_concat2(ctx, h.p, h.ld, h.C, sk.p, sk.ld, sk.C, cats[k].p, ct, np, s));
-    cat_c1.push_back(h.C);
-    cat_hw.push_back({ch, cw});
-    h = TV{cats[k].p, ct, ct};
-    cat_in.push_back(h);
+    if (ch != cat_hw[k].first || cw != cat_hw[k].second || h.p != cats[k].p) CGD_FAIL(ctx, "unet: concat bookkeeping mismatch");
+    h = cat_in[k];
     for (auto& m : out_blocks[k]) CGD_TRY(m->fwd(*this, h, B, ch, cw, &h, s));
   }
   // ---- head: GN -> SiLU -> conv3x3 (ch0 -> out_channels), NCHW out ----
@@ -557,16 +594,16 @@ int UNet::dgrad(const float* gout, float* gx, hipStream_t s) {
     dskip[k] = TV{d.p + c1, d.ld, d.C - c1};
     d = TV{d.p, d.ld, c1};
   }
-  for (int j = (int)mid.size() - 1; j >= 0; --j) CGD_TRY(mid[j]->bwd(*this, d, &d, s));
-  // input blocks in reverse: hs[i] was consumed by output block k = n-1-i
+  // hs[i] (the output of input block i, or of the stem for i = 0) was also consumed by output block k = n-1-i: its gradient is the
+  // sum of what the next module hands back and the skip half dskip[n-1-i].  The module that produces the former is always a
+  // ResBlock (input block i+1's first module, or middle_block.0 for the last one), whose final GroupNorm-backward pass adds the
+  // skip half on the fly (`add_skip`): no separate add kernel.
   const int n = (int)in_blocks.size();
-  for (int i = n - 1; i >= 0; --i) {
-    const TV& sk = dskip[n - 1 - i];
-    const long np = (long)B * hs_hw[i].first * hs_hw[i].second;
-    CGD_TRY(cgd_launch_copy2d(ctx, d.p, d.ld, sk.p, sk.ld, d.p, d.ld, np, d.C, s));  // d += skip-half (in place)
-    if (i == 0) break;
+  static_cast<ResBlock*>(mid[0].get())->add_skip = dskip[0];
+  for (int i = 1; i < n; ++i) static_cast<ResBlock*>(in_blocks[i][0].get())->add_skip = dskip[n - i];
+  for (int j = (int)mid.size() - 1; j >= 0; --j) CGD_TRY(mid[j]->bwd(*this, d, &d, s));
+  for (int i = n - 1; i >= 1; --i)
     for (int j = (int)in_blocks[i].size() - 1; j >= 0; --j) CGD_TRY(in_blocks[i][j]->bwd(*this, d, &d, s));
-  }
   // stem dgrad: NHWC (ch0) -> NCHW (in_channels)
   CGD_TRY(cgd_launch_conv_thin_out(ctx, d.p, d.ld, stem_wd, nullptr, gx, B, H, W, ch0, cfg.in_channels, s));
   return 0;
@@ -639,11 +676,13 @@ int cgd_unet_finalize(cgd_unet* u) {
 int cgd_unet_forward(cgd_unet* u, const float* x, const float* t, const int64_t* y, float* out, int B, int H, int W, void* stream) {
   if (!u) return -3;
   DeviceScope dev_scope(u->net.ctx);
-  return u->net.forward(x, t, y, out, B, H, W, (hipStream_t)stream);
+  CGD_TRY(u->net.forward(x, t, y, out, B, H, W, (hipStream_t)stream));
+  return cgd_flush_pending(u->net.ctx, (hipStream_t)stream);  // nothing deferred may outlive the call
 }
 int cgd_unet_dgrad(cgd_unet* u, const float* g_out, float* g_x, void* stream) {
   if (!u) return -3;
   DeviceScope dev_scope(u->net.ctx);
-  return u->net.dgrad(g_out, g_x, (hipStream_t)stream);
+  CGD_TRY(u->net.dgrad(g_out, g_x, (hipStream_t)stream));
+  return cgd_flush_pending(u->net.ctx, (hipStream_t)stream);
 }
 }

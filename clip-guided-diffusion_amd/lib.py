@@ -8,7 +8,8 @@ import os
 import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgd_mi355x.so")
+# CGD_LIB_PATH: tuning knob for same-box A/B runs of two builds (benchmarks/ab.sh); the product loads the in-tree library
+LIB_PATH = os.environ.get("CGD_LIB_PATH") or os.path.join(_HERE, "libcgd_mi355x.so")
 
 F32P = C.POINTER(C.c_float)
 vp = C.c_void_p
