@@ -35,7 +35,9 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
       return -4;
     }
   }
-  if (const char* e = getenv("CGD_DEFER")) ctx->defer_mode = atoi(e);  // tuning knob (A/B runs)
+  if (const char* e = getenv("CGD_DEFER")) ctx->defer_mode = atoi(e);  // tuning knobs (A/B runs)
+  if (const char* e = getenv("CGD_HGEMM_VAR")) ctx->hgemm_var = atoi(e);
+  if (const char* e = getenv("CGD_TILE_ORDER")) ctx->tile_order = atoi(e);
   ctx->ws_bytes = (size_t)256 << 20;
   if (hipMalloc((void**)&ctx->ws, ctx->ws_bytes) != hipSuccess) {
     delete ctx;

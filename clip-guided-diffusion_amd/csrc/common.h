@@ -64,6 +64,9 @@ struct cgd_ctx {
                       // 64 pixels x 64 channels instead of 128 x 32 (the kernel is power-limited: 128 x 32 moves half of the
                       // fragment traffic from the vector-memory path to the LDS, +1.2..1.8 % per layer at the 1.36 kW cap)
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int tile_order = 0;  // XCD tile order of hgemm2 / hconv2: 0 auto (weight-panel major when the weights are the larger operand),
+                       // 1 always weight-panel (N) major, 2 always row-panel (M) major (A/B knob)
+  int hgemm_var = 1;   // weight GEMM kernel variant (hgemm.hip cgd_hgemm_tile_m): 0 hgemm_kernel, 1 hgemm2 auto tile, 2 / 3 hgemm2 128 / 64 rows
   int hgemm_mode = 1, hgemm_min_m = 512, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
                                                                 // igemm's finer tiles win), chunks per split-K slice
   PendingReduce pending;                                       // see SplitSrc
@@ -174,7 +177,8 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------
 bool cgd_hgemm_supported(const cgd_ctx* ctx, const GemmParams& p);
-int cgd_hgemm_tiles(const GemmParams& p);
+int cgd_hgemm_tile_m(const cgd_ctx* ctx, const GemmParams& p);
+int cgd_hgemm_tiles(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_hgemm_chunks(const GemmParams& p);
 int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 void cgd_frag_cache_clear(cgd_ctx* ctx);

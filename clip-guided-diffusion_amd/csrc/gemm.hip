@@ -436,7 +436,7 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   if (tile == 513 && !use_g) CGD_FAIL(ctx, "cgd_launch_gemm: weight GEMM kernel does not support this problem");
   if (use_g) {
     tile = 513;
-    const long tiles = cgd_hgemm_tiles(p);
+    const long tiles = cgd_hgemm_tiles(ctx, p);
     const int nch = cgd_hgemm_chunks(p);
     if (auto_split && tiles < ctx->num_cu) {
       // about one workgroup per CU and >= hgemm_min_chunks chunks per slice (gemm_r1bb: ViT shapes, M = 800)
@@ -556,7 +556,7 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   if (kernel == 1) {
     wg = (long)(p.M / cgd_hconv_tile_m(&ctx, p)) * cdiv(p.N, 128);
   } else if (kernel == 2) {
-    wg = cgd_hgemm_tiles(p);
+    wg = cgd_hgemm_tiles(&ctx, p);
   } else {
     int bm = 0, bn = 0;
     tile_dims(tile, &bm, &bn);

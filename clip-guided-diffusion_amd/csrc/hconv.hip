@@ -47,6 +47,8 @@ struct HConvParams {
   int lda, ldc, ldr;
   int M, N, H, W, Cin, ups, splitk;
   float alpha;
+  int nmajor;  // 1: channel-tile major order within an XCD's run of tiles (the <= 64x64-pixel levels, where the packed weights
+               // are the larger operand: an XCD then owns a few output-channel panels and keeps their weights in its L2)
 };
 
 
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int mt = bid / ntn, n0 = (bid % ntn) * HB_N;
+  const int ntm = gridDim.x / ntn;
+  const int mt = p.nmajor ? bid % ntm : bid / ntn, n0 = (p.nmajor ? bid / ntm : bid % ntn) * HB_N;
   const int tpr = p.W >> 4, tpi = (p.H / TH) * tpr;
   const int img = mt / tpi, trem = mt - img * tpi;
   const int y0 = (trem / tpr) * TH, x0 = (trem % tpr) << 4;
@@ -381,6 +384,8 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.A = g.A; p.Bp = (const uint4*)g.Bpk; p.C = g.C; p.bias = g.bias; p.R = g.R; p.ws = g.ws;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
+  // weights 9 * Cin * N against activations M * Cin (both x 4 B): weight-panel major when the weights are larger
+  p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 9L * g.N >= g.M)) ? 1 : 0;
   const int tm = cgd_hconv_tile_m(ctx, g);
   dim3 grid((g.M / tm) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
 #define HC2_LAUNCH(M_, TH_, NJ_) \

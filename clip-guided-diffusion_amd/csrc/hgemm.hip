@@ -29,6 +29,9 @@ struct HGemmParams {
   int lda, ldc, ldr;
   int M, N, K, splitk;
   float alpha;
+  int nmajor;  // tile order within the XCD-contiguous runs: 0 = M-tile major (an XCD owns row panels and streams all weights),
+               // 1 = N-tile major (an XCD owns weight column panels, read from HBM once and kept in its 4 MB L2; the small
+               // activation matrix is what every XCD re-reads): chosen when the weights are the larger operand (N >= M)
 };
 
 __device__ __forceinline__ bf16x4 g_to_bf16x4(const f32x4 v) {
@@ -253,6 +256,235 @@ epilogue:
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// hgemm2_kernel: the same GEMM with the wave -> sub-tile mapping and the weight-fragment pipeline of hconv2_kernel.
+//   * Why: the rocprofv3 trace of round 2 (profiles/r2_trace_step_a.txt) shows the step's kernels running back to back, i.e.
+//     the time of the ViT linears (M = 800 token rows, 13-28 us for 1-4 GFLOP) is INSIDE hgemm_kernel: one workgroup per CU,
+//     one wavefront per SIMD, and B fragments fetched only two k-steps (~0.3 us) ahead while the weights stream from HBM
+//     (the ViT's 350 MB of packed weights do not stay in L2) at >1 us latency: the MFMA pipe waits for the ring.
+//   * wavefront sub-tile TM x 32 (TM = 128 or 64 rows): the 4 wavefronts sit side by side along N and share the A chunk in
+//     LDS; per k-step a wavefront issues 2 global fragment loads (hi / lo planes of ONE 32-column block) instead of 4, so an
+//     8-slot register ring (7 k-steps ~ 1.2 us ahead) costs the 64 VGPRs the 4-slot ring of the 64 x 64 mapping did;
+//   * TM = 64 for small M (fewer than one 128-row tile per CU): M = 800 gives 13 x N/128 workgroups instead of 7 x N/128, so
+//     the N >= 2304 linears fill the chip without split-K and the others split less; two to three workgroups fit a CU
+//     (LDS 36.9 KB, ~170 VGPRs), whose load stalls overlap;
+//   * the loop body covers TWO 64-deep chunks (8 k-steps = one turn of the ring), so every ring slot and LDS buffer is a
+//     compile-time constant; an odd chunk count ends with a single-chunk tail outside the loop;
+//   * A staging, conversion, barrier placement and the epilogue are those of hgemm_kernel.
+template <int MODE, int TM>
+__global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+                                                     const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
+                                                     const HGemmParams p) {
+  constexpr int NPL = MODE == 1 ? 2 : 1;
+  constexpr int NI = TM / 32;      // 32-row blocks per wavefront
+  constexpr int NPS = TM / 16;     // staging slots per thread: rows r0 + 16 j
+  constexpr int PLANE = TM * GPH;
+  constexpr int RING = 8, DIST = RING - 1;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int ntn = (p.N + GN - 1) / GN;
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntm = (p.M + TM - 1) / TM;
+  const int m0 = (p.nmajor ? bid % ntm : bid / ntn) * TM, n0 = (p.nmajor ? bid / ntm : bid % ntn) * GN;
+
+  const int c4 = tid & 15, r0 = tid >> 4;
+  int aoff[NPS];
+  unsigned amask = 0;
+#pragma unroll
+  for (int j = 0; j < NPS; ++j) {
+    const int r = m0 + r0 + 16 * j;
+    const bool ok = r < p.M;
+    aoff[j] = (ok ? r : p.M - 1) * p.lda + c4 * 4;
+    amask |= ok ? (1u << j) : 0u;
+  }
+  int fro[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) fro[i] = (i * 32 + l31) * GPH + hh * 8;
+
+  const int nchunk = p.K / GK;
+  int c0 = 0, c1 = nchunk;
+  if (p.splitk > 1) {
+    const int per = (nchunk + p.splitk - 1) / p.splitk;
+    c0 = blockIdx.z * per;
+    c1 = min(nchunk, c0 + per);
+  }
+  const int nb0 = (n0 >> 5) + wn, nbN = p.N >> 5;
+  const long bstride_nb = (long)(p.K >> 5) * 4 * 64;
+  const uint4* __restrict__ Bw0 = Bg + (long)(nb0 < nbN ? nb0 : nbN - 1) * bstride_nb + lane;
+  const int kq_last = c1 * 4 - 1;
+
+  f32x16 acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  if (c0 < c1) {
+    constexpr bool DEEP = TM == 64;      // activations two chunks ahead (second staging register set)
+    constexpr int AHEAD = DEEP ? 3 : 2;  // chunk fetched by the load at the end of chunk C
+    f32x4 pr[NPS], pr2[DEEP ? NPS : 1];
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#define H2_PATCH_LOAD(PR, CH)                                                                     \
+  {                                                                                               \
+    const float* __restrict__ Ac = Ag + (long)((CH) < c1 ? (CH) : c1 - 1) * GK;                   \
+    _Pragma("unroll") for (int j = 0; j < NPS; ++j) PR[j] = *(const f32x4*)(Ac + aoff[j]);        \
+  }
+#define H2_PATCH_STORE(PR, DSTB, J0, J1)                                                          \
+  {                                                                                               \
+    _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                             \
+      const int row = r0 + 16 * j;                                                                \
+      const f32x4 v = (amask >> j) & 1u ? PR[j] : z4;                                             \
+      const bf16x4 hi = g_to_bf16x4(v);                                                           \
+      *(bf16x4*)&(DSTB)[row * GPH + c4 * 4] = hi;                                                 \
+      if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + row * GPH + c4 * 4] = g_to_bf16x4(g_residual4(v, hi)); \
+    }                                                                                             \
+  }
+#define H2_A_LOAD(DST, SRCB, Q)                                                                   \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
+      DST[i][0] = *(const bf16x8*)&(SRCB)[fro[i] + (Q) * 16];                                     \
+      if constexpr (MODE == 1) DST[i][1] = *(const bf16x8*)&(SRCB)[PLANE + fro[i] + (Q) * 16];    \
+    }                                                                                             \
+  }
+#define H2_B_LOAD(DST, KQ)                                                                        \
+  {                                                                                               \
+    const int kq_ = (KQ) < kq_last ? (KQ) : kq_last;                                              \
+    const uint4* q_ = Bw0 + (long)kq_ * 128;                                                      \
+    DST[0] = q_[0];                                                                               \
+    if constexpr (MODE == 1) DST[1] = q_[64];                                                     \
+  }
+#define H2_MFMA(AQ, BQ)                                                                           \
+  {                                                                                               \
+    if constexpr (MODE == 1) {                                                                    \
+      _Pragma("unroll") for (int i = 0; i < NI; ++i)                                              \
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[0]), AQ[i][1], acc[i], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < NI; ++i)                                              \
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[1]), AQ[i][0], acc[i], 0, 0, 0); \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, BQ[0]), AQ[i][0], acc[i], 0, 0, 0); \
+  }
+  // after every MFMA: LDS fragment reads (NI * NPL per k-step), the two global fragment loads, a few conversion VALU ops and
+  // the LDS writes of the next chunk's patch
+#define H2_INTERLEAVE()                                                                           \
+  {                                                                                               \
+    _Pragma("unroll") for (int r = 0; r < 3 * NI; ++r) {                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+      if (r % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+      if (r % 3 == 2 && r < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 \
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                          \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  }
+  // one 64-deep chunk: ring slots S .. S+3 (S = 0 or 4), LDS buffers CUR -> NXT, staging registers PR (they hold chunk C+1 on
+  // entry and are refilled with chunk C+AHEAD once converted)
+#define H2_CHUNK(S, CUR, NXT, C, PR)                                                              \
+  {                                                                                               \
+    const int kq = (C) * 4;                                                                       \
+    H2_A_LOAD(af[1], CUR, 1);                                                                     \
+    H2_B_LOAD(bq[((S) + 0 + DIST) % RING], kq + 0 + DIST);                                        \
+    H2_MFMA(af[0], bq[(S) + 0]);                                                                  \
+    H2_INTERLEAVE();                                                                              \
+    H2_A_LOAD(af[0], CUR, 2);                                                                     \
+    H2_B_LOAD(bq[((S) + 1 + DIST) % RING], kq + 1 + DIST);                                        \
+    H2_MFMA(af[1], bq[(S) + 1]);                                                                  \
+    H2_PATCH_STORE(PR, NXT, 0, NPS / 2);                                                          \
+    H2_INTERLEAVE();                                                                              \
+    H2_A_LOAD(af[1], CUR, 3);                                                                     \
+    H2_B_LOAD(bq[((S) + 2 + DIST) % RING], kq + 2 + DIST);                                        \
+    H2_MFMA(af[0], bq[(S) + 2]);                                                                  \
+    H2_PATCH_STORE(PR, NXT, NPS / 2, NPS);                                                        \
+    H2_INTERLEAVE();                                                                              \
+    H2_PATCH_LOAD(PR, (C) + AHEAD);                                                               \
+    __syncthreads(); /* NXT fully written; every wavefront has fetched its last fragments of CUR */ \
+    H2_A_LOAD(af[0], NXT, 0);                                                                     \
+    H2_B_LOAD(bq[((S) + 3 + DIST) % RING], kq + 3 + DIST);                                        \
+    H2_MFMA(af[1], bq[(S) + 3]);                                                                  \
+    H2_INTERLEAVE();                                                                              \
+  }
+
+    bf16x8 af[2][NI][NPL];  // [pipeline slot][row block][plane]
+    uint4 bq[RING][NPL];    // [ring slot][plane]
+    __bf16* const buf0 = lds;
+    __bf16* const buf1 = lds + NPL * PLANE;
+    H2_PATCH_LOAD(pr, c0);
+#pragma unroll
+    for (int q = 0; q < DIST; ++q) H2_B_LOAD(bq[q], c0 * 4 + q);
+    H2_PATCH_STORE(pr, buf0, 0, NPS);
+    H2_PATCH_LOAD(pr, c0 + 1);
+    int c = c0;
+    if constexpr (DEEP) {
+      // A chunk of the 64-row tile lasts ~0.3 us, less than an L2 round trip: the activations are fetched TWO chunks ahead into
+      // alternating register sets (one chunk ahead left every chunk waiting ~0.7 us for its patch, gemm_r2b)
+      H2_PATCH_LOAD(pr2, c0 + 2);
+      __syncthreads();
+      H2_A_LOAD(af[0], buf0, 0);
+      for (; c + 1 < c1; c += 2) {
+        H2_CHUNK(0, buf0, buf1, c, pr);
+        H2_CHUNK(4, buf1, buf0, c + 1, pr2);
+      }
+      if (c < c1) H2_CHUNK(0, buf0, buf1, c, pr);
+    } else {
+      __syncthreads();
+      H2_A_LOAD(af[0], buf0, 0);
+      for (; c + 1 < c1; c += 2) {
+        H2_CHUNK(0, buf0, buf1, c, pr);
+        H2_CHUNK(4, buf1, buf0, c + 1, pr);
+      }
+      if (c < c1) H2_CHUNK(0, buf0, buf1, c, pr);
+    }
+#undef H2_PATCH_LOAD
+#undef H2_PATCH_STORE
+#undef H2_A_LOAD
+#undef H2_B_LOAD
+#undef H2_MFMA
+#undef H2_INTERLEAVE
+#undef H2_CHUNK
+  }
+
+  // ---- epilogue: D = W x A^T in the 32x32 C/D layout: column (lane & 31) = row m of C, accumulator quad g = columns 8g + 4hh ..
+  const int cb0 = n0 + wn * 32;
+  if (cb0 >= p.N) return;
+  if (p.splitk > 1) {
+    float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const long row = m0 + i * 32 + l31;
+      if (row < p.M) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)&ws[row * p.N + cb0 + 8 * g + 4 * hh] = f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const long row = m0 + i * 32 + l31;
+    if (row >= p.M) continue;
+    f32x4 rv[4];
+    if (Rg) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rv[g] = *(const f32x4*)&Rg[row * p.ldr + cb0 + 8 * g + 4 * hh];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = cb0 + 8 * g + 4 * hh;
+      f32x4 o = f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]} * p.alpha;
+      if (biasg) o += f32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
+      if (Rg) o += rv[g];
+      *(f32x4*)&Cg[row * p.ldc + col] = o;
+    }
+  }
+}
+
 // w [N][ldw] row-major (k contiguous) -> fragment order [N/32][K/32][ks][plane][lane][8] (bf16 hi / lo)
 __global__ __launch_bounds__(256) void pack_frag_linear_kernel(const float* __restrict__ w, int ldw, __bf16* __restrict__ out, int N, int K) {
   const long total = (long)N * K;
@@ -303,7 +535,14 @@ void cgd_frag_cache_clear(cgd_ctx* ctx) {
   ctx->frag_cache.clear();
 }
 
-int cgd_hgemm_tiles(const GemmParams& p) { return cdiv(p.M, GM) * cdiv(p.N, GN); }
+// rows per workgroup tile: hgemm_var 0 = hgemm_kernel (128 x 128, 64 x 64 per wavefront); 1 = hgemm2_kernel with 64-row tiles
+// while 128-row tiles would not give every CU a workgroup, 128 rows otherwise; 2 / 3 force hgemm2 with 128 / 64 rows
+int cgd_hgemm_tile_m(const cgd_ctx* ctx, const GemmParams& p) {
+  if (ctx->hgemm_var == 3) return 64;
+  if (ctx->hgemm_var == 1 && (long)cdiv(p.M, GM) * cdiv(p.N, GN) < ctx->num_cu) return 64;
+  return GM;
+}
+int cgd_hgemm_tiles(const cgd_ctx* ctx, const GemmParams& p) { return cdiv(p.M, cgd_hgemm_tile_m(ctx, p)) * cdiv(p.N, GN); }
 int cgd_hgemm_chunks(const GemmParams& p) { return p.K / GK; }
 
 int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
@@ -332,10 +571,20 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   HGemmParams p;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.K = g.K; p.splitk = g.splitk; p.alpha = g.alpha;
-  dim3 grid(cdiv(g.M, GM) * cdiv(g.N, GN), 1, g.splitk > 1 ? g.splitk : 1);
-  if (ctx->precision == CGD_PREC_BF16X3)
-    hipLaunchKernelGGL((hgemm_kernel<1>), grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p);
-  else
-    hipLaunchKernelGGL((hgemm_kernel<2>), grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p);
+  p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && g.N >= g.M)) ? 1 : 0;
+  const int tm = cgd_hgemm_tile_m(ctx, g);
+  dim3 grid(cdiv(g.M, tm) * cdiv(g.N, GN), 1, g.splitk > 1 ? g.splitk : 1);
+  const bool x3 = ctx->precision == CGD_PREC_BF16X3;
+  // hgemm2 addresses A with 32-bit element offsets
+  const bool v2 = ctx->hgemm_var != 0 && (long)g.M * g.lda < (1L << 31);
+#define HG_ARGS grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p
+  if (!v2) {
+    if (x3) hipLaunchKernelGGL((hgemm_kernel<1>), HG_ARGS); else hipLaunchKernelGGL((hgemm_kernel<2>), HG_ARGS);
+  } else if (tm == 64) {
+    if (x3) hipLaunchKernelGGL((hgemm2_kernel<1, 64>), HG_ARGS); else hipLaunchKernelGGL((hgemm2_kernel<2, 64>), HG_ARGS);
+  } else {
+    if (x3) hipLaunchKernelGGL((hgemm2_kernel<1, 128>), HG_ARGS); else hipLaunchKernelGGL((hgemm2_kernel<2, 128>), HG_ARGS);
+  }
+#undef HG_ARGS
   return 0;
 }

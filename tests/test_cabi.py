@@ -97,11 +97,12 @@ def test_dispatch_policy_of_the_contraction_launcher():
     assert conv(16, 1024, 1024) == (0, (1, 512, 8, 128))
     assert conv(8, 1024, 1024) == (0, (0, 64, 32, 512))
     assert conv(256, 256, 256, precision=0) == (0, (0, 1256, 1, 512))  # exact-fp32 mode: the halo kernel is bf16-only
-    # weight GEMMs (ViT-B/32 on 16 cutouts = 800 tokens): hgemm with the cached fragment copy, split-K to about one workgroup per CU
-    assert _plan(handle, M=800, N=768, K=768, weight=1) == (0, (2, 513, 3, 126))
-    assert _plan(handle, M=800, N=2304, K=768, weight=1) == (0, (2, 513, 2, 252))
-    assert _plan(handle, M=800, N=3072, K=768, weight=1) == (0, (2, 513, 1, 168))
-    assert _plan(handle, M=800, N=768, K=3072, weight=1) == (0, (2, 513, 6, 252))
+    # weight GEMMs (ViT-B/32 on 16 cutouts = 800 tokens): hgemm with the cached fragment copy; 128-row tiles would leave CUs idle, so
+    # the 64-row tile is used: the N >= 2304 linears fill the chip without split-K, the N = 768 ones split 3 ways
+    assert _plan(handle, M=800, N=768, K=768, weight=1) == (0, (2, 513, 3, 234))
+    assert _plan(handle, M=800, N=2304, K=768, weight=1) == (0, (2, 513, 1, 234))
+    assert _plan(handle, M=800, N=3072, K=768, weight=1) == (0, (2, 513, 1, 312))
+    assert _plan(handle, M=800, N=768, K=3072, weight=1) == (0, (2, 513, 3, 234))
     assert _plan(handle, M=65536, N=256, K=512, weight=1) == (0, (2, 513, 1, 1024))  # 1x1 skip conv at 256^2
     # activations x activations (no persistent weight) and small M stay on the generic kernel
     assert _plan(handle, M=800, N=768, K=768, weight=0)[1][0] == 0
