@@ -10,6 +10,14 @@
 namespace {
 
 constexpr int MAXJ = 4;  // float4 column iterations per thread: C <= 4096
+// independent 16-byte loads in flight per thread and input stream in the large-map kernels {stats, apply, bwd partial, bwd apply}.
+// Negative result kept as a knob: 8,8,4,4 / 8,8,8,8 / 6,6,6,6 are all 0.2-0.3 % SLOWER on the step than 4 everywhere (same-box
+// A/B, round 2) although the kernels run at 3.4-5.9 TB/s: more bytes in flight per thread do not buy bandwidth here.
+#ifndef CGD_GN_U
+#define CGD_GN_U 4, 4, 4, 4
+#endif
+constexpr int GN_UTAB[4] = {CGD_GN_U};
+constexpr int GN_US = GN_UTAB[0], GN_UA = GN_UTAB[1], GN_UP = GN_UTAB[2], GN_UB = GN_UTAB[3];  // stats, apply, bwd partial, bwd apply
 
 struct ColMap {
   int cq, TQ, rows, r, q0;
@@ -89,10 +97,10 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* x, f
     float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0);
     if (m.active) {
       // 4 independent loads in flight per thread: these kernels are latency-, not bandwidth-limited per wavefront
-      for (int pb = p0 + m.r; pb < p1; pb += 4 * m.rows) {
-        float4 v[4];
+      for (int pb = p0 + m.r; pb < p1; pb += GN_US * m.rows) {
+        float4 v[GN_US];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GN_US; ++u) {
           const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
           if (src.n) {
             v[u] = split_load4(src, (long)b * HW + pc, q * 4);
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* x, f
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GN_US; ++u) {
           if (pb + u * m.rows < p1) {
             const float dx = v[u].x - k4.x, dy = v[u].y - k4.y, dz = v[u].z - k4.z, dw = v[u].w - k4.w;
             s.x += dx; s.y += dy; s.z += dz; s.w += dw;
@@ -231,15 +239,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     if (q >= m.cq) break;
     const float4* cf = (const float4*)(coef + ((long)b * C + q * 4) * 4);
     const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
-    for (int pb = p0 + m.r; pb < p1; pb += 4 * m.rows) {
-      float4 vv[4];
+    for (int pb = p0 + m.r; pb < p1; pb += GN_UA * m.rows) {
+      float4 vv[GN_UA];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GN_UA; ++u) {
         const int p = pb + u * m.rows;
         vv[u] = *(const float4*)(xb + (long)(p < p1 ? p : pb) * ldx + q * 4);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GN_UA; ++u) {
         const int p = pb + u * m.rows;
         if (p < p1) {
           const float4 v = vv[u];
@@ -280,10 +288,10 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
     const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     if (m.active) {
-      for (int pb = p0 + m.r; pb < p1; pb += 4 * m.rows) {
-       float4 vv[4], dd[4];
+      for (int pb = p0 + m.r; pb < p1; pb += GN_UP * m.rows) {
+       float4 vv[GN_UP], dd[GN_UP];
 #pragma unroll
-       for (int u = 0; u < 4; ++u) {
+       for (int u = 0; u < GN_UP; ++u) {
          const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
          vv[u] = *(const float4*)(xb + (long)pc * ldx + q * 4);
          if (src.n) {
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
          }
        }
 #pragma unroll
-       for (int u = 0; u < 4; ++u) {
+       for (int u = 0; u < GN_UP; ++u) {
         if (pb + u * m.rows >= p1) continue;
         const float4 v = vv[u];
         float4 d = dd[u];
@@ -394,10 +402,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const float4* bf = (const float4*)(bcoef + ((long)b * C + q * 4) * 4);
     const float4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
     const float4 b0 = bf[0], b1 = bf[1], b2 = bf[2], b3 = bf[3];
-    for (int pb = p0 + m.r; pb < p1; pb += 4 * m.rows) {
-     float4 vv[4], dd[4], aa[4];
+    for (int pb = p0 + m.r; pb < p1; pb += GN_UB * m.rows) {
+     float4 vv[GN_UB], dd[GN_UB], aa[GN_UB];
 #pragma unroll
-     for (int u = 0; u < 4; ++u) {
+     for (int u = 0; u < GN_UB; ++u) {
        const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
        vv[u] = *(const float4*)(xb + (long)pc * ldx + q * 4);
        dd[u] = *(const float4*)(db + (long)pc * lddz + q * 4);
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
        }
      }
 #pragma unroll
-     for (int u = 0; u < 4; ++u) {
+     for (int u = 0; u < GN_UB; ++u) {
       const int p = pb + u * m.rows;
       if (p >= p1) continue;
       const float4 v = vv[u];
