@@ -38,6 +38,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_DEFER")) ctx->defer_mode = atoi(e);  // tuning knobs (A/B runs)
   if (const char* e = getenv("CGD_HGEMM_VAR")) ctx->hgemm_var = atoi(e);
   if (const char* e = getenv("CGD_TILE_ORDER")) ctx->tile_order = atoi(e);
+  if (const char* e = getenv("CGD_FUSE_GN")) ctx->fuse_gn = atoi(e);
   ctx->ws_bytes = (size_t)256 << 20;
   if (hipMalloc((void**)&ctx->ws, ctx->ws_bytes) != hipSuccess) {
     delete ctx;

@@ -64,6 +64,7 @@ struct cgd_ctx {
                       // 64 pixels x 64 channels instead of 128 x 32 (the kernel is power-limited: 128 x 32 moves half of the
                       // fragment traffic from the vector-memory path to the LDS, +1.2..1.8 % per layer at the 1.36 kW cap)
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int fuse_gn = 1;     // 1: ResBlock convs on the halo kernel apply their GroupNorm + FiLM + SiLU while staging (A/B knob)
   int tile_order = 0;  // XCD tile order of hgemm2 / hconv2: 0 auto (weight-panel major when the weights are the larger operand),
                        // 1 always weight-panel (N) major, 2 always row-panel (M) major (A/B knob)
   int hgemm_var = 1;   // weight GEMM kernel variant (hgemm.hip cgd_hgemm_tile_m): 0 hgemm_kernel, 1 hgemm2 auto tile, 2 / 3 hgemm2 128 / 64 rows
@@ -160,6 +161,8 @@ struct GemmParams {
   int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel
   int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
+  const float* gn_ab = nullptr;  // conv on the halo kernel only: apply SiLU(x * a + b) to the input while staging it; {a, b} pairs
+                                 // [B][Cin][2] of the GroupNorm(+FiLM) that precedes the conv (kernels.h cgd_gn_ab)
   int defer = 0;       // 1: if the launch splits K, leave the slices in the workspace (ctx->pending): the caller guarantees that the
                        // next kernel reading C is one that consumes a SplitSrc (cgd_take_pending); anything else flushes first
 };
@@ -184,6 +187,8 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 void cgd_frag_cache_clear(cgd_ctx* ctx);
 
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s);
+// would cgd_launch_gemm run this conv on the halo kernel (the only one that can apply a GroupNorm on the fly)?
+bool cgd_conv_uses_hconv(cgd_ctx* ctx, GemmParams p);
 
 // thin direct convs for the 3-channel ends of the UNet
 int cgd_launch_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w /*[Cout][3][3][Cin] (co,ky,kx,ci)*/, const float* bias,

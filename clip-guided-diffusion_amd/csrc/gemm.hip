@@ -493,6 +493,15 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   return 0;
 }
 
+int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out);
+bool cgd_conv_uses_hconv(cgd_ctx* ctx, GemmParams p) {
+  int tile = 0, kernel = 0;
+  const std::string keep = ctx->err;
+  const bool ok = p.conv && ctx->fuse_gn && cgd_plan_gemm(ctx, p, &tile, &kernel) == 0 && kernel == 1;
+  ctx->err = keep;
+  return ok;
+}
+
 int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s) {
   if (!ctx->pending.valid) return 0;
   const PendingReduce& q = ctx->pending;
@@ -519,6 +528,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   int tile = 0, kernel = 0;
   CGD_TRY(cgd_plan_gemm(ctx, p, &tile, &kernel));
   const bool use_h = kernel == 1, use_g = kernel == 2;
+  if (p.gn_ab && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: only the halo conv kernel applies a GroupNorm on the fly (cgd_conv_uses_hconv)");
   if (p.splitk > 1) p.ws = ctx->ws;
   ProfRec pr;
   CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? CGD_PROF_HCONV : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));

@@ -47,6 +47,7 @@ struct HConvParams {
   int lda, ldc, ldr;
   int M, N, H, W, Cin, ups, splitk;
   float alpha;
+  const float* gn;  // GN variant: {a, b} pairs [B][Cin][2] of the GroupNorm(+FiLM) in front of this conv (GemmParams::gn_ab)
   int nmajor;  // 1: channel-tile major order within an XCD's run of tiles (the <= 64x64-pixel levels, where the packed weights
                // are the larger operand: an XCD then owns a few output-channel panels and keeps their weights in its L2)
 };
@@ -78,10 +79,15 @@ constexpr int PW2 = 18;     // patch width: 16 + 2
 constexpr int HRS = 768;    // LDS pitch of a patch row (bf16 elements)
 constexpr int NPASS2 = 6;   // staging passes (both tile heights)
 
-template <int MODE, int TH, int NJ>
+//   * GN = true: the conv's input is SiLU(GroupNorm(x) [* (1 + scale) + shift]) of a tensor x whose statistics are already
+//     folded into per-(sample, channel) pairs {a, b}: the patch staging applies y = silu(x * a + b) to the values it has in
+//     registers anyway (4 VALU + 2 transcendental ops per element, in the shadow of the MFMAs), so the normalised tensor is
+//     never written nor re-read: one read + one write of the tensor and one launch less per ResBlock conv.  Padding positions
+//     stay exact zeros (they are padding of the ACTIVATED tensor).
+template <int MODE, int TH, int NJ, bool GN>
 __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                          const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
-                                                         const HConvParams p) {
+                                                         const float* __restrict__ gng, const HConvParams p) {
   constexpr int NPL = MODE == 1 ? 2 : 1;   // bf16 planes (hi, lo)
   constexpr int NP2 = (TH + 2) * PW2;      // patch rows: 324 / 180
   constexpr int PLANE = (TH + 2) * HRS;    // elements per plane
@@ -164,18 +170,29 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   f32x4 pr[NPASS2];
+  f32x4 ga[GN ? 2 : 1];  // {a0, b0, a1, b1}, {a2, b2, a3, b3} of this thread's 4 channels of the chunk being staged
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ gnimg = GN ? gng + ((long)img * p.Cin + c4 * 4) * 2 : nullptr;
 
 #define PATCH_LOAD2(CH)                                                                             \
   {                                                                                                 \
     const float* __restrict__ Ac = Aimg + (CH) * 32;                                                \
+    if constexpr (GN) {                                                                             \
+      ga[0] = *(const f32x4*)(gnimg + (CH) * 64);                                                   \
+      ga[1] = *(const f32x4*)(gnimg + (CH) * 64 + 4);                                               \
+    }                                                                                               \
     _Pragma("unroll") for (int j = 0; j < NPASS2; ++j)                                              \
         pr[j] = *(const f32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4)); /* zeroed at store time */  \
   }
+#define GN_SILU(X, A, B) ({ const float u_ = (X) * (A) + (B); u_ / (1.f + __expf(-u_)); })
 #define PATCH_STORE2(DSTB, J0, J1)                                                                  \
   {                                                                                                 \
     _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                               \
-      const f32x4 v = poff[j] >= 0 ? pr[j] : z4;                                                    \
+      f32x4 v = pr[j];                                                                              \
+      if constexpr (GN)                                                                             \
+        v = f32x4{GN_SILU(v.x, ga[0].x, ga[0].y), GN_SILU(v.y, ga[0].z, ga[0].w), GN_SILU(v.z, ga[1].x, ga[1].y),  \
+                  GN_SILU(v.w, ga[1].z, ga[1].w)};                                                  \
+      v = poff[j] >= 0 ? v : z4;                                                                    \
       const bf16x4 hi = to_bf16x4(v);                                                               \
       *(bf16x4*)&(DSTB)[soff[j]] = hi;                                                              \
       if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + soff[j]] = to_bf16x4(residual4(v, hi));    \
@@ -277,6 +294,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
   }
 #undef PATCH_LOAD2
 #undef PATCH_STORE2
+#undef GN_SILU
 #undef A_LOAD2
 #undef B_LOAD2
 #undef MFMA12
@@ -384,18 +402,24 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.A = g.A; p.Bp = (const uint4*)g.Bpk; p.C = g.C; p.bias = g.bias; p.R = g.R; p.ws = g.ws;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
+  p.gn = g.gn_ab;
   // weights 9 * Cin * N against activations M * Cin (both x 4 B): weight-panel major when the weights are larger
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 9L * g.N >= g.M)) ? 1 : 0;
   const int tm = cgd_hconv_tile_m(ctx, g);
   dim3 grid((g.M / tm) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
-#define HC2_LAUNCH(M_, TH_, NJ_) \
-  hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p)
+#define HC2_LAUNCH(M_, TH_, NJ_)                                                                                                   \
+  {                                                                                                                                \
+    if (p.gn)                                                                                                                      \
+      hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_, true>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p);  \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_, false>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p); \
+  }
 #define HC2_LAUNCH_T(M_, NJ_)  \
   {                            \
     if (tm == 128)             \
-      HC2_LAUNCH(M_, 8, NJ_);  \
+      HC2_LAUNCH(M_, 8, NJ_)   \
     else                       \
-      HC2_LAUNCH(M_, 16, NJ_); \
+      HC2_LAUNCH(M_, 16, NJ_)  \
   }
   const bool nj1 = (ctx->hconv_var & 4) == 0;  // wave -> sub-tile mapping (kernel header): 128 pixels x 32 channels unless bit 2
   if (ctx->precision == CGD_PREC_BF16X3) {

@@ -9,6 +9,10 @@ size_t cgd_gn_scratch_floats(int B, int HW, int C);
 // `scratch` (cgd_gn_scratch_floats) keeps the statistics and folded coefficients for the backward pass.
 int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma,
                       const float* beta, const float* film, int ldfilm, int act, float eps, float* scratch, hipStream_t s);
+// y == nullptr: statistics and folded coefficients only; cgd_gn_ab() then locates the compact {a, b} pairs [B][C][2] with which
+// the consumer applies y = act(x * a + b) itself (the halo conv kernel while it stages its input: the normalised tensor is never
+// written).
+const float* cgd_gn_ab(const float* scratch, int B, int HW, int C);
 // dx = dGN/dx (dz) (+ add) (+ add2);  needs the forward's scratch.  add / add2: residual-path and skip-connection gradients
 // that meet at this tensor (both optional, own row strides).
 int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add,

@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
     o[1] = bt - meanf * gm * rstd;
     o[2] = gm;
     o[3] = meanf;
+    float* ab = coef + (long)gridDim.y * C * 8 + ((long)b * C + c) * 2;  // compact copy behind bcoef (cgd_gn_ab)
+    ab[0] = o[0];
+    ab[1] = o[1];
   }
 }
 
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* x, flo
   const bool act_q = q < cq;
   const float* xg = x + (long)b * HW * ldx + g * cpg + q * VEC;
   float* xwg = xw + (long)b * HW * ldx + g * cpg + q * VEC;
-  float* yg = y + (long)b * HW * ldy + g * cpg + q * VEC;
+  float* yg = y ? y + (long)b * HW * ldy + g * cpg + q * VEC : nullptr;
   const long row0 = (long)b * HW;
   const int col = g * cpg + q * VEC;
   float k0;  // shift for the sums, common to the workgroup (see gn_stats_partial_kernel: never through the aliasable residual)
@@ -736,7 +739,11 @@ __global__ __launch_bounds__(GS_NT) void gn_small_fwd_kernel(const float* x, flo
     o[1] = cb[threadIdx.x] = bt - mean * gm * rstd;
     o[2] = gm;
     o[3] = mean;
+    float* ab = coef + (long)gridDim.y * C * 8 + ((long)b * C + c) * 2;  // compact copy behind bcoef (cgd_gn_ab)
+    ab[0] = o[0];
+    ab[1] = o[1];
   }
+  if (!y) return;  // statistics only: the consumer conv applies y = act(x * a + b) while it stages its input
   __syncthreads();
   if (!act_q) return;
   float a[VEC], bb[VEC];
@@ -998,10 +1005,17 @@ int pick_chunk(int HW, int B) {
 size_t cgd_gn_scratch_floats(int B, int HW, int C) {
   const int chunk = pick_chunk(HW, B);
   const int nchunk = cdiv(HW, chunk);
-  return (size_t)B * nchunk * 64 + (size_t)B * 64 + (size_t)B * C * 4 * 2;
+  return (size_t)B * nchunk * 64 + (size_t)B * 64 + (size_t)B * C * 4 * 2 + (size_t)B * C * 2;
 }
 
-// scratch layout: part | stats (B*64) | coef (B*C*4) | bcoef (B*C*4)
+// compact {a, b} pairs of the folded forward coefficients (y = act(x * a + b)): what the conv kernel's staging reads when the
+// normalisation is applied on the fly (hconv.hip, GemmParams::gn_ab)
+const float* cgd_gn_ab(const float* scratch, int B, int HW, int C) {
+  const int nchunk = cdiv(HW, pick_chunk(HW, B));
+  return scratch + (size_t)B * nchunk * 64 + (size_t)B * 64 + (size_t)B * C * 4 * 2;
+}
+
+// scratch layout: part | stats (B*64) | coef (B*C*4) | bcoef (B*C*4) | ab (B*C*2)
 static void gn_layout(float* scratch, int B, int HW, int C, int* chunk, int* nchunk, float** part, float** stats, float** coef,
                       float** bcoef) {
   *chunk = pick_chunk(HW, B);
@@ -1015,7 +1029,8 @@ static void gn_layout(float* scratch, int B, int HW, int C, int* chunk, int* nch
 int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma,
                       const float* beta, const float* film, int ldfilm, int act, float eps, float* scratch, hipStream_t s) {
   if (C % 32 || C > 4096) CGD_FAIL(ctx, "groupnorm: C must be a multiple of 32 and <= 4096");
-  if ((ldx & 3) || (ldy & 3)) CGD_FAIL(ctx, "groupnorm: row strides must be multiples of 4");
+  if ((ldx & 3) || (y && (ldy & 3))) CGD_FAIL(ctx, "groupnorm: row strides must be multiples of 4");
+  if (!y) ldy = 4;  // statistics only (y == nullptr): see cgd_gn_ab
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
@@ -1028,8 +1043,8 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
     CGD_TRY(cgd_flush_pending(ctx, s));
     src = SplitSrc();
   }
-  ProfRec pr;  // algorithmic HBM bytes of a GroupNorm forward: one read of x, one write of y
-  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, 8.0 * B * HW * C, s));
+  ProfRec pr;  // algorithmic HBM bytes of a GroupNorm forward: one read of x, one write of y; statistics only: the read
+  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (y ? 8.0 : 4.0) * B * HW * C, s));
   if (HW <= GN_SMALL_HW) {
     if (act)
       launch_gn_small_fwd<1>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s, src);
@@ -1043,10 +1058,12 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, (float*)x, ldx, HW, C, chunk, part, src);
   hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats, gamma, beta, film,
                      ldfilm, coef);
-  if (act)
-    hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
-  else
-    hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+  if (y) {
+    if (act)
+      hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+    else
+      hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+  }
   CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
   cgd_prof_push(ctx, &pr);
   CGD_HIP(ctx, hipGetLastError());

@@ -127,23 +127,36 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   const long npi = (long)B * H * W, npo = (long)B * Ho * Wo;
   CGD_TRY(u.ensure(s1, cgd_gn_scratch_floats(B, H * W, cin)));
   CGD_TRY(u.ensure(s2, cgd_gn_scratch_floats(B, Ho * Wo, cout)));
-  CGD_TRY(u.ensure(h1, npi * cin));
   CGD_TRY(u.ensure(h2, npo * cout));
-  CGD_TRY(u.ensure(h3, npo * cout));
   if (!dst.p) CGD_TRY(u.ensure(out, npo * cout));
   float* const outp = dst.p ? dst.p : out.p;
   const int ldo = dst.p ? dst.ld : cout;
-  // in_layers: GN -> SiLU
-  CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, h1.p, cin, B, H * W, cin, g1, b1, nullptr, 0, 1, 1e-5f, s1.p, s));
-  const float* conv_in = h1.p;
+  // conv1 (the nearest-2x upsample of an `up` block is folded into the conv's gather)
+  GemmParams c1;
+  c1.B = cw1f; c1.Bpk = cw1fp; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
+  c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
+  c1.defer = 1;  // a split-K launch leaves its slices for the GroupNorm right below (SplitSrc)
+  // in_layers: GN -> SiLU.  When conv1 runs on the halo kernel (and nothing else reads the normalised tensor: `down` blocks
+  // pool it first) the kernel applies SiLU(GN(x)) while it stages its input: only the statistics pass runs here and h1 is
+  // never materialised.
+  c1.A = x.p; c1.lda = x.ld;
+  const bool fuse1 = !down && cgd_conv_uses_hconv(ctx, c1);
   const float* skip_src = x.p;
   int skip_ld = x.ld;
+  if (fuse1) {
+    CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, nullptr, 0, B, H * W, cin, g1, b1, nullptr, 0, 1, 1e-5f, s1.p, s));
+    c1.gn_ab = cgd_gn_ab(s1.p, B, H * W, cin);
+  } else {
+    CGD_TRY(u.ensure(h1, npi * cin));
+    CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, h1.p, cin, B, H * W, cin, g1, b1, nullptr, 0, 1, 1e-5f, s1.p, s));
+    c1.A = h1.p; c1.lda = cin;
+  }
   if (down) {
     CGD_TRY(u.ensure(h1p, npo * cin));
     CGD_TRY(u.ensure(xr, npo * cin));
     CGD_TRY(cgd_launch_pool2x2(ctx, h1.p, cin, h1p.p, cin, nullptr, 0, B, Ho, Wo, cin, 0.25f, s));
     CGD_TRY(cgd_launch_pool2x2(ctx, x.p, x.ld, xr.p, cin, nullptr, 0, B, Ho, Wo, cin, 0.25f, s));
-    conv_in = h1p.p;
+    c1.A = h1p.p; c1.lda = cin;
     skip_src = xr.p;
     skip_ld = cin;
   } else if (up) {
@@ -152,15 +165,23 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
     skip_src = xr.p;
     skip_ld = cin;
   }
-  // conv1 (the nearest-2x upsample of an `up` block is folded into the conv's gather)
-  GemmParams c1;
-  c1.A = conv_in; c1.lda = cin; c1.B = cw1f; c1.Bpk = cw1fp; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
-  c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
-  c1.defer = 1;  // a split-K launch leaves its slices for the GroupNorm right below (SplitSrc)
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
-  // out_layers: GN * (1+scale) + shift -> SiLU -> conv2 (+ skip)
-  CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, h3.p, cout, B, Ho * Wo, cout, g2, b2, u.emb_all.p + emb_off, (int)u.emb_total, 1, 1e-5f,
-                            s2.p, s));
+  // out_layers: GN * (1+scale) + shift -> SiLU -> conv2 (+ skip); same on-the-fly application when conv2 runs on the halo kernel
+  GemmParams c2;
+  c2.A = h2.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2;
+  c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
+  c2.defer = 1;  // the next module starts with a GroupNorm of this tensor (or the launcher flushes: concat inputs, the head)
+  const bool fuse2 = cgd_conv_uses_hconv(ctx, c2);
+  if (fuse2) {
+    CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, nullptr, 0, B, Ho * Wo, cout, g2, b2, u.emb_all.p + emb_off, (int)u.emb_total, 1, 1e-5f,
+                              s2.p, s));
+    c2.gn_ab = cgd_gn_ab(s2.p, B, Ho * Wo, cout);
+  } else {
+    CGD_TRY(u.ensure(h3, npo * cout));
+    CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, h3.p, cout, B, Ho * Wo, cout, g2, b2, u.emb_all.p + emb_off, (int)u.emb_total, 1, 1e-5f,
+                              s2.p, s));
+    c2.A = h3.p;
+  }
   const float* R = skip_src;
   int ldr = skip_ld;
   if (skip_conv) {
@@ -172,10 +193,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
     R = outp;
     ldr = ldo;
   }
-  GemmParams c2;
-  c2.A = h3.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2; c2.R = R; c2.ldr = ldr;
-  c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
-  c2.defer = 1;  // the next module starts with a GroupNorm of this tensor (or the launcher flushes: concat inputs, the head)
+  c2.R = R; c2.ldr = ldr;
   CGD_TRY(cgd_launch_gemm(ctx, c2, s));
   Hh = Ho; Ww = Wo;
   *o = TV{outp, ldo, cout};
