@@ -64,17 +64,7 @@ class _Visual:
         self.tower = tower
 
 
-class _EncodeImageFunction(th.autograd.Function):
-    """tower.encode_image as an autograd node; backward = the tower's hand-derived backward-to-image of its LAST forward."""
-
-    @staticmethod
-    def forward(ctx, image, tower):
-        ctx.tower, ctx.in_shape = tower, tuple(image.shape)
-        return tower.encode_image(image.detach().float().contiguous())
-
-    @staticmethod
-    def backward(ctx, d_emb):
-        return ctx.tower.dgrad(d_emb.float().contiguous()).view(ctx.in_shape), None
+_EncodeImageFunction = _nets.EncodeImageFunction  # autograd node over cgd_*_forward / cgd_*_dgrad
 
 
 class ClipModel:

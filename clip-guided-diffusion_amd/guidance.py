@@ -9,6 +9,8 @@ gradient in closed form through the C ABI:
 Cutout coordinates are drawn exactly like the reference does (three CPU-generator draws per cutout,
 /root/reference/cgd/modules.py:44-46).
 """
+import math
+
 import torch as th
 import torch.nn.functional as F
 
@@ -33,15 +35,89 @@ def crop_geometry(coords, H, W):
     return [(oy, ox, max(0, min(size, H - oy)), max(0, min(size, W - ox))) for (ox, oy, size) in coords]
 
 
+def _sample_grid(x, xi, yi, mode):
+    """x (N,C,H,W) sampled at input pixel-centre coordinates (xi, yi) of shape (H,W) each; zeros outside (torchvision fill=0)."""
+    _, _, H, W = x.shape
+    grid = th.stack([xi / (W / 2), yi / (H / 2)], dim=-1).unsqueeze(0).expand(x.shape[0], -1, -1, -1)
+    return F.grid_sample(x, grid.to(x.dtype), mode=mode, padding_mode="zeros", align_corners=False)
+
+
+def aug_affine(x, angle_deg, tx, ty):
+    """torchvision.transforms.functional.affine(x, angle, (tx, ty), scale=1, shear=0), NEAREST, fill 0: rotation about the image
+    centre (positive = counter-clockwise), then translation; expressed as the inverse map output pixel -> input pixel."""
+    _, _, H, W = x.shape
+    ys, xs = th.meshgrid(th.arange(H, device=x.device, dtype=th.float32) + 0.5 - H / 2,
+                         th.arange(W, device=x.device, dtype=th.float32) + 0.5 - W / 2, indexing="ij")
+    a = math.radians(angle_deg)
+    xo, yo = xs - tx, ys - ty
+    xi = math.cos(a) * xo - math.sin(a) * yo
+    yi = math.sin(a) * xo + math.cos(a) * yo
+    return _sample_grid(x, xi, yi, "nearest")
+
+
+def aug_perspective(x, startpoints, endpoints):
+    """torchvision.transforms.functional.perspective(x, startpoints, endpoints), BILINEAR, fill 0: the homography that takes the
+    `endpoints` (output corners) to the `startpoints` (input corners), solved like torchvision's _get_perspective_coeffs."""
+    _, _, H, W = x.shape
+    A = th.zeros(8, 8, dtype=th.float64)
+    for i, ((x1, y1), (x2, y2)) in enumerate(zip(endpoints, startpoints)):
+        A[2 * i] = th.tensor([x1, y1, 1, 0, 0, 0, -x2 * x1, -x2 * y1], dtype=th.float64)
+        A[2 * i + 1] = th.tensor([0, 0, 0, x1, y1, 1, -y2 * x1, -y2 * y1], dtype=th.float64)
+    b = th.tensor([c for p in startpoints for c in p], dtype=th.float64)
+    co = th.linalg.lstsq(A, b).solution.float().tolist()
+    ys, xs = th.meshgrid(th.arange(H, device=x.device, dtype=th.float32) + 0.5, th.arange(W, device=x.device, dtype=th.float32) + 0.5,
+                         indexing="ij")
+    den = co[6] * xs + co[7] * ys + 1.0
+    xi = (co[0] * xs + co[1] * ys + co[2]) / den - W / 2
+    yi = (co[3] * xs + co[4] * ys + co[5]) / den - H / 2
+    return _sample_grid(x, xi, yi, "bilinear")
+
+
+def aug_grayscale(x):
+    """torchvision rgb_to_grayscale with 3 output channels (ITU-R 601-2 luma)."""
+    gray = 0.2989 * x[:, 0:1] + 0.587 * x[:, 1:2] + 0.114 * x[:, 2:3]
+    return gray.expand(-1, 3, -1, -1)
+
+
+def reference_augs(x):
+    """The reference's `use_augs` pipeline (/root/reference/cgd/modules.py:13-24) on one batched cutout (N,3,h,w):
+    RandomHorizontalFlip(0.5), RandomAffine(degrees=15, translate=(0.1, 0.1)), RandomPerspective(0.4, p=0.7),
+    RandomGrayscale(0.15), each followed by additive N(0, 0.01^2) noise.  Restated with plain torch ops (differentiable through
+    grid_sample); the parameter draws follow torchvision's order on the global CPU generator (one draw set per call, shared by
+    the batch, like a torchvision transform on a batched tensor).  torchvision is not installed in the build environment, so the
+    stream equivalence with its own `get_params` is by construction, not pinned by a fixture."""
+    _, _, H, W = x.shape
+    noise = lambda t: t + th.randn_like(t) * 0.01  # noqa: E731
+    if th.rand(1).item() < 0.5:
+        x = x.flip(-1)
+    x = noise(x)
+    angle = float(th.empty(1).uniform_(-15.0, 15.0).item())
+    tx = int(round(th.empty(1).uniform_(-0.1 * W, 0.1 * W).item()))
+    ty = int(round(th.empty(1).uniform_(-0.1 * H, 0.1 * H).item()))
+    x = noise(aug_affine(x, angle, tx, ty))
+    if th.rand(1).item() < 0.7:
+        hw, hh = W // 2, H // 2
+        d = 0.4
+        tl = [int(th.randint(0, int(d * hw) + 1, (1,)).item()), int(th.randint(0, int(d * hh) + 1, (1,)).item())]
+        tr = [int(th.randint(W - int(d * hw) - 1, W, (1,)).item()), int(th.randint(0, int(d * hh) + 1, (1,)).item())]
+        br = [int(th.randint(W - int(d * hw) - 1, W, (1,)).item()), int(th.randint(H - int(d * hh) - 1, H, (1,)).item())]
+        bl = [int(th.randint(0, int(d * hw) + 1, (1,)).item()), int(th.randint(H - int(d * hh) - 1, H, (1,)).item())]
+        x = aug_perspective(x, [[0, 0], [W - 1, 0], [W - 1, H - 1], [0, H - 1]], [tl, tr, br, bl])
+    x = noise(x)
+    if th.rand(1).item() < 0.15:
+        x = aug_grayscale(x)
+    return noise(x)
+
+
 class MakeCutouts(th.nn.Module):
     """Drop-in for cgd.modules.MakeCutouts (modules.py:5-66): same constructor, forward(input, use_cache,
     num_cutouts_override) and cache_coordinates(side_x, side_y); the crop+pool runs in one HIP kernel.
-    `use_augs` is accepted for signature parity; the reference CLI hard-codes it to False (cgd.py:402)."""
+    `use_augs=True` (Python API only: the reference CLI hard-codes False, cgd.py:402) applies the reference's augmentation
+    pipeline to every crop before pooling; that path is plain differentiable torch ops (`reference_augs`), not a HIP kernel."""
 
     def __init__(self, cut_size, num_cutouts, cutout_size_power=1.0, use_augs=False, ctx=None):
         super().__init__()
-        if use_augs:
-            raise NotImplementedError("torchvision augmentations are outside the MI355X hot path (cgd.py:402 disables them)")
+        self.augs = reference_augs if use_augs else None
         self.cut_size, self.cutn, self.cut_pow = cut_size, num_cutouts, cutout_size_power
         self.cached_coords = None
         self.ctx = ctx
@@ -59,15 +135,25 @@ class MakeCutouts(th.nn.Module):
     def forward(self, input, use_cache=False, num_cutouts_override=None):
         """input (B,3,H,W) in [0,1] -> (cutn*B,3,cut,cut) NCHW, *not* normalised (as in the reference).  Differentiable: when
         `input` requires grad the result is an autograd node whose backward is the cutout scatter kernel (cgd_cutouts_bwd)."""
-        if self.ctx is None:
-            self.ctx = L.Context(input.device.index or 0)
         _, _, H, W = input.shape
         coords = self.draw(H, W, use_cache, num_cutouts_override)  # (side_x, side_y) = (H, W): reference naming
         self.last_coords = coords
+        if self.augs is not None:
+            return self.augmented(input, coords)
+        if self.ctx is None:
+            self.ctx = L.Context(input.device.index or 0)
         geo = th.tensor(crop_geometry(coords, H, W), dtype=th.int32, device=input.device)
         if input.requires_grad and th.is_grad_enabled():
             return _CutoutsFunction.apply(input, self, geo, len(coords))
         return self._pool(input, geo, len(coords))
+
+    def augmented(self, input, coords):
+        """crop -> augment -> adaptive average pool -> cat, as modules.py:58-66 does with `self.augs` set: torch ops with autograd."""
+        outs = []
+        for ox, oy, size in coords:
+            cut = self.augs(input[:, :, oy:oy + size, ox:ox + size])
+            outs.append(F.adaptive_avg_pool2d(cut, self.cut_size))
+        return th.cat(outs)
 
     def _pool(self, input, geo, ncut):
         B, _, H, W = input.shape
@@ -253,7 +339,11 @@ class ClipGuidance:
                                                       loss=self._b("lpips_loss", (B,), dev))
             acc = 1
         clip_part = self._b("clip_part", (len(self.towers) * N,), dev)
+        if self.make_cutouts.augs is not None:
+            self._clip_leg_with_augs(x_in, coords, wm, gclip, clip_part, acc)
         for k, (tower, targets) in enumerate(zip(self.towers, self.targets_list)):
+            if self.make_cutouts.augs is not None:
+                break
             cs, patch = tower.input_resolution, tower.patch
             if patch:  # ViT towers: the cutout kernel writes the patch rows of the patch-embedding GEMM directly (layout 1)
                 gsz = cs // patch
@@ -287,6 +377,34 @@ class ClipGuidance:
                                   int(self.use_magnitude), self.scalars.data_ptr(), s))
         self._keep = geo
         return g
+
+    def _clip_leg_with_augs(self, x_in, coords, wm, gclip, clip_part, accumulate):
+        """`use_augs=True`: the augmentations sit between the crop and the pool, so the closed-form cutout adjoint does not
+        apply; this leg follows the reference recipe (cgd.py:190-204) with torch autograd — crop / augment / pool / normalise in
+        torch, the CLIP tower as the autograd node over cgd_*_forward / _dgrad — and hands d(CLIP loss)/d x_in to the native chain."""
+        from .nets import EncodeImageFunction
+        B = x_in.shape[0]
+        mean = th.tensor(CLIP_MEAN, device=x_in.device).view(1, 3, 1, 1)
+        std = th.tensor(CLIP_STD, device=x_in.device).view(1, 3, 1, 1)
+        with th.enable_grad():
+            xr = x_in.detach().requires_grad_()
+            total = 0
+            for tower, targets in zip(self.towers, self.targets_list):
+                mk = MakeCutouts(tower.input_resolution, len(coords), self.make_cutouts.cut_pow, use_augs=True)
+                cut = mk.augmented(xr.add(1).div(2), coords)
+                emb = EncodeImageFunction.apply(((cut - mean) / std).contiguous(), tower).view(len(coords), B, 1, -1)
+                en = F.normalize(emb, dim=-1)
+                d = (en - targets.view(1, 1, -1, targets.shape[-1])).norm(dim=-1).div(2).arcsin().pow(2).mul(2)  # (cutn, B, P)
+                total = total + (d * wm.view(1, B, -1)).sum(2).mean(0).sum() * self.cgs
+                if tower is self.towers[0]:
+                    self.emb = emb.detach().view(len(coords) * B, -1)
+            g_in, = th.autograd.grad(total, xr)
+        if accumulate:
+            gclip.add_(g_in)
+        else:
+            gclip.copy_(g_in)
+        clip_part.zero_()
+        clip_part[0] = total.detach()
 
     def snapshot(self):
         """Asynchronous host copies of the last call's scalars: `log(snapshot)` later costs no wait on newer GPU work."""

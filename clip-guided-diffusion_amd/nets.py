@@ -189,6 +189,19 @@ class ClipImageTower(_Net):
         return d_img
 
 
+class EncodeImageFunction(th.autograd.Function):
+    """tower.encode_image as an autograd node; backward = the tower's hand-derived backward-to-image of its LAST forward."""
+
+    @staticmethod
+    def forward(ctx, image, tower):
+        ctx.tower, ctx.in_shape = tower, tuple(image.shape)
+        return tower.encode_image(image.detach().float().contiguous())
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        return ctx.tower.dgrad(d_emb.float().contiguous()).view(ctx.in_shape), None
+
+
 RN_CONFIGS = {
     # name: (resolution, width, layers, out_dim, heads)   (clip/model.py ModifiedResNet)
     "RN50": (224, 64, (3, 4, 6, 3), 1024, 32),

@@ -527,3 +527,39 @@ def test_clip_architecture_inference_from_state_dict_shapes():
         else:
             res, width, layers, out, heads = clip_util._rn_config_from_state_dict(sd)
             assert (res, width, tuple(layers), out, heads) == tuple(nets.RN_CONFIGS[name]), name
+
+
+def test_use_augs_pipeline_ops_match_their_torchvision_definitions():
+    """`use_augs=True` (reference modules.py:13-24): the torch-op restatements of the torchvision transforms the reference composes —
+    affine (rotation about the centre + integer translation, NEAREST, fill 0), perspective (homography from 4 corner pairs, BILINEAR),
+    grayscale (ITU-R 601-2) — checked on their defining special cases; MakeCutouts(use_augs=True) is differentiable and draws its
+    parameters from the global CPU generator (same seed -> same augmented cutouts)."""
+    import cgd_amd  # noqa: F401
+    from cgd_amd import guidance as dg
+    x = th.rand(2, 3, 40, 40, generator=th.Generator().manual_seed(1))
+    assert th.allclose(dg.aug_affine(x, 0.0, 0, 0), x, atol=1e-6)
+    t = dg.aug_affine(x, 0.0, 3, -2)                                   # output[y][x] = input[y + 2][x - 3], zeros shifted in
+    assert th.allclose(t[:, :, 5, 10], x[:, :, 7, 7]) and float(t[:, :, :, :3].abs().max()) == 0.0
+    assert th.allclose(dg.aug_affine(x, 90.0, 0, 0), th.rot90(x, 1, (2, 3)), atol=1e-6)  # positive angle = counter-clockwise
+    corners = [[0, 0], [39, 0], [39, 39], [0, 39]]
+    assert th.allclose(dg.aug_perspective(x, corners, corners), x, atol=1e-4)
+    ramp = (th.arange(40.0).view(1, 1, 1, 40) / 40).expand(1, 3, 40, 40).contiguous()
+    shrunk = dg.aug_perspective(ramp, corners, [[4, 4], [35, 4], [35, 35], [4, 35]])   # content pulled inwards, zero border
+    assert float(shrunk[:, :, :3, :3].abs().max()) == 0.0
+    assert abs(float(shrunk[0, 0, 20, 20]) - ((20 - 4) * 39 / 31) / 40) < 0.02         # output x = 20 reads input x = (20-4)*39/31
+    g = dg.aug_grayscale(x)
+    assert th.allclose(g[:, 0], 0.2989 * x[:, 0] + 0.587 * x[:, 1] + 0.114 * x[:, 2]) and th.equal(g[:, 0], g[:, 2])
+    outs = []
+    for _ in range(2):
+        th.manual_seed(5)
+        mk = dg.MakeCutouts(16, 3, use_augs=True)
+        xr = x.clone().requires_grad_()
+        out = mk(xr)
+        assert out.shape == (6, 3, 16, 16) and out.requires_grad
+        out.square().sum().backward()
+        assert float(xr.grad.abs().sum()) > 0
+        outs.append(out.detach())
+    assert th.equal(outs[0], outs[1])
+    th.manual_seed(5)
+    plain = dg.MakeCutouts.augmented(dg.MakeCutouts(16, 3, use_augs=True), x, mk.last_coords)
+    assert not th.equal(plain, outs[0])  # a different position in the RNG stream gives different augmentations
