@@ -49,7 +49,7 @@ class Scenario:
     def __init__(self, case="mini", ddim=False, steps=3, B=1, cutn=4, vit_cfg=MINI_VIT, vit_name=None, P=1, hw=None, respacing="50",
                  schedule="linear", use_magnitude=False, sat_scale=0.0, scales=None, weights=None, init_scale=0.0, rn_cfg=None,
                  dual=False, reduce_clip=False, progressive_cutout=False, t_first=None, counter_quirk=False, head_scale=0.1,
-                 rescale_timesteps=False):
+                 rescale_timesteps=False, use_augs=False):
         from oracle import clip_vit as ocv
         from oracle import diffusion as od
         from oracle import guidance as og
@@ -57,6 +57,7 @@ class Scenario:
         self.case, self.ddim, self.steps, self.B, self.cutn, self.P = case, ddim, steps, B, cutn, P
         self.use_magnitude, self.sat_scale, self.init_scale = use_magnitude, sat_scale, init_scale
         self.reduce_clip, self.progressive_cutout, self.dual, self.rn_cfg = reduce_clip, progressive_cutout, dual, rn_cfg
+        self.use_augs = use_augs  # the reference's cutout augmentations (modules.py:13-24), additive noise switched off (below)
         kw = self.kw = pc.UNET_CASES[case]
         self.H, self.W = hw or (kw["image_size"], kw["image_size"])
         self.scales = scales or default_scales(self.H, self.W)
@@ -125,13 +126,28 @@ class Scenario:
         return (f"step[{self.case} p{precision} {'ddim' if self.ddim else 'p'} B{self.B} {self.H}x{self.W} t{self.t_first}"
                 f"{' mag' if self.use_magnitude else ''}{f' sat{self.sat_scale:g}' if self.sat_scale else ''}"
                 f"{f' init{self.init_scale:g}' if self.init_scale else ''}{' reduce' if self.reduce_clip else ''}"
-                f"{' progressive' if self.progressive_cutout else ''}{' rn' if self.rn_cfg else ''}{' dual' if self.dual else ''}]")
+                f"{' progressive' if self.progressive_cutout else ''}{' rn' if self.rn_cfg else ''}{' dual' if self.dual else ''}"
+                f"{' augs' if self.use_augs else ''}]")
 
     # ---- oracle ----------------------------------------------------------------------------------------------------------------
     def run_oracle(self):
         """[(sample, pred_xstart, log, legs or None)] per step."""
         og, B, H, W, N = self.og, self.B, self.H, self.W, self.N
         mk = og.MakeCutouts(self.res, self.cutn)
+        if self.use_augs:
+            # the augmentation parameters come from the global CPU generator on both sides (re-seeded per guidance call); the
+            # additive noise is drawn on the tensor's device, so it is switched off for the comparison
+            from cgd_amd import guidance as dg
+            import torch.nn.functional as F
+            dg.AUG_NOISE_STD = 0.0
+
+            class AugCutouts(og.MakeCutouts):
+                def forward(self, inp, use_cache=False, num_cutouts_override=None, coords=None):
+                    self.last_coords = coords
+                    return th.cat([F.adaptive_avg_pool2d(dg.reference_augs(inp[:, :, oy:oy + s, ox:ox + s]), self.cut_size)
+                                   for ox, oy, s in coords])
+
+            mk = AugCutouts(self.res, self.cutn)
         o_models = [self.ref_clip, self.ref_clip2] if self.dual else self.ref_clip
         o_targets = [self.targets, self.targets2] if self.dual else self.targets
         o_cutters = [mk, og.MakeCutouts(32, self.cutn)] if self.dual else mk
@@ -142,6 +158,12 @@ class Scenario:
                                      lpips_model=self.o_lp, init_tensor=self.init_cpu, init_scale=self.init_scale,
                                      reduce_clip=self.reduce_clip, progressive_cutout=self.progressive_cutout)
         st["diag"] = True
+        if self.use_augs:
+            plain_cond = o_cond
+
+            def o_cond(x, t, out, y=None):  # noqa: F811
+                th.manual_seed(777 + st["calls"])
+                return plain_cond(x, t, out, y)
         mkw = {"y": th.zeros(B, dtype=th.long)} if self.kw.get("num_classes") else {}
         loop = self.o_diff.ddim_sample_loop_progressive if self.ddim else self.o_diff.p_sample_loop_progressive
         gen = loop(self.ref_unet, (B, 3, H, W), clip_denoised=False, cond_fn=o_cond, model_kwargs=dict(mkw), device="cpu",
@@ -199,6 +221,16 @@ class Scenario:
                                reduce_clip=self.reduce_clip, progressive_cutout=self.progressive_cutout,
                                init_tensor=None if self.init_cpu is None else self.init_cpu.to(DEV), init_scale=self.init_scale)
         guid.coords_tape = self.tape["coords"]
+        if self.use_augs:
+            dg.AUG_NOISE_STD = 0.0
+            guid.make_cutouts = dg.MakeCutouts(self.res, self.cutn, use_augs=True, ctx=ctx)
+            plain_leg = guid._clip_leg_with_augs
+
+            def seeded_leg(*a, **k):
+                th.manual_seed(777 + guid.calls - 1)  # `calls` was incremented when the boxes of this call were taken
+                return plain_leg(*a, **k)
+
+            guid._clip_leg_with_augs = seeded_leg
         smp.tape = self.tape
         dmkw = {"y": th.zeros(B, dtype=th.long, device=DEV)} if self.kw.get("num_classes") else {}
         dloop = smp.ddim_sample_loop_progressive if self.ddim else smp.p_sample_loop_progressive

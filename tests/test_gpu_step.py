@@ -290,19 +290,28 @@ def test_launcher_shards_the_batch_like_the_single_process_run(tmp_path, monkeyp
         assert np.abs(fa - fb).max() <= 1 and (fa != fb).mean() < 1e-2, (a, np.abs(fa - fb).max(), (fa != fb).mean())
 
 
-def test_dropin_generator_with_use_augs(tmp_path, monkeypatch):
-    """`use_augs=True` through the Python API (reference cgd.py:107-109, modules.py:13-24): crops are augmented with torch ops
-    before pooling and the CLIP leg of the gradient comes from autograd over the C-ABI tower node; TV / range / UNet legs stay
-    native.  The run must produce finite frames that differ from the un-augmented run with the same seed."""
+def test_use_augs_guided_steps_against_the_oracle():
+    """`use_augs=True` (reference cgd.py:107-109, modules.py:13-24): crops are augmented (flip / affine / perspective /
+    grayscale as torch ops) before pooling and the CLIP leg of the gradient comes from autograd over the C-ABI tower node; the
+    TV / range / UNet legs stay native.  Against the CPU oracle running the same augmentation ops with the same per-call CPU
+    seed (the additive noise is drawn on the tensor's device and is switched off for the comparison); the nearest-neighbour
+    affine resampling makes g piecewise constant in the crop, hence the literal tolerance applies."""
+    from cgd_amd import guidance as dg
+    try:
+        _assert_all(sc.check_step("mini", 1, steps=2, B=2, use_augs=True))
+    finally:
+        dg.AUG_NOISE_STD = 0.01
+
+
+def test_dropin_generator_accepts_use_augs(tmp_path, monkeypatch):
+    """The Python-API switch end to end (noise on): finite frames are produced and yielded in order."""
     import numpy as np
     from PIL import Image
     monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
     monkeypatch.chdir(tmp_path)
     from cgd.cgd import clip_guided_diffusion
-    kw = dict(prompts=["Loose seal."], image_size=64, batch_size=1, num_cutouts=4, timestep_respacing="6", noise_schedule="cosine",
-              checkpoints_dir=str(tmp_path / "ckpt"), save_frequency=5, progress=False, device="cuda", seed=2, clip_guidance_scale=2000)
-    a = list(clip_guided_diffusion(prefix_path=str(tmp_path / "aug"), use_augs=True, **kw))
-    b = list(clip_guided_diffusion(prefix_path=str(tmp_path / "plain"), use_augs=False, **kw))
-    assert [x[0] for x in a] == [x[0] for x in b] and len(a) >= 1
-    fa, fb = np.asarray(Image.open(a[-1][1])).astype(int), np.asarray(Image.open(b[-1][1])).astype(int)
-    assert fa.shape == (64, 64, 3) and (fa != fb).any()
+    items = list(clip_guided_diffusion(prompts=["Loose seal."], image_size=64, batch_size=1, num_cutouts=4, timestep_respacing="4",
+                                       noise_schedule="cosine", prefix_path=str(tmp_path / "aug"), checkpoints_dir=str(tmp_path / "ckpt"),
+                                       save_frequency=1, progress=False, device="cuda", seed=2, use_augs=True))
+    assert [b for b, _ in items] == [0, 0, 0, 0]
+    assert np.asarray(Image.open(items[-1][1])).shape == (64, 64, 3)
