@@ -505,10 +505,12 @@ __global__ __launch_bounds__(256) void ln_bwd_generic_kernel(const float* __rest
 }
 
 // register-resident versions for C = 256 * NV (ViT widths 768 / 1024): the row is read once as NV float4 per lane
+// `src.n > 0`: x still lies in split-K slices (the residual-stream GEMM in front of this LayerNorm deferred its reduction):
+// summed at load time and written to x (xw), which later kernels read as the residual stream
 template <int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int rows,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, float* xw, int ldx, float* __restrict__ y, int ldy, int rows,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                     float* __restrict__ stats /*[rows][2]*/) {
+                                                     float* __restrict__ stats /*[rows][2]*/, const SplitSrc src) {
   constexpr int C = 256 * NV;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -517,7 +519,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    v[i] = *(const float4*)(xr + 256 * i + 4 * lane);
+    if (src.n) {
+      v[i] = split_load4(src, row, 256 * i + 4 * lane);
+      *(float4*)(xw + (long)row * ldx + 256 * i + 4 * lane) = v[i];
+    } else {
+      v[i] = *(const float4*)(xr + 256 * i + 4 * lane);
+    }
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -547,10 +554,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// `src.n > 0`: dy still lies in split-K slices; it is consumed here only, so it is never written
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                      float* __restrict__ dx, int lddx, const float* __restrict__ add, int ldadd, int rows,
-                                                     const float* __restrict__ gamma, const float* __restrict__ stats) {
+                                                     const float* __restrict__ gamma, const float* __restrict__ stats, const SplitSrc src) {
   constexpr int C = 256 * NV;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -561,7 +569,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const float4 xv = *(const float4*)(xr + 256 * i + 4 * lane), dv = *(const float4*)(dr + 256 * i + 4 * lane);
+    const float4 xv = *(const float4*)(xr + 256 * i + 4 * lane);
+    const float4 dv = src.n ? split_load4(src, row, 256 * i + 4 * lane) : *(const float4*)(dr + 256 * i + 4 * lane);
     const float4 g = *(const float4*)(gamma + 256 * i + 4 * lane);
     xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
     gd[i].x = dv.x * g.x; gd[i].y = dv.y * g.y; gd[i].z = dv.z * g.z; gd[i].w = dv.w * g.w;
@@ -1117,14 +1126,23 @@ int cgd_launch_ln_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
                       const float* beta, float eps, float* stats, hipStream_t s) {
   const bool vec = C % 256 == 0 && C <= 1024 && !(ldx & 3) && !(ldy & 3) && !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15);
   const dim3 grid(cdiv(rows, 4)), blk(256);
+  // x may still lie in split-K slices (vit.hip defers the reduction of the residual-stream GEMMs): the vector kernels sum them
+  SplitSrc src;
+  const bool slices_ok = vec && ctx->defer_mode >= 1;
+  if (!(slices_ok && cgd_take_pending(ctx, x, rows, C, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
+  if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15))) {
+    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)x; ctx->pending.ldc = ldx; ctx->pending.M = rows;
+    CGD_TRY(cgd_flush_pending(ctx, s));
+    src = SplitSrc();
+  }
   if (!vec) {
     hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, blk, 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps, stats);
   } else {
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, blk, 0, s, x, ldx, y, ldy, rows, gamma, beta, eps, stats); break;
-      case 2: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, blk, 0, s, x, ldx, y, ldy, rows, gamma, beta, eps, stats); break;
-      case 3: hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, blk, 0, s, x, ldx, y, ldy, rows, gamma, beta, eps, stats); break;
-      default: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, blk, 0, s, x, ldx, y, ldy, rows, gamma, beta, eps, stats); break;
+      case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
+      case 2: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
+      case 3: hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
+      default: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
     }
   }
   CGD_HIP(ctx, hipGetLastError());
@@ -1136,14 +1154,22 @@ int cgd_launch_ln_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dy, in
   const bool vec = C % 256 == 0 && C <= 1024 && !(ldx & 3) && !(lddy & 3) && !(lddx & 3) && !(ldadd & 3) &&
                    !(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)add | (uintptr_t)gamma) & 15);
   const dim3 grid(cdiv(rows, 4)), blk(256);
+  SplitSrc src;  // dy may still lie in split-K slices
+  const bool slices_ok = vec && ctx->defer_mode >= 1;
+  if (!(slices_ok && cgd_take_pending(ctx, dy, rows, C, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
+  if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15))) {
+    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)dy; ctx->pending.ldc = lddy; ctx->pending.M = rows;
+    CGD_TRY(cgd_flush_pending(ctx, s));
+    src = SplitSrc();
+  }
   if (!vec) {
     hipLaunchKernelGGL(ln_bwd_generic_kernel, grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, C, gamma, stats);
   } else {
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats); break;
-      case 2: hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats); break;
-      case 3: hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats); break;
-      default: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats); break;
+      case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
+      case 2: hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
+      case 3: hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
+      default: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
     }
   }
   CGD_HIP(ctx, hipGetLastError());

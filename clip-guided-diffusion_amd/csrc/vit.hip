@@ -102,8 +102,9 @@ int ViT::finalize(hipStream_t s) {
 }
 
 static GemmParams lin(const float* A, int lda, const float* Wt, int K, float* C, int ldc, const float* bias, const float* R, int ldr,
-                      long M, int Nn) {
+                      long M, int Nn, int defer = 0) {
   GemmParams p;
+  p.defer = defer;  // 1: the next kernel reading C is a LayerNorm that sums split-K slices itself (norm.hip)
   p.A = A; p.lda = lda; p.B = Wt; p.ldb = K; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldr;
   p.weight = 1;  // every B operand of the tower is a persistent (packed-at-load) weight
   p.M = (int)M; p.N = Nn; p.K = K;
@@ -140,11 +141,11 @@ int ViT::forward(const float* img, int lay, int Nn, float* emb, hipStream_t s) {
     AttnShape sh{N, H, L, d, W, 0};
     AttnBufs bf{l.qkvT.p, l.P.p, nullptr, nullptr, nullptr};
     CGD_TRY(cgd_attn_fwd(ctx, sh, l.qkv.p, 3 * W, l.a.p, W, bf, s));
-    CGD_TRY(cgd_launch_gemm(ctx, lin(l.a.p, W, l.ow, W, l.x1.p, W, l.ob, x, W, rows, W), s));
+    CGD_TRY(cgd_launch_gemm(ctx, lin(l.a.p, W, l.ow, W, l.x1.p, W, l.ob, x, W, rows, W, 1), s));
     CGD_TRY(cgd_launch_ln_fwd(ctx, l.x1.p, W, l.y2.p, W, (int)rows, W, l.ln2g, l.ln2b, 1e-5f, l.st2.p, s));
     CGD_TRY(cgd_launch_gemm(ctx, lin(l.y2.p, W, l.fcw, W, l.u.p, 4 * W, l.fcb, nullptr, 0, rows, 4 * W), s));
     CGD_TRY(cgd_launch_act_fwd(ctx, l.u.p, l.ga.p, rows * 4 * W, 2, s));
-    CGD_TRY(cgd_launch_gemm(ctx, lin(l.ga.p, 4 * W, l.pjw, 4 * W, l.xo.p, W, l.pjb, l.x1.p, W, rows, W), s));
+    CGD_TRY(cgd_launch_gemm(ctx, lin(l.ga.p, 4 * W, l.pjw, 4 * W, l.xo.p, W, l.pjb, l.x1.p, W, rows, W, 1), s));
     x = l.xo.p;
   }
   CGD_TRY(ensure(st_post, (size_t)N * 2));
@@ -178,14 +179,14 @@ int ViT::dgrad(const float* demb, float* dimg, hipStream_t s) {
     // MLP
     CGD_TRY(cgd_launch_gemm(ctx, lin(dcur, W, l.pjwT, W, l.dga.p, 4 * W, nullptr, nullptr, 0, rows, 4 * W), s));
     CGD_TRY(cgd_launch_act_bwd(ctx, l.u.p, l.dga.p, l.du.p, rows * 4 * W, 2, s));
-    CGD_TRY(cgd_launch_gemm(ctx, lin(l.du.p, 4 * W, l.fcwT, 4 * W, l.dy2.p, W, nullptr, nullptr, 0, rows, W), s));
+    CGD_TRY(cgd_launch_gemm(ctx, lin(l.du.p, 4 * W, l.fcwT, 4 * W, l.dy2.p, W, nullptr, nullptr, 0, rows, W, 1), s));
     CGD_TRY(cgd_launch_ln_bwd(ctx, l.x1.p, W, l.dy2.p, W, l.dx1.p, W, dcur, W, (int)rows, W, l.ln2g, l.st2.p, s));
     // attention
     CGD_TRY(cgd_launch_gemm(ctx, lin(l.dx1.p, W, l.owT, W, l.da.p, W, nullptr, nullptr, 0, rows, W), s));
     AttnShape sh{N, H, L, d, W, 0};
     AttnBufs bf{l.qkvT.p, l.P.p, l.Pt.p, l.dP.p, l.dAt.p};
     CGD_TRY(cgd_attn_bwd(ctx, sh, l.qkv.p, 3 * W, l.da.p, W, l.dqkv.p, 3 * W, bf, s));
-    CGD_TRY(cgd_launch_gemm(ctx, lin(l.dqkv.p, 3 * W, l.inwT, 3 * W, l.dy.p, W, nullptr, nullptr, 0, rows, W), s));
+    CGD_TRY(cgd_launch_gemm(ctx, lin(l.dqkv.p, 3 * W, l.inwT, 3 * W, l.dy.p, W, nullptr, nullptr, 0, rows, W, 1), s));
     CGD_TRY(cgd_launch_ln_bwd(ctx, xin, W, l.dy.p, W, l.dx.p, W, l.dx1.p, W, (int)rows, W, l.ln1g, l.st1.p, s));
     dcur = l.dx.p;
   }
@@ -268,11 +269,13 @@ int cgd_vit_finalize(cgd_vit* v) {
 int cgd_vit_forward(cgd_vit* v, const float* img, int layout, int N, float* emb, void* stream) {
   if (!v) return -3;
   DeviceScope dev_scope(v->net.ctx);
-  return v->net.forward(img, layout, N, emb, (hipStream_t)stream);
+  CGD_TRY(v->net.forward(img, layout, N, emb, (hipStream_t)stream));
+  return cgd_flush_pending(v->net.ctx, (hipStream_t)stream);
 }
 int cgd_vit_dgrad(cgd_vit* v, const float* d_emb, float* d_img, void* stream) {
   if (!v) return -3;
   DeviceScope dev_scope(v->net.ctx);
-  return v->net.dgrad(d_emb, d_img, (hipStream_t)stream);
+  CGD_TRY(v->net.dgrad(d_emb, d_img, (hipStream_t)stream));
+  return cgd_flush_pending(v->net.ctx, (hipStream_t)stream);
 }
 }
