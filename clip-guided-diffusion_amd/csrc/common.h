@@ -63,6 +63,7 @@ struct cgd_ctx {
                       // bit 0 = 16x16 / 8 wavefronts everywhere, bit 1 = 16x16 below 16384 pixels, bit 2 = wavefront sub-tile
                       // 64 pixels x 64 channels instead of 128 x 32 (the kernel is power-limited: 128 x 32 moves half of the
                       // fragment traffic from the vector-memory path to the LDS, +1.2..1.8 % per layer at the 1.36 kW cap)
+  int hconv_small_m = 0, hconv_small_slots = 512, hconv_small_min_chunks = 2;  // optional separate split-K target for M <= hconv_small_m
   int hconv_slots = 0, hconv_min_chunks = 4;                 // split-K target of the halo conv: workgroup slots (0 = one per CU), chunks per slice
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   int fuse_gn = 1;     // 1: ResBlock convs on the halo kernel apply their GroupNorm + FiLM + SiLU while staging (A/B knob)

@@ -435,8 +435,12 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
     const int nchunk = p.Cin / 32;
     // split-K target: about one workgroup per CU and >= 4 chunks per slice (sweep r1bc: 2 per CU / 2 chunks 37.3 steps/s,
     // 1 per CU / 4 chunks 38.0-38.5, 0.75 per CU 38.7, 0.5 per CU 37.9): fewer, longer slices beat filling both resident slots
-    const long slots = ctx->hconv_slots > 0 ? ctx->hconv_slots : ctx->num_cu;
-    const int min_ch = ctx->hconv_min_chunks;
+    long slots = ctx->hconv_slots > 0 ? ctx->hconv_slots : ctx->num_cu;
+    int min_ch = ctx->hconv_min_chunks;
+    if (ctx->hconv_small_m > 0 && p.M <= ctx->hconv_small_m) {  // weight-streaming levels: more slices in flight (A/B knob)
+      slots = ctx->hconv_small_slots;
+      min_ch = ctx->hconv_small_min_chunks;
+    }
     if (auto_split && tiles < slots) {
       long want = std::min<long>(cdiv(slots, tiles), nchunk / min_ch);
       while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
