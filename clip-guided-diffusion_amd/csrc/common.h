@@ -66,6 +66,7 @@ struct cgd_ctx {
   int hconv_small_m = 0, hconv_small_slots = 512, hconv_small_min_chunks = 2;  // optional separate split-K target for M <= hconv_small_m
   int hconv_slots = 0, hconv_min_chunks = 4;                 // split-K target of the halo conv: workgroup slots (0 = one per CU), chunks per slice
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
   int fuse_gn = 1;     // 1: ResBlock convs on the halo kernel apply their GroupNorm + FiLM + SiLU while staging (A/B knob)
   int tile_order = 0;  // XCD tile order of hgemm2 / hconv2: 0 auto (weight-panel major when the weights are the larger operand),
                        // 1 always weight-panel (N) major, 2 always row-panel (M) major (A/B knob)
@@ -163,6 +164,12 @@ struct GemmParams {
   int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel
   int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
+  // weight GEMM on hgemm2 without split-K only (cgd_gemm_fuses_act): activation fused into the epilogue.
+  //   act_out: second output C2[m][n] = act(C[m][n]) (C keeps the pre-activation, the backward pass needs it);
+  //   act_in : C[m][n] = (alpha * acc + bias + R) * act'(U[m][n]) (backward through the activation whose input was U)
+  float* act_out = nullptr;
+  const float* act_in = nullptr;
+  int ld_act = 0, act = 0;  // act: 1 SiLU, 2 QuickGELU
   const float* gn_ab = nullptr;  // conv on the halo kernel only: apply SiLU(x * a + b) to the input while staging it; {a, b} pairs
                                  // [B][Cin][2] of the GroupNorm(+FiLM) that precedes the conv (kernels.h cgd_gn_ab)
   int defer = 0;       // 1: if the launch splits K, leave the slices in the workspace (ctx->pending): the caller guarantees that the
@@ -191,6 +198,8 @@ void cgd_frag_cache_clear(cgd_ctx* ctx);
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s);
 // would cgd_launch_gemm run this conv on the halo kernel (the only one that can apply a GroupNorm on the fly)?
 bool cgd_conv_uses_hconv(cgd_ctx* ctx, GemmParams p);
+// would cgd_launch_gemm run this GEMM on hgemm2 in one slice (the only path that fuses an activation into its epilogue)?
+bool cgd_gemm_fuses_act(cgd_ctx* ctx, GemmParams p);
 
 // thin direct convs for the 3-channel ends of the UNet
 int cgd_launch_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w /*[Cout][3][3][Cin] (co,ky,kx,ci)*/, const float* bias,

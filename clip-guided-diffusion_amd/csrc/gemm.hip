@@ -506,6 +506,15 @@ bool cgd_conv_uses_hconv(cgd_ctx* ctx, GemmParams p) {
   return ok;
 }
 
+bool cgd_gemm_fuses_act(cgd_ctx* ctx, GemmParams p) {
+  int tile = 0, kernel = 0;
+  const std::string keep = ctx->err;
+  const bool ok = !p.conv && ctx->fuse_act && ctx->hgemm_var != 0 && (long)p.M * p.lda < (1L << 31) &&
+                  cgd_plan_gemm(ctx, p, &tile, &kernel) == 0 && kernel == 2 && p.splitk == 1;
+  ctx->err = keep;
+  return ok;
+}
+
 int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s) {
   if (!ctx->pending.valid) return 0;
   const PendingReduce& q = ctx->pending;
@@ -533,6 +542,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   CGD_TRY(cgd_plan_gemm(ctx, p, &tile, &kernel));
   const bool use_h = kernel == 1, use_g = kernel == 2;
   if (p.gn_ab && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: only the halo conv kernel applies a GroupNorm on the fly (cgd_conv_uses_hconv)");
+  if ((p.act_out || p.act_in) && !(use_g && p.splitk == 1 && ctx->hgemm_var != 0))
+    CGD_FAIL(ctx, "cgd_launch_gemm: only hgemm2 in one slice fuses an activation into its epilogue (cgd_gemm_fuses_act)");
   if (p.splitk > 1) p.ws = ctx->ws;
   ProfRec pr;
   CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? CGD_PROF_HCONV : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));

@@ -29,6 +29,9 @@ struct HGemmParams {
   int lda, ldc, ldr;
   int M, N, K, splitk;
   float alpha;
+  float* act_out;       // hgemm2 epilogue: C2 = act(C) (GemmParams::act_out)
+  const float* act_in;  // hgemm2 epilogue: C = (...) * act'(U)
+  int ld_act, act;
   int nmajor;  // tile order within the XCD-contiguous runs: 0 = M-tile major (an XCD owns row panels and streams all weights),
                // 1 = N-tile major (an XCD owns weight column panels, read from HBM once and kept in its 4 MB L2; the small
                // activation matrix is what every XCD re-reads): chosen when the weights are the larger operand (N >= M)
@@ -474,13 +477,34 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
 #pragma unroll
       for (int g = 0; g < 4; ++g) rv[g] = *(const f32x4*)&Rg[row * p.ldr + cb0 + 8 * g + 4 * hh];
     }
+    f32x4 uv[4];
+    if (p.act_in) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) uv[g] = *(const f32x4*)&p.act_in[row * p.ld_act + cb0 + 8 * g + 4 * hh];
+    }
+    const float ka = p.act == 2 ? 1.702f : 1.f;  // QuickGELU x * sigmoid(1.702 x) / SiLU
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int col = cb0 + 8 * g + 4 * hh;
       f32x4 o = f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]} * p.alpha;
       if (biasg) o += f32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
       if (Rg) o += rv[g];
+      if (p.act_in) {  // backward through the activation: multiply by act'(u), same arithmetic as elem.hip dact_f
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sg = 1.f / (1.f + __expf(-ka * uv[g][e]));
+          d[e] = sg * (1.f + ka * uv[g][e] * (1.f - sg));
+        }
+        o *= d;
+      }
       *(f32x4*)&Cg[row * p.ldc + col] = o;
+      if (p.act_out) {  // second output: the activated tensor, same arithmetic as elem.hip act_f
+        f32x4 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = o[e] / (1.f + __expf(-ka * o[e]));
+        *(f32x4*)&p.act_out[row * p.ld_act + col] = a;
+      }
     }
   }
 }
@@ -572,6 +596,7 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.K = g.K; p.splitk = g.splitk; p.alpha = g.alpha;
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && g.N >= g.M)) ? 1 : 0;
+  p.act_out = g.act_out; p.act_in = g.act_in; p.ld_act = g.ld_act; p.act = g.act;
   const int tm = cgd_hgemm_tile_m(ctx, g);
   dim3 grid(cdiv(g.M, tm) * cdiv(g.N, GN), 1, g.splitk > 1 ? g.splitk : 1);
   const bool x3 = ctx->precision == CGD_PREC_BF16X3;

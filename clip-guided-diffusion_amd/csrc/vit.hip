@@ -143,8 +143,18 @@ int ViT::forward(const float* img, int lay, int Nn, float* emb, hipStream_t s) {
     CGD_TRY(cgd_attn_fwd(ctx, sh, l.qkv.p, 3 * W, l.a.p, W, bf, s));
     CGD_TRY(cgd_launch_gemm(ctx, lin(l.a.p, W, l.ow, W, l.x1.p, W, l.ob, x, W, rows, W, 1), s));
     CGD_TRY(cgd_launch_ln_fwd(ctx, l.x1.p, W, l.y2.p, W, (int)rows, W, l.ln2g, l.ln2b, 1e-5f, l.st2.p, s));
-    CGD_TRY(cgd_launch_gemm(ctx, lin(l.y2.p, W, l.fcw, W, l.u.p, 4 * W, l.fcb, nullptr, 0, rows, 4 * W), s));
-    CGD_TRY(cgd_launch_act_fwd(ctx, l.u.p, l.ga.p, rows * 4 * W, 2, s));
+    {
+      // c_fc + QuickGELU: the activation runs in the GEMM's epilogue where hgemm2 takes the launch in one slice (u is kept
+      // for the backward pass, ga feeds c_proj); otherwise the separate elementwise kernel
+      GemmParams fc = lin(l.y2.p, W, l.fcw, W, l.u.p, 4 * W, l.fcb, nullptr, 0, rows, 4 * W);
+      if (cgd_gemm_fuses_act(ctx, fc)) {
+        fc.act_out = l.ga.p; fc.ld_act = 4 * W; fc.act = 2;
+        CGD_TRY(cgd_launch_gemm(ctx, fc, s));
+      } else {
+        CGD_TRY(cgd_launch_gemm(ctx, fc, s));
+        CGD_TRY(cgd_launch_act_fwd(ctx, l.u.p, l.ga.p, rows * 4 * W, 2, s));
+      }
+    }
     CGD_TRY(cgd_launch_gemm(ctx, lin(l.ga.p, 4 * W, l.pjw, 4 * W, l.xo.p, W, l.pjb, l.x1.p, W, rows, W, 1), s));
     x = l.xo.p;
   }
@@ -177,8 +187,18 @@ int ViT::dgrad(const float* demb, float* dimg, hipStream_t s) {
     CGD_TRY(ensure(l.Pt, (size_t)N * H * L * Tp)); CGD_TRY(ensure(l.dP, (size_t)N * H * L * Tp));
     CGD_TRY(ensure(l.dAt, (size_t)N * W * Tp));
     // MLP
-    CGD_TRY(cgd_launch_gemm(ctx, lin(dcur, W, l.pjwT, W, l.dga.p, 4 * W, nullptr, nullptr, 0, rows, 4 * W), s));
-    CGD_TRY(cgd_launch_act_bwd(ctx, l.u.p, l.dga.p, l.du.p, rows * 4 * W, 2, s));
+    {
+      // d(c_proj) and the backward of QuickGELU: du = (dcur @ W_proj) * gelu'(u), fused like the forward
+      GemmParams pj = lin(dcur, W, l.pjwT, W, l.dga.p, 4 * W, nullptr, nullptr, 0, rows, 4 * W);
+      if (cgd_gemm_fuses_act(ctx, pj)) {
+        pj.C = l.du.p;
+        pj.act_in = l.u.p; pj.ld_act = 4 * W; pj.act = 2;
+        CGD_TRY(cgd_launch_gemm(ctx, pj, s));
+      } else {
+        CGD_TRY(cgd_launch_gemm(ctx, pj, s));
+        CGD_TRY(cgd_launch_act_bwd(ctx, l.u.p, l.dga.p, l.du.p, rows * 4 * W, 2, s));
+      }
+    }
     CGD_TRY(cgd_launch_gemm(ctx, lin(l.du.p, 4 * W, l.fcwT, 4 * W, l.dy2.p, W, nullptr, nullptr, 0, rows, W, 1), s));
     CGD_TRY(cgd_launch_ln_bwd(ctx, l.x1.p, W, l.dy2.p, W, l.dx1.p, W, dcur, W, (int)rows, W, l.ln2g, l.st2.p, s));
     // attention
