@@ -563,3 +563,112 @@ def test_use_augs_pipeline_ops_match_their_torchvision_definitions():
     th.manual_seed(5)
     plain = dg.MakeCutouts.augmented(dg.MakeCutouts(16, 3, use_augs=True), x, mk.last_coords)
     assert not th.equal(plain, outs[0])  # a different position in the RNG stream gives different augmentations
+
+
+def _fake_generator_env(monkeypatch, tmp_path, events, fail_at=None, gated=()):
+    """Shared fakes of the drop-in generator tests: recording sampler (optionally raising while step `fail_at` is enqueued) and a
+    guidance object whose `last_ran` is False on the `gated` steps (what ClipGuidance.native reports for --reduce-clip skips)."""
+    import types
+    from cgd import cgd as mine
+    from cgd import clip_util, script_util
+    monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.chdir(tmp_path)
+
+    class FakeTorch:
+        def __getattr__(self, k):
+            return getattr(th, k)
+
+        @staticmethod
+        def tensor(data, device=None, **kw):
+            return th.tensor(data, **kw)
+
+        @staticmethod
+        def zeros(shape, device=None, **kw):
+            return th.zeros(shape, **kw)
+
+    monkeypatch.setattr(mine, "th", FakeTorch())
+    tower = types.SimpleNamespace(ctx="ctx", input_resolution=16, out_dim=8, patch=8)
+    monkeypatch.setattr(clip_util, "load_clip", lambda name, device: (types.SimpleNamespace(tower=tower), 16))
+    monkeypatch.setattr(clip_util, "encode_text_prompt", lambda txt, w, name, device: (th.full((1, 8), float(len(txt))), w))
+    state = {}
+
+    class FakeDiffusion:
+        num_timesteps = 6
+
+        def p_sample_loop_progressive(self, model, shape, **kw):
+            for i in range(self.num_timesteps - kw["skip_timesteps"]):
+                if fail_at is not None and i == fail_at:
+                    raise RuntimeError("HIP error: device-side failure while enqueuing this step")
+                events.append(("enqueue", i))
+                state["guid"].last_ran = i not in gated
+                yield {"sample": th.zeros(shape), "pred_xstart": th.full(shape, -1.0 + 0.1 * i)}
+
+        ddim_sample_loop_progressive = p_sample_loop_progressive
+
+    monkeypatch.setattr(script_util, "load_guided_diffusion", lambda **kw: (types.SimpleNamespace(ctx="ctx"), FakeDiffusion()))
+
+    class FakeGuidance:
+        def __init__(self, *a, **kw):
+            self.scalars, self.current_timestep, self.n, self.last_ran = th.zeros(8), None, 0, True
+            state["guid"] = self
+
+        def snapshot(self):
+            self.n += 1
+            return self.n
+
+        def log(self, snap):
+            events.append(("log", snap))
+            return {"CLIP Loss": float(snap), "TV Loss": 0.5}
+
+    monkeypatch.setattr(mine, "ClipGuidance", FakeGuidance)
+    monkeypatch.setattr(script_util, "stage_images", lambda x: types.SimpleNamespace(get=lambda: script_util.to_uint8_hwc(x)))
+    return mine
+
+
+def test_generator_logs_nothing_on_gated_reduce_clip_steps(tmp_path, monkeypatch, capsys):
+    """with --reduce-clip the reference's cond_fn returns before any logging on the skipped steps (cgd.py:155-160), so a
+    gated step must neither snapshot the (stale) scalars nor print a loss line."""
+    events = []
+    mine = _fake_generator_env(monkeypatch, tmp_path, events, gated=(1, 2, 4))
+    list(mine.clip_guided_diffusion(prompts=["ab"], image_size=128, batch_size=1, num_cutouts=4, timestep_respacing="6",
+                                    prefix_path=str(tmp_path / "out"), checkpoints_dir=str(tmp_path / "ck"), save_frequency=100,
+                                    device="cuda", skip_timesteps=1, progress=True))
+    assert [e for e in events if e[0] == "enqueue"] == [("enqueue", i) for i in range(5)]
+    assert [e for e in events if e[0] == "log"] == [("log", 1), ("log", 2)]  # steps 0 and 3 only
+    assert len([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("CLIP Loss")]) == 2
+
+
+def test_generator_delivers_the_finished_step_when_the_next_one_fails(tmp_path, monkeypatch):
+    """the output path is pipelined by one timestep, so an error raised while step k+1 is being enqueued must not swallow
+    the already computed frame of step k: it is written and yielded first, then the error propagates (the unpipelined reference
+    would have saved step k before starting k+1)."""
+    events = []
+    mine = _fake_generator_env(monkeypatch, tmp_path, events, fail_at=2)
+    gen = mine.clip_guided_diffusion(prompts=["ab"], image_size=128, batch_size=1, num_cutouts=4, timestep_respacing="6",
+                                     prefix_path=str(tmp_path / "out"), checkpoints_dir=str(tmp_path / "ck"), save_frequency=1,
+                                     device="cuda", progress=False)
+    got = []
+    with pytest.raises(RuntimeError, match="device-side failure"):
+        for item in gen:
+            got.append(item)
+    assert [(b, os.path.basename(p)) for b, p in got] == [(0, "0000.png"), (0, "0001.png")]
+    assert all(os.path.isfile(p) for _, p in got)
+
+
+def test_oracle_ddim_yields_the_unconditioned_prediction():
+    """ADVICE r1 / [3P] crowsonkb/guided-diffusion `ddim_sample_with_grad`: the yielded `pred_xstart` is the UNCONDITIONED prediction
+    (`out_orig`), while the sample is built from the guidance-conditioned x0'.  A cond_fn with a non-zero gradient separates the two."""
+    from oracle import diffusion as od
+    diff = od.create_gaussian_diffusion(1000, "linear", "ddim50", False)
+    x = th.randn(1, 3, 8, 8, generator=th.Generator().manual_seed(3))
+    t = th.tensor([20])
+    model = lambda xx, ts, **kw: th.cat([0.1 * xx, th.zeros_like(xx)], dim=1)  # noqa: E731  (eps = 0.1 x, v = 0)
+    g_const = th.full_like(x, 0.7)
+    plain = diff.ddim_sample_with_grad(model, x, t, clip_denoised=False, cond_fn=None)
+    guided = diff.ddim_sample_with_grad(model, x, t, clip_denoised=False, cond_fn=lambda xx, tt, out, **kw: g_const)
+    assert th.equal(guided["pred_xstart"], plain["pred_xstart"])          # what the generator saves as a frame: unconditioned
+    assert (guided["sample"] - plain["sample"]).abs().max() > 1e-3         # the update did use the conditioned x0'
+    ab, abp = float(diff.alphas_cumprod[20]), float(diff.alphas_cumprod_prev[20])
+    eps = 0.1 * x - (1 - ab) ** 0.5 * g_const
+    x0c = (1 / ab) ** 0.5 * x - (1 / ab - 1) ** 0.5 * eps
+    assert th.allclose(guided["sample"], abp ** 0.5 * x0c + (1 - abp) ** 0.5 * eps, atol=1e-5)
