@@ -40,6 +40,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_TILE_ORDER")) ctx->tile_order = atoi(e);
   if (const char* e = getenv("CGD_FUSE_GN")) ctx->fuse_gn = atoi(e);
   if (const char* e = getenv("CGD_FUSE_ACT")) ctx->fuse_act = atoi(e);
+  if (const char* e = getenv("CGD_HCONV_W8")) ctx->hconv_w8 = atoi(e);
   if (const char* e = getenv("CGD_HCONV_SPLIT")) sscanf(e, "%d,%d", &ctx->hconv_slots, &ctx->hconv_min_chunks);
   if (const char* e = getenv("CGD_HCONV_SMALL")) sscanf(e, "%d,%d,%d", &ctx->hconv_small_m, &ctx->hconv_small_slots, &ctx->hconv_small_min_chunks);
   ctx->ws_bytes = (size_t)256 << 20;

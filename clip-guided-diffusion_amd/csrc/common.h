@@ -65,6 +65,9 @@ struct cgd_ctx {
                       // fragment traffic from the vector-memory path to the LDS, +1.2..1.8 % per layer at the 1.36 kW cap)
   int hconv_small_m = 0, hconv_small_slots = 512, hconv_small_min_chunks = 2;  // optional separate split-K target for M <= hconv_small_m
   int hconv_slots = 0, hconv_min_chunks = 4;                 // split-K target of the halo conv: workgroup slots (0 = one per CU), chunks per slice
+  int hconv_w8 = 0;    // 1: 8-pixel-wide maps (the UNet's 8x8 level) run on the halo kernel with half-filled tiles.  Supported and
+                       // parity-tested (tile code 512), but no faster than igemm 64x64 + split-K on the step (22.07 vs 22.07-22.11 ms,
+                       // same-box A/B round 2), so off by default
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
   int fuse_gn = 1;     // 1: ResBlock convs on the halo kernel apply their GroupNorm + FiLM + SiLU while staging (A/B knob)
@@ -185,6 +188,7 @@ size_t cgd_hconv_packed_floats(int Co, int Ci);
 int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w /*[Co][Ci][3][3]*/, float* out, int Co, int Ci, int dgrad, hipStream_t s);
 bool cgd_hconv_supported(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_hconv_tile_m(const cgd_ctx* ctx, const GemmParams& p);
+long cgd_hconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------

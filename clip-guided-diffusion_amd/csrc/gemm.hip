@@ -425,13 +425,15 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   bool auto_split = p.splitk == 1 && p.nbatch == 1 && !p.no_split;
   // halo-staged conv kernel (hconv.hip): tile code 512
   bool use_h = false;
-  if (cgd_hconv_supported(ctx, p)) use_h = tile == 512 || (!tile && ctx->hconv_mode && p.M >= ctx->hconv_min_m);
+  // M >= hconv_min_m pixels, or the 8-pixel-wide maps (weight-streaming layers: the halo kernel's pre-packed bf16 weights and
+  // fragment ring beat the generic kernel's in-loop fp32 -> bf16 conversion although half of every tile is padding)
+  if (cgd_hconv_supported(ctx, p))
+    use_h = tile == 512 || (!tile && ctx->hconv_mode && (p.M >= ctx->hconv_min_m || (p.W == 8 && ctx->hconv_w8)));
   if (tile == 512 && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel does not support this problem");
   if (use_h) {
     tile = 512;
-    const int tm = cgd_hconv_tile_m(ctx, p);
-    if (p.M % tm) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel needs M to be a multiple of its pixel tile");
-    const long tiles = (long)(p.M / tm) * cdiv(p.N, 128);
+    if (p.M % (p.H * p.W)) CGD_FAIL(ctx, "cgd_launch_gemm: conv M must be a whole number of H x W images");
+    const long tiles = cgd_hconv_tiles_m(ctx, p) * cdiv(p.N, 128);
     const int nchunk = p.Cin / 32;
     // split-K target: about one workgroup per CU and >= 4 chunks per slice (sweep r1bc: 2 per CU / 2 chunks 37.3 steps/s,
     // 1 per CU / 4 chunks 38.0-38.5, 0.75 per CU 38.7, 0.5 per CU 37.9): fewer, longer slices beat filling both resident slots
@@ -594,7 +596,7 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   if (rc != 0) return rc;
   long wg;
   if (kernel == 1) {
-    wg = (long)(p.M / cgd_hconv_tile_m(&ctx, p)) * cdiv(p.N, 128);
+    wg = cgd_hconv_tiles_m(&ctx, p) * cdiv(p.N, 128);
   } else if (kernel == 2) {
     wg = cgd_hgemm_tiles(&ctx, p);
   } else {

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
   }
   const int ntm = gridDim.x / ntn;
   const int mt = p.nmajor ? bid % ntm : bid / ntn, n0 = (p.nmajor ? bid / ntm : bid % ntn) * HB_N;
-  const int tpr = p.W >> 4, tpi = (p.H / TH) * tpr;
+  const int tpr = (p.W + 15) >> 4, tpi = (p.H / TH) * tpr;  // W = 8 (the UNet's 8x8 level): one half-filled tile per row
   const int img = mt / tpi, trem = mt - img * tpi;
   const int y0 = (trem / tpr) * TH, x0 = (trem % tpr) << 4;
   const int HW = p.H * p.W;
@@ -138,13 +138,13 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
   }
   // this lane's pixels (one per 32-pixel block of the wavefront's NI): patch position and output row
   int fro[NI];
-  long mrow[NI];
+  long mrow[NI];  // output row of this lane's pixel, or -1 for a tile column beyond the image (W not a multiple of 16)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int pix = wm * (NI * 32) + i * 32 + l31;
     const int ty = pix >> 4, tx = pix & 15;
     fro[i] = ty * HRS + tx * HPH + hh * 8;
-    mrow[i] = (long)img * HW + (long)(y0 + ty) * p.W + x0 + tx;
+    mrow[i] = x0 + tx < p.W ? (long)img * HW + (long)(y0 + ty) * p.W + x0 + tx : -1L;
   }
 
   const int nchunk = p.Cin >> 5;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int cb0 = (nb0 + j) * 32;
-        if (cb0 < p.N) {
+        if (cb0 < p.N && mrow[i] >= 0) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             *(f32x4*)&ws[mrow[i] * p.N + cb0 + 8 * g + 4 * hh] =
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int cb0 = (nb0 + j) * 32;
-      if (cb0 >= p.N) continue;
+      if (cb0 >= p.N || mrow[i] < 0) continue;
       f32x4 rv[4];
       if (Rg) {
 #pragma unroll
@@ -382,7 +382,9 @@ int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int 
 bool cgd_hconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
   if (!p.conv || !p.Bpk || ctx->precision == CGD_PREC_F32 || p.nbatch != 1) return false;
   if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
-  if (p.H <= 0 || p.W <= 0 || (p.H & 15) || (p.W & 15)) return false;  // TH x 16-pixel tiles
+  // TH x 16-pixel tiles; W = 8 runs with half-filled tiles (8x8 level: weight streaming, not MFMA, bounds those layers)
+  if (p.H <= 0 || p.W <= 0 || (p.H & 7) || ((p.W & 15) && p.W != 8)) return false;
+  if ((p.H & 15) && ((ctx->hconv_var & 1) || ((ctx->hconv_var & 2) && p.M < 16384))) return false;  // the 16-row tile variants
   if (p.ups && ((p.H | p.W) & 1)) return false;
   if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;               // 16-byte epilogue accesses
   if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
@@ -397,6 +399,12 @@ int cgd_hconv_tile_m(const cgd_ctx* ctx, const GemmParams& p) {
   return 128;
 }
 
+// pixel tiles of a launch: images x tile rows x tile columns (the last column tile may be partial)
+long cgd_hconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p) {
+  const int th = cgd_hconv_tile_m(ctx, p) / 16;
+  return (long)(p.M / (p.H * p.W)) * (p.H / th) * cdiv(p.W, 16);
+}
+
 int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   HConvParams p;
   p.A = g.A; p.Bp = (const uint4*)g.Bpk; p.C = g.C; p.bias = g.bias; p.R = g.R; p.ws = g.ws;
@@ -406,7 +414,7 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   // weights 9 * Cin * N against activations M * Cin (both x 4 B): weight-panel major when the weights are larger
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 9L * g.N >= g.M)) ? 1 : 0;
   const int tm = cgd_hconv_tile_m(ctx, g);
-  dim3 grid((g.M / tm) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
+  dim3 grid((int)cgd_hconv_tiles_m(ctx, g) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
 #define HC2_LAUNCH(M_, TH_, NJ_)                                                                                                   \
   {                                                                                                                                \
     if (p.gn)                                                                                                                      \

@@ -145,7 +145,11 @@ def check_conv(precision):
             ctx.check(ctx.lib.cgd_set_hconv(ctx.h, 1 + 16 * var, 256))
             for (Bn, H, W, Ci, Co, ups, sk) in [(1, 256, 256, 32, 64, 0, 1), (2, 16, 16, 64, 160, 0, 1), (1, 32, 32, 128, 128, 0, 2),
                                                 (1, 64, 64, 64, 96, 1, 1), (1, 128, 128, 32, 32, 0, 1), (1, 16, 32, 64, 64, 0, 1),
-                                                (1, 256, 512, 32, 32, 0, 1), (2, 48, 32, 32, 64, 0, 1), (1, 32, 32, 256, 64, 0, 3)]:
+                                                (1, 256, 512, 32, 32, 0, 1), (2, 48, 32, 32, 64, 0, 1), (1, 32, 32, 256, 64, 0, 3),
+                                                # 8-pixel-wide maps: half-filled tiles (the UNet's 8x8 level), with split-K and batch
+                                                (1, 8, 8, 64, 96, 0, 1), (2, 8, 8, 128, 160, 0, 2), (1, 16, 8, 64, 64, 0, 1)]:
+                if (var & 1) and H % 16:
+                    continue  # the 16-row tile variants need H to be a multiple of 16
                 Hs, Ws = (H // 2, W // 2) if ups else (H, W)
                 x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
                 w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)

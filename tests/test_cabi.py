@@ -88,7 +88,8 @@ def test_dispatch_policy_of_the_contraction_launcher():
         return _plan(handle, conv=1, M=H * H, N=co, H=H, W=H, Cin=ci, **kw)
 
     # 3x3 convs: the halo kernel from 16^2 pixels up; split-K over 32-channel chunks once there are fewer tiles than CUs
-    # (about one workgroup per CU, >= 4 chunks per slice); 8x8 maps fall back to the 64x64 igemm tile
+    # (about one workgroup per CU, >= 4 chunks per slice); 8x8 maps fall back to the 64x64 igemm tile (the halo kernel supports
+    # them with half-filled tiles, CGD_HCONV_W8=1, but is no faster there)
     assert conv(256, 256, 256) == (0, (1, 512, 1, 1024))
     assert conv(256, 512, 256) == (0, (1, 512, 1, 1024))
     assert conv(128, 256, 256) == (0, (1, 512, 1, 256))
