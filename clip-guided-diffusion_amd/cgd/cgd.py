@@ -97,8 +97,6 @@ def clip_guided_diffusion(image_size=128, num_cutouts=16, prompts=[], image_prom
     rank, nranks = shard.world()
     mine = shard.rank_samples(batch_size) if nranks > 1 else list(range(batch_size))
     local_batch = len(mine)
-    if local_batch == 0:
-        return  # more ranks than samples: nothing to do here
     model_kwargs = {}
     if class_cond:
         model_kwargs["y"] = th.zeros([local_batch], device=device, dtype=th.long)
@@ -106,6 +104,9 @@ def clip_guided_diffusion(image_size=128, num_cutouts=16, prompts=[], image_prom
     gd_model, diffusion = script_util.load_guided_diffusion(
         checkpoint_path=diffusion_path, image_size=image_size, class_cond=class_cond, diffusion_steps=diffusion_steps,
         timestep_respacing=timestep_respacing, use_fp16=True, device=device, noise_schedule=noise_schedule, dropout=dropout)
+
+    if local_batch == 0:
+        return  # more ranks than samples: this rank only took part in the weight broadcasts above (they are collectives)
 
     if reduce_clip and skip_timesteps == 0:
         skip_timesteps = int(diffusion.num_timesteps * 0.2)
