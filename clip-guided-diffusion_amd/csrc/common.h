@@ -70,6 +70,8 @@ struct cgd_ctx {
                        // same-box A/B round 2), so off by default
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
+  int fuse_gn_max_m = 1 << 30, fuse_gn_min_m = 0;  // ... only for convs of at most / at least this many pixels (A/B knob,
+                                                   // CGD_FUSE_GN="1,<max pixels>,<min pixels>")
   int fuse_gn = 1;     // 1: ResBlock convs on the halo kernel apply their GroupNorm + FiLM + SiLU while staging (A/B knob)
   int tile_order = 0;  // XCD tile order of hgemm2 / hconv2: 0 auto (weight-panel major when the weights are the larger operand),
                        // 1 always weight-panel (N) major, 2 always row-panel (M) major (A/B knob)
