@@ -41,6 +41,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_FUSE_GN")) sscanf(e, "%d,%d,%d", &ctx->fuse_gn, &ctx->fuse_gn_max_m, &ctx->fuse_gn_min_m);
   if (const char* e = getenv("CGD_FUSE_ACT")) ctx->fuse_act = atoi(e);
   if (const char* e = getenv("CGD_HCONV_W8")) ctx->hconv_w8 = atoi(e);
+  if (const char* e = getenv("CGD_WINO")) sscanf(e, "%d,%d", &ctx->wino_mode, &ctx->wino_min_m);
   if (const char* e = getenv("CGD_HCONV_SPLIT")) sscanf(e, "%d,%d", &ctx->hconv_slots, &ctx->hconv_min_chunks);
   if (const char* e = getenv("CGD_HCONV_SMALL")) sscanf(e, "%d,%d,%d", &ctx->hconv_small_m, &ctx->hconv_small_slots, &ctx->hconv_small_min_chunks);
   ctx->ws_bytes = (size_t)256 << 20;
@@ -234,6 +235,26 @@ int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, 
 int cgd_op_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, void* stream) {
   CGD_NEED_CTX(ctx);
   return cgd_pack_conv3x3_frag(ctx, w, out, Co, Ci, dgrad, S(stream));
+}
+int cgd_op_pack_conv3x3_wino(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, void* stream) {
+  CGD_NEED_CTX(ctx);
+  return cgd_pack_conv3x3_wino(ctx, w, out, Co, Ci, dgrad, S(stream));
+}
+int cgd_op_conv3x3_wino(cgd_ctx* ctx, const float* x, int ldx, const float* w_wino, float* y, int ldy, const float* bias, const float* R,
+                        int ldr, const float* gn_ab, int Bn, int H, int W, int Cin, int Cout, int ups, void* stream) {
+  CGD_NEED_CTX(ctx);
+  GemmParams p;
+  p.Bwk = w_wino;
+  p.A = x; p.lda = ldx; p.B = x /* unused: the kernel reads only the transformed weights */; p.ldb = 9 * Cin; p.C = y; p.ldc = ldy;
+  p.bias = bias; p.R = R; p.ldr = ldr; p.gn_ab = gn_ab;
+  p.M = Bn * H * W; p.N = Cout; p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.ups = ups; p.force_tile = 515;
+  return cgd_launch_gemm(ctx, p, S(stream));
+}
+int cgd_set_wino(cgd_ctx* ctx, int mode, int min_m) {
+  CGD_NEED_CTX(ctx);
+  ctx->wino_mode = mode;
+  if (min_m > 0) ctx->wino_min_m = min_m;
+  return 0;
 }
 int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m) {
   CGD_NEED_CTX(ctx);

@@ -69,6 +69,8 @@ struct cgd_ctx {
                        // parity-tested (tile code 512), but no faster than igemm 64x64 + split-K on the step (22.07 vs 22.07-22.11 ms,
                        // same-box A/B round 2), so off by default
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int wino_mode = 0, wino_min_m = 16384;  // Winograd F(2,3) variant of the halo conv (wconv.hip): 0 off, 1 for convs of >= wino_min_m
+                                          // pixels whose transformed weights were packed (CGD_WINO="1[,<min pixels>]")
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
   int fuse_gn_max_m = 1 << 30, fuse_gn_min_m = 0;  // ... only for convs of at most / at least this many pixels (A/B knob,
                                                    // CGD_FUSE_GN="1,<max pixels>,<min pixels>")
@@ -166,9 +168,11 @@ struct GemmParams {
   int splitk = 1;
   int no_split = 0;  // 1: never split K automatically (the caller keeps data of its own in the workspace)
   float* ws = nullptr;
-  int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel
+  int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel;
+                       // 515 Winograd halo conv kernel (wconv.hip)
   int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
+  const void* Bwk = nullptr;  // conv only: Winograd F(2,3)-transformed weights in fragment order (cgd_pack_conv3x3_wino) for wconv.hip
   // weight GEMM on hgemm2 without split-K only (cgd_gemm_fuses_act): activation fused into the epilogue.
   //   act_out: second output C2[m][n] = act(C[m][n]) (C keeps the pre-activation, the backward pass needs it);
   //   act_in : C[m][n] = (alpha * acc + bias + R) * act'(U[m][n]) (backward through the activation whose input was U)
@@ -192,6 +196,13 @@ bool cgd_hconv_supported(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_hconv_tile_m(const cgd_ctx* ctx, const GemmParams& p);
 long cgd_hconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
+
+// ---- Winograd F(2,3) halo conv for the large maps (wconv.hip) ------------------------------------------
+size_t cgd_wconv_packed_floats(int Co, int Ci);
+int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w /*[Co][Ci][3][3]*/, float* out, int Co, int Ci, int dgrad, hipStream_t s);
+bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p);
+long cgd_wconv_tiles_m(const GemmParams& p);
+int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------
 bool cgd_hgemm_supported(const cgd_ctx* ctx, const GemmParams& p);

@@ -427,10 +427,17 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   bool use_h = false;
   // M >= hconv_min_m pixels, or the 8-pixel-wide maps (weight-streaming layers: the halo kernel's pre-packed bf16 weights and
   // fragment ring beat the generic kernel's in-loop fp32 -> bf16 conversion although half of every tile is padding)
-  if (cgd_hconv_supported(ctx, p))
+  const bool wino_forced = tile == 515;  // tests / micro-benchmarks: needs only the transformed weights (Bwk)
+  if (wino_forced) {
+    p.splitk = 1;
+    if (!cgd_wconv_supported(ctx, p)) CGD_FAIL(ctx, "cgd_launch_gemm: Winograd conv kernel does not support this problem");
+    use_h = true;
+    auto_split = false;
+  } else if (cgd_hconv_supported(ctx, p)) {
     use_h = tile == 512 || (!tile && ctx->hconv_mode && (p.M >= ctx->hconv_min_m || (p.W == 8 && ctx->hconv_w8)));
+  }
   if (tile == 512 && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel does not support this problem");
-  if (use_h) {
+  if (use_h && !wino_forced) {
     tile = 512;
     if (p.M % (p.H * p.W)) CGD_FAIL(ctx, "cgd_launch_gemm: conv M must be a whole number of H x W images");
     const long tiles = cgd_hconv_tiles_m(ctx, p) * cdiv(p.N, 128);
@@ -449,6 +456,8 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
       if (want >= 2) p.splitk = (int)want;
     }
     auto_split = false;
+    // Winograd F(2,3) variant (wconv.hip, tile code 515): the large maps, one slice, transformed weights packed
+    if (!p.force_tile && ctx->wino_mode && p.M >= ctx->wino_min_m && cgd_wconv_supported(ctx, p)) tile = 515;
   }
   // weight GEMM kernel (hgemm.hip): tile code 513; automatic for persistent weights with M >= hgemm_min_m
   bool use_g = false;
@@ -550,7 +559,10 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   ProfRec pr;
   CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? CGD_PROF_HCONV : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));
   if (use_h) {
-    CGD_TRY(cgd_launch_hconv(ctx, p, s));
+    if (tile == 515)
+      CGD_TRY(cgd_launch_wconv(ctx, p, s));
+    else
+      CGD_TRY(cgd_launch_hconv(ctx, p, s));
     CGD_TRY(cgd_prof_stamp(ctx, &pr, s));  // the halo conv kernel alone, without its split-K reduce
   } else if (use_g) {
     CGD_TRY(cgd_launch_hgemm(ctx, p, s));
@@ -596,7 +608,7 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   if (rc != 0) return rc;
   long wg;
   if (kernel == 1) {
-    wg = cgd_hconv_tiles_m(&ctx, p) * cdiv(p.N, 128);
+    wg = (tile == 515 ? cgd_wconv_tiles_m(p) : cgd_hconv_tiles_m(&ctx, p)) * cdiv(p.N, 128);
   } else if (kernel == 2) {
     wg = cgd_hgemm_tiles(&ctx, p);
   } else {

@@ -65,6 +65,7 @@ struct ResBlock : Module {
   float *g1 = 0, *b1 = 0, *cw1f = 0, *cw1d = 0, *cb1 = 0, *g2 = 0, *b2 = 0, *cw2f = 0, *cw2d = 0, *cb2 = 0, *skw = 0, *skwT = 0,
         *skb = 0;
   float *cw1fp = 0, *cw1dp = 0, *cw2fp = 0, *cw2dp = 0;  // MFMA-fragment-order bf16 hi/lo copies for the halo conv kernel
+  float *cw1wp = 0, *cw1wd = 0, *cw2wp = 0, *cw2wd = 0;  // Winograd F(2,3)-transformed copies (wconv.hip), only with ctx->wino_mode
   // runtime
   int B = 0, H = 0, W = 0, Ho = 0, Wo = 0;
   TV x;
@@ -133,7 +134,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   const int ldo = dst.p ? dst.ld : cout;
   // conv1 (the nearest-2x upsample of an `up` block is folded into the conv's gather)
   GemmParams c1;
-  c1.B = cw1f; c1.Bpk = cw1fp; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
+  c1.B = cw1f; c1.Bpk = cw1fp; c1.Bwk = cw1wp; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
   c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
   c1.defer = 1;  // a split-K launch leaves its slices for the GroupNorm right below (SplitSrc)
   // in_layers: GN -> SiLU.  When conv1 runs on the halo kernel (and nothing else reads the normalised tensor: `down` blocks
@@ -168,7 +169,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
   // out_layers: GN * (1+scale) + shift -> SiLU -> conv2 (+ skip); same on-the-fly application when conv2 runs on the halo kernel
   GemmParams c2;
-  c2.A = h2.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2;
+  c2.A = h2.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.Bwk = cw2wp; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   c2.defer = 1;  // the next module starts with a GroupNorm of this tensor (or the launcher flushes: concat inputs, the head)
   const bool fuse2 = cgd_conv_uses_hconv(ctx, c2);
@@ -209,7 +210,7 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   CGD_TRY(u.ensure(dx, npi * cin));
   // conv2 dgrad (a split-K launch leaves its slices for the GroupNorm backward right below)
   GemmParams c2;
-  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
+  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.Bwk = cw2wd; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   c2.defer = 1;
   CGD_TRY(cgd_launch_gemm(ctx, c2, s));
@@ -238,7 +239,7 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   }
   // conv1 dgrad (at the conv's own resolution)
   GemmParams c1;
-  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
+  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.Bwk = cw1wd; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
   c1.M = (int)npo; c1.N = cin; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cout;
   c1.defer = (up || down) ? 0 : 1;  // plain blocks: GN1's backward below consumes the slices; resampling blocks read d1 first
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
@@ -465,6 +466,18 @@ int UNet::finalize(hipStream_t s) {
     CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".in_layers.2.weight"), rb->cw1dp, rb->cout, rb->cin, 1, s));
     CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".out_layers.3.weight"), rb->cw2fp, rb->cout, rb->cout, 0, s));
     CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".out_layers.3.weight"), rb->cw2dp, rb->cout, rb->cout, 1, s));
+    if (ctx->wino_mode) {  // transformed copies for the large-map Winograd kernel (A/B knob CGD_WINO, off by default)
+      if (!rb->cw1wp) {
+        CGD_TRY(alloc(&rb->cw1wp, cgd_wconv_packed_floats(rb->cout, rb->cin)));
+        CGD_TRY(alloc(&rb->cw1wd, cgd_wconv_packed_floats(rb->cout, rb->cin)));
+        CGD_TRY(alloc(&rb->cw2wp, cgd_wconv_packed_floats(rb->cout, rb->cout)));
+        CGD_TRY(alloc(&rb->cw2wd, cgd_wconv_packed_floats(rb->cout, rb->cout)));
+      }
+      CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".in_layers.2.weight"), rb->cw1wp, rb->cout, rb->cin, 0, s));
+      CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".in_layers.2.weight"), rb->cw1wd, rb->cout, rb->cin, 1, s));
+      CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wp, rb->cout, rb->cout, 0, s));
+      CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wd, rb->cout, rb->cout, 1, s));
+    }
     CGD_TRY(cgd_pack_conv3x3(ctx, P(p + ".in_layers.2.weight"), rb->cw1f, rb->cw1d, rb->cout, rb->cin, s));
     CGD_TRY(cgd_pack_conv3x3(ctx, P(p + ".out_layers.3.weight"), rb->cw2f, rb->cw2d, rb->cout, rb->cout, s));
     if (rb->skip_conv) {

@@ -1,0 +1,360 @@
+// Winograd F(2,3)-along-W variant of the halo-staged 3x3 convolution (bf16x3 MFMA) for the UNet's large maps (gfx950).
+//
+// hconv2_kernel (hconv.hip) runs at the board power cap with the MFMA pipe ~58 % busy: on the >= 128x128-pixel levels the only
+// lever left is fewer MFMAs per output.  The 1-D Winograd transform F(2,3) along the image row computes two adjacent output
+// pixels from 4 products instead of 6:
+//     d0..d3 = x[2p-1 .. 2p+2],  g0..g2 = one filter row
+//     m0 = (d0 - d2) g0,  m1 = (d1 + d2)(g0 + g1 + g2)/2,  m2 = (d2 - d1)(g0 - g1 + g2)/2,  m3 = (d1 - d3) g2
+//     y[2p] = m0 + m1 + m2,   y[2p+1] = m1 - m2 - m3
+// so the contraction over (filter row ky, input channel) needs 4 "positions" x 3 rows = 12 channel-GEMMs per pixel PAIR instead
+// of 9 per pixel: 2/3 of the MFMAs, 2/3 of the LDS fragment reads, 4/3 of the weight bytes (U = G g, packed at load time).
+// The transform is exact in fp32 up to the rounding of U and of V = B^T d; with bf16x3 products the error of a 256-channel
+// layer is 1.3x that of the direct kernel (5.6e-6 vs 4.3e-6 rms at unit scale; 2-D F(2x2,3x3) would save 2.25x but needs 4x
+// the accumulators).  See DESIGN.md section 4.
+//
+// Shape of the kernel (differences to hconv2_kernel):
+//   * tile = 16 x 16 pixels x 128 output channels, 4 wavefronts, ONE workgroup per CU (1 wavefront per SIMD, up to 512
+//     registers): a wavefront owns all 256 pixels (128 pairs = 4 MFMA column blocks) x 32 channels x 4 positions = 256
+//     accumulator registers.  Per step (ky, position, 16 channels): 8 ds_read_b128 + 2 global fragment loads for 12 MFMAs —
+//     the ratios of hconv2's 128 x 32 sub-tile, which a two-workgroup tiling of the doubled accumulators cannot keep.
+//   * LDS holds the TRANSFORMED patch V[row 18][position 4][pair 8][32 ch] as bf16 hi / lo planes, double-buffered:
+//     2 x 2 x 36,864 B = 147,456 B.  No padding: 16-byte unit u of a cell is stored at (u + row) & 3, which makes every
+//     ds_read_b128 lane group {0-3,12-15,20-27} / {4-11,16-19,28-31} hit 16 distinct slots of the 256-byte bank row.
+//   * staging: a thread loads the 4 patch pixels of one (row, pair) for its 4 channels, applies GroupNorm+SiLU if fused,
+//     transforms, splits and writes 8 x 8 B; 5 such tasks per thread and chunk (18 rows x 8 pairs x 8 channel quads = 1152
+//     tasks; the last 128 slots repeat rows 16-17: same values to the same addresses), spread over the 24 steps.
+//   * weights: [N/32][Cin/32][ky 3][position 4][kstep 2][plane 2][lane 64][8 bf16], 8-deep register ring.
+// No split-K, W and H multiples of 16 only: the launcher (gemm.hip) uses it for M >= ctx->wino_min_m pixels when enabled.
+#include "common.h"
+
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef float wf32x16 __attribute__((ext_vector_type(16)));
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WROW = 1024;            // bf16 elements per patch row: 4 positions x 8 pairs x 32 channels
+constexpr int WPLANE = 18 * WROW;     // elements per plane
+constexpr int WSTEPS = 24;            // (ky, position, kstep) per 32-channel chunk
+constexpr int WRING = 8, WDIST = WRING - 1;
+
+struct WConvParams {
+  int lda, ldc, ldr;
+  int M, N, H, W, Cin, ups;
+  float alpha;
+  int nmajor;
+};
+
+__device__ __forceinline__ wbf16x4 w_bf16x4(const wf32x4 v) {
+  wbf16x4 r;
+  r[0] = (__bf16)v.x;
+  r[1] = (__bf16)v.y;
+  r[2] = (__bf16)v.z;
+  r[3] = (__bf16)v.w;
+  return r;
+}
+__device__ __forceinline__ wf32x4 w_residual4(const wf32x4 v, const wbf16x4 hi) {
+  return wf32x4{v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]};
+}
+__device__ __forceinline__ float w_silu(float x, float a, float b) {
+  const float u = x * a + b;
+  return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));  // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
+}
+
+template <bool GN>
+__global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+                                                    const float* __restrict__ biasg, const float* Rg,
+                                                    const float* __restrict__ gng, const WConvParams p) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * WPLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int ntn = (p.N + 127) >> 7;
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntm = gridDim.x / ntn;
+  const int mt = p.nmajor ? bid % ntm : bid / ntn, n0 = (p.nmajor ? bid / ntm : bid % ntn) << 7;
+  const int tpr = p.W >> 4, tpi = (p.H >> 4) * tpr;
+  const int img = mt / tpi, trem = mt - img * tpi;
+  const int y0 = (trem / tpr) << 4, x0 = (trem % tpr) << 4;
+  const int HW = p.H * p.W;
+  const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
+  const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
+
+  // ---- staging tasks of this thread: (patch row wave + 4j, pair sp, channel quad c4), j = 0..4
+  const int c4 = tid & 7, sp = (tid >> 3) & 7;
+  int rowoff[5], wbase[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    int row = wave + 4 * j;
+    if (row >= 18) row -= 2;  // task slots beyond the patch repeat rows 16 / 17 (identical values, identical addresses)
+    const int y = y0 + row - 1;
+    rowoff[j] = (unsigned)y < (unsigned)p.H ? (p.ups ? y >> 1 : y) * Ws * p.lda : -1;
+    wbase[j] = row * WROW + sp * 32 + (((c4 >> 1) + row) & 3) * 8 + (c4 & 1) * 4;
+  }
+  int colo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = x0 + 2 * sp + k - 1;
+    colo[k] = (unsigned)x < (unsigned)p.W ? (p.ups ? x >> 1 : x) * p.lda + c4 * 4 : -1;
+  }
+  // ---- fragment reads of this lane: pair column l31 of every block = (tile row 4b + (l31 >> 3), pair l31 & 7)
+  const int lr = l31 >> 3, lp = l31 & 7;
+  int fro[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) fro[t] = lr * WROW + lp * 32 + ((hh + lr + t) & 3) * 8;
+
+  const int nchunk = p.Cin >> 5;
+  const int nb0 = (n0 >> 5) + wave;
+  const int nbN = p.N >> 5;
+  const long bstride_nb = (long)nchunk * (WSTEPS * 2 * 64);
+  const uint4* __restrict__ Bw0 = Bg + (long)(nb0 < nbN ? nb0 : nbN - 1) * bstride_nb + lane;
+
+  wf32x16 acc[4][4];  // [position][block]
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[x][b][e] = 0.f;
+
+  wf32x4 pr[2][4];  // two tasks in flight
+  wf32x4 ga[2];     // GN: {a0, b0, a1, b1}, {a2, b2, a3, b3} of this thread's channels in the chunk being staged
+  const wf32x4 z4 = wf32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ gnimg = GN ? gng + ((long)img * p.Cin + c4 * 4) * 2 : nullptr;
+
+#define W_TASK_LOAD(ARR, J, CH)                                                                      \
+  {                                                                                                  \
+    const float* __restrict__ Ac_ = Aimg + (CH) * 32;                                                \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                    \
+        ARR[k] = *(const wf32x4*)(Ac_ + ((rowoff[J] | colo[k]) >= 0 ? rowoff[J] + colo[k] : c4 * 4)); \
+  }
+#define W_GN_LOAD(CH)                                                                                \
+  if constexpr (GN) {                                                                                \
+    ga[0] = *(const wf32x4*)(gnimg + (CH) * 64);                                                     \
+    ga[1] = *(const wf32x4*)(gnimg + (CH) * 64 + 4);                                                 \
+  }
+  // activation (fused GroupNorm) and zero padding of pixel K of the task held in ARR
+#define W_TASK_PIX(ARR, J, K)                                                                        \
+  {                                                                                                  \
+    wf32x4 v_ = ARR[K];                                                                              \
+    if constexpr (GN)                                                                                \
+      v_ = wf32x4{w_silu(v_.x, ga[0].x, ga[0].y), w_silu(v_.y, ga[0].z, ga[0].w), w_silu(v_.z, ga[1].x, ga[1].y),   \
+                  w_silu(v_.w, ga[1].z, ga[1].w)};                                                   \
+    ARR[K] = (rowoff[J] | colo[K]) >= 0 ? v_ : z4;                                                   \
+  }
+#define W_TASK_PUT(DSTB, J, XI, V)                                                                   \
+  {                                                                                                  \
+    const wf32x4 t_ = (V);                                                                           \
+    const wbf16x4 hi_ = w_bf16x4(t_);                                                                \
+    *(wbf16x4*)&(DSTB)[wbase[J] + (XI) * 256] = hi_;                                                 \
+    *(wbf16x4*)&(DSTB)[WPLANE + wbase[J] + (XI) * 256] = w_bf16x4(w_residual4(t_, hi_));             \
+  }
+  // a task is transformed in three pieces of similar VALU weight (one per step)
+#define W_TASK_P1(DSTB, ARR, J)                                                                      \
+  {                                                                                                  \
+    W_TASK_PIX(ARR, J, 0) W_TASK_PIX(ARR, J, 2)                                                      \
+    W_TASK_PUT(DSTB, J, 0, ARR[0] - ARR[2])                                                          \
+  }
+#define W_TASK_P2(DSTB, ARR, J)                                                                      \
+  {                                                                                                  \
+    W_TASK_PIX(ARR, J, 1)                                                                            \
+    W_TASK_PUT(DSTB, J, 1, ARR[1] + ARR[2])                                                          \
+    W_TASK_PUT(DSTB, J, 2, ARR[2] - ARR[1])                                                          \
+  }
+#define W_TASK_P3(DSTB, ARR, J)                                                                      \
+  {                                                                                                  \
+    W_TASK_PIX(ARR, J, 3)                                                                            \
+    W_TASK_PUT(DSTB, J, 3, ARR[1] - ARR[3])                                                          \
+  }
+  // A fragments of step Q = (ky * 4 + xi) * 2 + ks: [block][plane]
+#define W_A_LOAD(DST, SRCB, Q)                                                                       \
+  {                                                                                                  \
+    const int ky_ = (Q) >> 3, xi_ = ((Q) >> 1) & 3, ks_ = (Q) & 1;                                   \
+    const int o_ = fro[(2 * ks_ + ky_) & 3] + ky_ * WROW + xi_ * 256;                                \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                  \
+      DST[b][0] = *(const wbf16x8*)&(SRCB)[o_ + b * (4 * WROW)];                                     \
+      DST[b][1] = *(const wbf16x8*)&(SRCB)[WPLANE + o_ + b * (4 * WROW)];                            \
+    }                                                                                                \
+  }
+#define W_B_LOAD(DST, BASE, Q)                                                                       \
+  {                                                                                                  \
+    const uint4* bp_ = (BASE) + (Q) * 128;                                                           \
+    DST[0] = bp_[0];                                                                                 \
+    DST[1] = bp_[64];                                                                                \
+  }
+#define W_MFMA12(XI, AQ, BQ)                                                                         \
+  {                                                                                                  \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
+        acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[0]), AQ[b][1], acc[XI][b], 0, 0, 0); \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
+        acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[1]), AQ[b][0], acc[XI][b], 0, 0, 0); \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
+        acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[0]), AQ[b][0], acc[XI][b], 0, 0, 0); \
+  }
+
+  wbf16x8 af[2][4][2];   // [pipeline slot][block][plane]
+  uint4 bq[WRING][2];    // [ring slot][plane]
+  {
+    // prologue: stage chunk 0 completely, start the weight ring
+    W_GN_LOAD(0);
+#pragma unroll
+    for (int q = 0; q < WDIST; ++q) W_B_LOAD(bq[q], Bw0, q);
+    wf32x4 pro[5][4];  // all five tasks in flight (the accumulators are not live yet)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) W_TASK_LOAD(pro[j], j, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      W_TASK_P1(lds, pro[j], j);
+      W_TASK_P2(lds, pro[j], j);
+      W_TASK_P3(lds, pro[j], j);
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    const int cn = more ? c + 1 : c;  // the last chunk re-stages itself into the idle buffer: no branch in the scheduled region
+    const __bf16* cur = lds + (c & 1) * (2 * WPLANE);
+    __bf16* nxt = lds + ((c & 1) ^ 1) * (2 * WPLANE);
+    const uint4* __restrict__ cb = Bw0 + (long)c * (WSTEPS * 128);
+    const uint4* __restrict__ nb = Bw0 + (long)cn * (WSTEPS * 128);
+    W_GN_LOAD(cn);
+    W_A_LOAD(af[0], cur, 0);
+#pragma unroll
+    for (int q = 0; q < WSTEPS; ++q) {
+      // ---- issue: A fragments one step ahead, B fragments WDIST steps ahead, one staging task every 4 steps
+      if (q + 1 < WSTEPS) W_A_LOAD(af[(q + 1) & 1], cur, q + 1);
+      {
+        const int q2 = (q + WDIST) % WSTEPS;
+        const uint4* __restrict__ base = (q + WDIST < WSTEPS) ? cb : nb;
+        W_B_LOAD(bq[(q + WDIST) % WRING], base, q2);
+      }
+      if ((q & 3) == 0 && q < 20) W_TASK_LOAD(pr[(q >> 2) & 1], q >> 2, cn);
+      W_MFMA12((q >> 1) & 3, af[q & 1], bq[q % WRING]);
+      // task k is loaded at step 4k and transformed at steps 4k + 5 .. 4k + 7
+      if (q >= 5 && ((q - 5) & 3) == 0) W_TASK_P1(nxt, pr[((q - 5) >> 2) & 1], (q - 5) >> 2);
+      if (q >= 6 && ((q - 6) & 3) == 0) W_TASK_P2(nxt, pr[((q - 6) >> 2) & 1], (q - 6) >> 2);
+      if (q >= 7 && ((q - 7) & 3) == 0) W_TASK_P3(nxt, pr[((q - 7) >> 2) & 1], (q - 7) >> 2);
+#pragma unroll
+      for (int r = 0; r < 12; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+        if (r < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        // DS read (8 per step)
+        if (r == 8 || r == 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // VMEM read (2 weight fragments)
+        if ((q & 3) == 0 && q < 20 && (r & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // patch loads (4)
+        __builtin_amdgcn_sched_group_barrier(0x002, GN ? 6 : 3, 0);                          // VALU
+        if (q >= 5 && (q & 3) != 0 && (r % 3) == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (<= 4 per step)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // patch c consumed by every wavefront, patch c + 1 written
+  }
+#undef W_TASK_LOAD
+#undef W_GN_LOAD
+#undef W_TASK_PIX
+#undef W_TASK_PUT
+#undef W_TASK_P1
+#undef W_TASK_P2
+#undef W_TASK_P3
+#undef W_A_LOAD
+#undef W_B_LOAD
+#undef W_MFMA12
+
+  // ---- epilogue: output transform in registers.  D = U x V^T in the 32x32 C/D layout: column (lane & 31) = pixel pair, row =
+  //      channel (r & 3) + 8 (r >> 2) + 4 hh: accumulator quad g holds channels 8g + 4hh .. + 3 of the lane's pair.
+  const int cb0 = nb0 * 32;
+  if (cb0 >= p.N) return;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const long m_even = (long)img * HW + (long)(y0 + 4 * b + lr) * p.W + x0 + 2 * lp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = cb0 + 8 * g + 4 * hh;
+      wf32x4 m[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) m[x] = wf32x4{acc[x][b][4 * g], acc[x][b][4 * g + 1], acc[x][b][4 * g + 2], acc[x][b][4 * g + 3]};
+      wf32x4 oe = (m[0] + m[1] + m[2]) * p.alpha, oo = (m[1] - m[2] - m[3]) * p.alpha;
+      if (biasg) {
+        const wf32x4 bv = wf32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
+        oe += bv;
+        oo += bv;
+      }
+      if (Rg) {
+        oe += *(const wf32x4*)&Rg[m_even * p.ldr + col];
+        oo += *(const wf32x4*)&Rg[(m_even + 1) * p.ldr + col];
+      }
+      *(wf32x4*)&Cg[m_even * p.ldc + col] = oe;
+      *(wf32x4*)&Cg[(m_even + 1) * p.ldc + col] = oo;
+    }
+  }
+}
+
+// w: torch conv weight [Co][Ci][3][3].  dgrad = 0: g[kx] = w[n][k][ky][kx]; dgrad = 1: g[kx] = w[k][n][2-ky][2-kx].
+// U = (g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2), computed in double, stored as bf16 hi / lo in fragment order (header).
+__global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Co, int Ci, int dgrad) {
+  const int N = dgrad ? Ci : Co, K = dgrad ? Co : Ci;
+  const int nchunk = K >> 5;
+  const long total = (long)N * K * 12;  // elements per plane
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(t & 7);
+    long u = t >> 3;
+    const int lane = (int)(u & 63);
+    u >>= 6;
+    const int q = (int)(u % WSTEPS);
+    u /= WSTEPS;
+    const int chunk = (int)(u % nchunk), nb = (int)(u / nchunk);
+    const int ky = q >> 3, xi = (q >> 1) & 3, ks = q & 1;
+    const int n = nb * 32 + (lane & 31), k = chunk * 32 + ks * 16 + (lane >> 5) * 8 + e;
+    double g[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+      g[kx] = dgrad ? (double)w[(((long)k * Ci + n) * 3 + (2 - ky)) * 3 + (2 - kx)] : (double)w[(((long)n * Ci + k) * 3 + ky) * 3 + kx];
+    const double uv = xi == 0 ? g[0] : xi == 1 ? 0.5 * (g[0] + g[1] + g[2]) : xi == 2 ? 0.5 * (g[0] - g[1] + g[2]) : g[2];
+    const float v = (float)uv;
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const long blk = (((long)nb * nchunk + chunk) * WSTEPS + q) * 2;  // + plane
+    out[(blk + 0) * 512 + lane * 8 + e] = hi;
+    out[(blk + 1) * 512 + lane * 8 + e] = lo;
+  }
+}
+
+}  // namespace
+
+size_t cgd_wconv_packed_floats(int Co, int Ci) { return (size_t)Co * Ci * 12; }  // 2 bf16 planes = one float per transformed weight
+
+int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, hipStream_t s) {
+  if ((Co & 31) || (Ci & 31)) CGD_FAIL(ctx, "pack_conv3x3_wino: channels must be multiples of 32");
+  const long total = (long)Co * Ci * 12;
+  hipLaunchKernelGGL(pack_wino_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
+  if (!p.conv || !p.Bwk || ctx->precision != CGD_PREC_BF16X3 || p.nbatch != 1 || p.splitk > 1) return false;
+  if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
+  if (p.H <= 0 || p.W <= 0 || (p.H & 15) || (p.W & 15) || p.M % (p.H * p.W)) return false;
+  if (p.ups && ((p.H | p.W) & 1)) return false;
+  if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
+  if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
+  return true;
+}
+
+long cgd_wconv_tiles_m(const GemmParams& p) { return (long)(p.M / (p.H * p.W)) * (p.H >> 4) * (p.W >> 4); }
+
+int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
+  WConvParams p;
+  p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
+  p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.alpha = g.alpha;
+  p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 12L * g.N >= g.M)) ? 1 : 0;
+  dim3 grid((int)cgd_wconv_tiles_m(g) * cdiv(g.N, 128));
+  if (g.gn_ab)
+    hipLaunchKernelGGL((wconv_kernel<true>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p);
+  else
+    hipLaunchKernelGGL((wconv_kernel<false>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p);
+  return 0;
+}

@@ -53,6 +53,25 @@ def conv3x3(ctx, x_nhwc, w_packed, bias=None, R=None, upsample_input=False, forc
     return y
 
 
+def pack_conv3x3_wino(ctx, w, dgrad=False):
+    """torch conv weight [Co][Ci][3][3] (on the GPU) -> Winograd F(2,3)-transformed bf16 hi/lo fragments for wconv.hip."""
+    co, ci = w.shape[:2]
+    out = th.empty(co * ci * 12, device=w.device, dtype=th.float32)
+    wc = w.contiguous().float()
+    ctx.check(ctx.lib.cgd_op_pack_conv3x3_wino(ctx.h, wc.data_ptr(), out.data_ptr(), co, ci, int(dgrad), _s()))
+    return out
+
+
+def conv3x3_wino(ctx, x_nhwc, w_wino, cout, bias=None, R=None, upsample_input=False, gn_ab=None):
+    """The Winograd halo conv kernel on x (B,H,W,Cin) NHWC (H, W multiples of 16); gn_ab (B,Cin,2): convolve SiLU(x * a + b)."""
+    Bn, Hs, Ws, Cin = x_nhwc.shape
+    H, W = (Hs * 2, Ws * 2) if upsample_input else (Hs, Ws)
+    y = th.empty((Bn, H, W, cout), device=x_nhwc.device, dtype=th.float32)
+    ctx.check(ctx.lib.cgd_op_conv3x3_wino(ctx.h, x_nhwc.data_ptr(), Cin, w_wino.data_ptr(), y.data_ptr(), cout, L.ptr(bias), L.ptr(R), cout,
+                                          L.ptr(gn_ab), Bn, H, W, Cin, cout, int(upsample_input), _s()))
+    return y
+
+
 def conv_in(ctx, x_nchw, w_packed, bias, cout):
     Bn, Cin, H, W = x_nchw.shape
     y = th.empty((Bn, H, W, cout), device=x_nchw.device, dtype=th.float32)

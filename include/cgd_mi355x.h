@@ -204,6 +204,16 @@ int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m);
 int cgd_op_conv3x3(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_packed, const float* w_frag, float* y_nhwc, int ldy,
                    const float* bias, const float* R, int ldr, int Bn, int H, int W, int Cin, int Cout, int upsample_input, int force_tile,
                    int splitk, void* stream);
+/* Winograd F(2,3)-along-W variant of the halo conv (wconv.hip; H, W multiples of 16, bf16x3 only): w_wino = the torch weights
+ * transformed and packed by cgd_op_pack_conv3x3_wino (Co*Ci*12 floats of storage).  gn_ab (optional): per-(sample, channel) pairs
+ * {a, b} [Bn][Cin][2]; the kernel then convolves SiLU(x * a + b) (the fused GroupNorm of the UNet's ResBlocks).
+ * cgd_set_wino: mode 1 = the UNet's 3x3 convs of >= min_m pixels run on this kernel (set BEFORE cgd_unet_finalize, which packs the
+ * transformed weights; default off, environment CGD_WINO="1[,min_m]"). */
+int cgd_op_pack_conv3x3_wino(cgd_ctx* ctx, const float* w_torch, float* out, int Co, int Ci, int dgrad, void* stream);
+int cgd_op_conv3x3_wino(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_wino, float* y_nhwc, int ldy, const float* bias,
+                        const float* R, int ldr, const float* gn_ab, int Bn, int H, int W, int Cin, int Cout, int upsample_input,
+                        void* stream);
+int cgd_set_wino(cgd_ctx* ctx, int mode, int min_m);
 int cgd_op_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w, const float* bias, float* y_nhwc, int Bn, int H, int W, int Cin,
                    int Cout, void* stream);
 int cgd_op_conv_thin_out(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w, const float* bias, float* y_nchw, int Bn, int H,

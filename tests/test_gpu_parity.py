@@ -39,6 +39,10 @@ def test_conv(precision):
     _assert_all(pc.check_conv(precision))
 
 
+def test_conv_winograd_variant():
+    _assert_all(pc.check_wconv())
+
+
 def test_groupnorm_layernorm():
     _assert_all(pc.check_norm())
 
