@@ -20,7 +20,8 @@ broadcast of the packed weights at start-up, no per-step collective.  Timing: ba
 steps, max over ranks.
 
 Prints ONE JSON line (driver contract) with three extra objects:
-  roofline     : dominant kernel = the halo-staged MFMA 3x3 conv (`hconv2_kernel`): algorithmic FLOP of its launches / their summed
+  roofline     : dominant kernel = the Winograd halo-staged MFMA 3x3 conv of the large maps (`wconv_kernel`; the direct `hconv2_kernel`
+                 of the smaller maps rides along as `other_conv_kernel`): algorithmic FLOP of its launches / their summed
                  HIP-event duration (events recorded by the library on the launch stream, in a separate UNTIMED pass after the
                  timed region), against the dense bf16 MFMA peak (2.5 PF/s).  bf16x3 issues 3 MFMA products per algorithmic
                  product (`mfma_issue_frac` = 3 x frac).  `traffic` = HBM bytes/launch from the committed PMC passes (profiles/).
@@ -42,9 +43,12 @@ sys.path.insert(0, ROOT)
 
 U256 = dict(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64)
 U512 = dict(image_size=512, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64)
-# mean algorithmic HBM bytes of a halo-conv launch in config 2: 4 B * M * (Cin + Cout) activations + 4 B * 9 * Cin * Cout packed
-# weights, averaged over the 136 launches of a step (bench/plan_dump.py; checked by tests/test_flop_accounting.py)
-HCONV_ALGO_BYTES_PER_LAUNCH = 55.27e6
+# mean algorithmic HBM bytes of a 3x3-conv launch in config 2: 4 B * M * (Cin + Cout) activations + 4 B * taps * Cin * Cout packed
+# weights (taps = 12 transformed filter taps for the Winograd kernel, 9 for the direct one), averaged over the kernel's launches of
+# a step: 52 wconv_kernel launches (>= 128x128 pixels), 84 hconv2_kernel launches (tests/plan_dump.py; checked by
+# tests/test_flop_accounting.py)
+WCONV_ALGO_BYTES_PER_LAUNCH = 97.64e6
+HCONV_ALGO_BYTES_PER_LAUNCH = 29.77e6
 METRIC = "diffusion steps/sec (UNet+CLIP+grad) at 256x256 cutn=16"
 
 # BASELINE.json configs[1..4]; tflop = algorithmic TFLOP per sample-step (SURVEY.md 8d / BASELINE.md section 2).
@@ -306,25 +310,39 @@ def main():
         tp = time.perf_counter()
         for _ in range(args.profile_steps):
             next(steps)
-        buf = (C.c_double * 9)()
+        buf = (C.c_double * 12)()
         ctx.check(ctx.lib.cgd_profile_read(ctx.h, buf))
         dtp = time.perf_counter() - tp
         ctx.check(ctx.lib.cgd_profile(ctx.h, 0))
-        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n, gn_ms, gn_bytes, gn_n = list(buf)
+        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n, gn_ms, gn_bytes, gn_n, w_ms, w_flop, w_n = list(buf)
         ps = args.profile_steps
         nprod = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
+
+        def conv_leg(name, ms, flop, n, products, algo_bytes, pmc_name):
+            ach = flop / (ms * 1e-3) / 1e12
+            return {"kernel": name, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                    "traffic": pmc_traffic(pmc_name) if args.config == 2 else None,
+                    "algorithmic_bytes_per_launch": algo_bytes if args.config == 2 else None,
+                    "launches_per_step": n / ps, "avg_launch_us": round(ms * 1e3 / n, 2), "flop_per_launch": flop / n,
+                    "kernel_time_share": round(ms * 1e-3 / dtp, 4), "mfma_products_per_flop": products,
+                    "mfma_issue_frac": round(products * ach / 2500.0, 4)}
+
+        legs = []
+        if w_n > 0:  # Winograd F(2,3): 4 transformed products per 6 algorithmic ones, each on `nprod` MFMAs
+            legs.append(conv_leg(f"wconv_kernel (Winograd F(2,3) halo-staged 3x3 conv, {args.precision}, wconv.hip)", w_ms, w_flop, w_n,
+                                 round(nprod * 2.0 / 3.0, 3), WCONV_ALGO_BYTES_PER_LAUNCH, "wconv_kernel"))
         if h_n > 0:
-            ach = h_flop / (h_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": f"hconv2_kernel<{args.precision}> (halo-staged 3x3 conv, hconv.hip)", "achieved": round(ach, 2),
-                    "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                    "traffic": pmc_traffic("hconv2_kernel") if args.config == 2 else None,
-                    "algorithmic_bytes_per_launch": HCONV_ALGO_BYTES_PER_LAUNCH if args.config == 2 else None,
-                    "launches_per_step": h_n / ps, "avg_launch_us": round(h_ms * 1e3 / h_n, 2), "flop_per_launch": h_flop / h_n,
-                    "kernel_time_share": round(h_ms * 1e-3 / dtp, 4), "mfma_products_per_flop": nprod,
-                    "mfma_issue_frac": round(nprod * ach / 2500.0, 4), "measured_in": f"untimed pass of {ps} steps after the timed region",
-                    "other_mfma_kernel": {"kernel": "igemm_kernel / hgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / ps,
-                                          "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
-                                          "ms_per_step": round(ig_ms / ps, 3), "kernel_time_share": round(ig_ms * 1e-3 / dtp, 4)}}
+            legs.append(conv_leg(f"hconv2_kernel<{args.precision}> (direct halo-staged 3x3 conv, hconv.hip)", h_ms, h_flop, h_n, nprod,
+                                 HCONV_ALGO_BYTES_PER_LAUNCH, "hconv2_kernel"))
+        if legs:
+            legs.sort(key=lambda leg: -leg["kernel_time_share"])  # the dominant kernel leads; the other 3x3-conv kernel rides along
+            roof = dict({"bound": "mfma"}, **legs[0])
+            roof["measured_in"] = f"untimed pass of {ps} steps after the timed region"
+            if len(legs) > 1:
+                roof["other_conv_kernel"] = legs[1]
+            roof["other_mfma_kernel"] = {"kernel": "igemm_kernel / hgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / ps,
+                                         "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
+                                         "ms_per_step": round(ig_ms / ps, 3), "kernel_time_share": round(ig_ms * 1e-3 / dtp, 4)}
         else:  # exact-fp32 mode: the halo kernel is bf16-only, every contraction runs in igemm_kernel on v_mfma_f32_32x32x2_f32
             ach = ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12
             roof = {"bound": "mfma", "kernel": "igemm_kernel<f32> (implicit GEMM, gemm.hip)", "achieved": round(ach, 2), "peak": 157.3,

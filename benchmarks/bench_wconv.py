@@ -43,7 +43,10 @@ for (H, ci, co) in [(256, 256, 256), (256, 512, 256), (128, 256, 256), (128, 512
     ed = (yd[:, :32, :32].double() - ref).abs().max().item()
     ew = (yw[:, :32, :32].double() - ref).abs().max().item()
     td = timed(lambda: ops.conv3x3(ctx, x, w, b, force_tile=512, w_frag=wfrag))
-    tw = timed(lambda: ops.conv3x3_wino(ctx, x, wwin, co, b))
-    twg = timed(lambda: ops.conv3x3_wino(ctx, x, wwin, co, b, gn_ab=ab))
-    print(f"{H}x{H} {ci}->{co}: direct {td:7.1f} us ({flop / td / 1e6:5.0f} TF) err {ed:.2e} | winograd {tw:7.1f} us ({flop / tw / 1e6:5.0f} TF) err {ew:.2e} "
-          f"| winograd+GN {twg:7.1f} us | ratio {td / tw:.2f}", flush=True)
+    tw = {}
+    for mode in (2, 3):  # 16-row / 8-row tiles
+        ctx.check(ctx.lib.cgd_set_wino(ctx.h, mode, 0))
+        tw[mode] = (timed(lambda: ops.conv3x3_wino(ctx, x, wwin, co, b)), timed(lambda: ops.conv3x3_wino(ctx, x, wwin, co, b, gn_ab=ab)))
+    ctx.check(ctx.lib.cgd_set_wino(ctx.h, 1, 0))
+    print(f"{H}x{H} {ci}->{co}: direct {td:7.1f} us ({flop / td / 1e6:5.0f} TF) err {ed:.2e} | winograd 16-row {tw[2][0]:7.1f} (+GN {tw[2][1]:7.1f}) "
+          f"8-row {tw[3][0]:7.1f} (+GN {tw[3][1]:7.1f}) us err {ew:.2e} | best ratio {td / min(tw[2][0], tw[3][0]):.2f}", flush=True)

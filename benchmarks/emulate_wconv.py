@@ -2,10 +2,14 @@
 the packed Winograd weight order, the MFMA 32x32x16 operand / accumulator layout and the output transform, for one 16x16 tile
 (float64 values instead of bf16 hi/lo).  Checks the result against a direct 3x3 convolution and reports the ds_read_b128 bank
 conflicts of the lane groups.  Development aid for changes of the kernel's layouts: python benchmarks/emulate_wconv.py"""
+import sys
+
 import numpy as np
 
 WROW, WSTEPS = 1024, 24
-H = W = 16
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 4  # blocks of 4 tile rows: 4 (16x16 tile) or 2 (8x16 tile)
+TR, NTASK = 4 * NB, (5 if NB == 4 else 3)
+H, W = TR, 16
 CIN, COUT = 64, 32
 rng = np.random.default_rng(0)
 x = rng.standard_normal((H, W, CIN))
@@ -26,17 +30,17 @@ for nb in range(COUT // 32):
                     g = w[n, k, ky, :]
                     U[nb, chunk, q, lane, e] = (g[0], 0.5 * (g[0] + g[1] + g[2]), 0.5 * (g[0] - g[1] + g[2]), g[2])[xi]
 
-acc = np.zeros((4, 4, 64, 16))  # [xi][block][lane][r]  (wave 0 = channel block 0)
+acc = np.zeros((4, NB, 64, 16))  # [xi][block][lane][r]  (wave 0 = channel block 0)
 groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
 groups += [[l + 32 for l in g] for g in groups[:2]]
 worst = 0
 for chunk in range(nchunk):
-    lds = np.full(18 * WROW, np.nan)
+    lds = np.full((TR + 2) * WROW, np.nan)
     for tid in range(256):
         wave, c4, sp = tid >> 6, tid & 7, (tid >> 3) & 7
-        for j in range(5):
+        for j in range(NTASK):
             row = wave + 4 * j
-            if row >= 18:
+            if row >= TR + 2:
                 row -= 2
             yy = y0 + row - 1
             wbase = row * WROW + sp * 32 + (((c4 >> 1) + row) & 3) * 8 + (c4 & 1) * 4
@@ -50,7 +54,7 @@ for chunk in range(nchunk):
                 lds[wbase + xi * 256: wbase + xi * 256 + 4] = V[xi]
     for q in range(WSTEPS):
         ky, xi, ks = q >> 3, (q >> 1) & 3, q & 1
-        for b in range(4):
+        for b in range(NB):
             Amat = np.zeros((32, 16))  # pixel pairs x k
             Bmat = np.zeros((32, 16))  # channels x k
             addr = {}
@@ -76,7 +80,7 @@ out = np.zeros((H, W, 32))
 for lane in range(64):
     l31, hh = lane & 31, lane >> 5
     lr, lp = l31 >> 3, l31 & 7
-    for b in range(4):
+    for b in range(NB):
         for g in range(4):
             for i in range(4):
                 m = [acc[xi, b, lane, 4 * g + i] for xi in range(4)]

@@ -13,9 +13,10 @@
 // 2: single bf16 product (fp32 accumulate)
 enum { CGD_PREC_F32 = 0, CGD_PREC_BF16X3 = 1, CGD_PREC_BF16 = 2 };
 
-// kinds of profiled launches (bench.py): MFMA GEMM kernels (igemm / hgemm incl. their split-K reduce), the halo conv kernel alone
-// (the dominant kernel of the step), GroupNorm forward / backward (all launches of one norm; `work` = algorithmic HBM bytes)
-enum { CGD_PROF_GEMM = 0, CGD_PROF_HCONV = 1, CGD_PROF_GN = 2, CGD_PROF_KINDS = 3 };
+// kinds of profiled launches (bench.py): MFMA GEMM kernels (igemm / hgemm incl. their split-K reduce), the direct halo conv kernel
+// alone, GroupNorm forward / backward (all launches of one norm; `work` = algorithmic HBM bytes), the Winograd halo conv kernel
+// (the dominant kernel of the step: the 3x3 convs of the >= 128x128-pixel levels)
+enum { CGD_PROF_GEMM = 0, CGD_PROF_HCONV = 1, CGD_PROF_GN = 2, CGD_PROF_WCONV = 3, CGD_PROF_KINDS = 4 };
 
 struct ProfRec {
   hipEvent_t a = nullptr, b = nullptr;
@@ -69,8 +70,9 @@ struct cgd_ctx {
                        // parity-tested (tile code 512), but no faster than igemm 64x64 + split-K on the step (22.07 vs 22.07-22.11 ms,
                        // same-box A/B round 2), so off by default
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
-  int wino_mode = 0, wino_min_m = 16384;  // Winograd F(2,3) variant of the halo conv (wconv.hip): 0 off, 1 for convs of >= wino_min_m
-                                          // pixels whose transformed weights were packed (CGD_WINO="1[,<min pixels>]")
+  int wino_mode = 1, wino_min_m = 16384;  // Winograd F(2,3) variant of the halo conv (wconv.hip): 0 off, 1 for convs of >= wino_min_m
+                                          // pixels whose transformed weights were packed (2 / 3: force 16- / 8-row tiles; A/B knob
+                                          // CGD_WINO="<mode>[,<min pixels>]"; same-box A/B: 21.96 -> 20.37 ms/step, 4096: 20.35)
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
   int fuse_gn_max_m = 1 << 30, fuse_gn_min_m = 0;  // ... only for convs of at most / at least this many pixels (A/B knob,
                                                    // CGD_FUSE_GN="1,<max pixels>,<min pixels>")
@@ -201,7 +203,8 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 size_t cgd_wconv_packed_floats(int Co, int Ci);
 int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w /*[Co][Ci][3][3]*/, float* out, int Co, int Ci, int dgrad, hipStream_t s);
 bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p);
-long cgd_wconv_tiles_m(const GemmParams& p);
+int cgd_wconv_nb(const cgd_ctx* ctx, const GemmParams& p);
+long cgd_wconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------

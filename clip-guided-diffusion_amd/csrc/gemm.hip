@@ -557,7 +557,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     CGD_FAIL(ctx, "cgd_launch_gemm: only hgemm2 in one slice fuses an activation into its epilogue (cgd_gemm_fuses_act)");
   if (p.splitk > 1) p.ws = ctx->ws;
   ProfRec pr;
-  CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? CGD_PROF_HCONV : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));
+  CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? (tile == 515 ? CGD_PROF_WCONV : CGD_PROF_HCONV) : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));
   if (use_h) {
     if (tile == 515)
       CGD_TRY(cgd_launch_wconv(ctx, p, s));
@@ -602,13 +602,13 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   p.M = M; p.N = N; p.K = conv ? 9 * Cin : K;
   p.lda = conv ? Cin : K; p.ldb = p.K; p.ldc = N;
   p.conv = conv; p.H = H; p.W = W; p.Cin = Cin; p.weight = weight;
-  if (conv) p.Bpk = dummy;
+  if (conv) p.Bpk = p.Bwk = dummy;
   int tile = 0, kernel = 0;
   const int rc = cgd_plan_gemm(&ctx, p, &tile, &kernel);
   if (rc != 0) return rc;
   long wg;
   if (kernel == 1) {
-    wg = (tile == 515 ? cgd_wconv_tiles_m(p) : cgd_hconv_tiles_m(&ctx, p)) * cdiv(p.N, 128);
+    wg = (tile == 515 ? cgd_wconv_tiles_m(&ctx, p) : cgd_hconv_tiles_m(&ctx, p)) * cdiv(p.N, 128);
   } else if (kernel == 2) {
     wg = cgd_hgemm_tiles(&ctx, p);
   } else {

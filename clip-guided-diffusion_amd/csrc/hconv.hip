@@ -184,7 +184,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     _Pragma("unroll") for (int j = 0; j < NPASS2; ++j)                                              \
         pr[j] = *(const f32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4)); /* zeroed at store time */  \
   }
-#define GN_SILU(X, A, B) ({ const float u_ = (X) * (A) + (B); u_ / (1.f + __expf(-u_)); })
+#define GN_SILU(X, A, B) ({ const float u_ = (X) * (A) + (B); u_ * __builtin_amdgcn_rcpf(1.f + __expf(-u_)); })  /* v_rcp_f32: 1 ulp */
 #define PATCH_STORE2(DSTB, J0, J1)                                                                  \
   {                                                                                                 \
     _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                               \

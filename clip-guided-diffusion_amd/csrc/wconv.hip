@@ -35,9 +35,24 @@ typedef float wf32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int WROW = 1024;            // bf16 elements per patch row: 4 positions x 8 pairs x 32 channels
-constexpr int WPLANE = 18 * WROW;     // elements per plane
 constexpr int WSTEPS = 24;            // (ky, position, kstep) per 32-channel chunk
 constexpr int WRING = 8, WDIST = WRING - 1;
+
+// staging schedule (steps of a chunk): task k of the NEXT chunk is loaded at step w_load_task == k into slot k & 1 and transformed
+// in three pieces at the steps w_proc_task(q, piece) == k.  NB = 4 (16 tile rows, 12 MFMAs per step): 5 tasks, loaded every 4th
+// step, transformed 5..7 steps (1920 MFMA cycles) later.  NB = 2 (8 tile rows, 6 MFMAs per step): 3 tasks, loads at steps 0, 4 and
+// 13 (slot 0 is free after step 12), transformed from steps 10, 14 and 21.
+template <int NB>
+__host__ __device__ constexpr int w_load_task(int q) {
+  if (NB == 4) return ((q & 3) == 0 && q < 20) ? (q >> 2) : -1;
+  return q == 0 ? 0 : q == 4 ? 1 : q == 13 ? 2 : -1;
+}
+template <int NB>
+__host__ __device__ constexpr int w_proc_task(int q, int piece) {
+  const int s = q - piece;
+  if (NB == 4) return (s >= 5 && ((s - 5) & 3) == 0) ? ((s - 5) >> 2) : -1;
+  return s == 10 ? 0 : s == 14 ? 1 : s == 21 ? 2 : -1;
+}
 
 struct WConvParams {
   int lda, ldc, ldr;
@@ -62,10 +77,13 @@ __device__ __forceinline__ float w_silu(float x, float a, float b) {
   return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));  // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
 }
 
-template <bool GN>
+template <bool GN, int NB>
 __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg,
                                                     const float* __restrict__ gng, const WConvParams p) {
+  constexpr int TR = 4 * NB;               // tile rows (16 or 8); the tile is 16 pixels wide
+  constexpr int WPLANE = (TR + 2) * WROW;  // elements per plane
+  constexpr int NTASK = NB == 4 ? 5 : 3;   // staging tasks per thread and chunk: (TR + 2) rows x 8 pairs x 8 channel quads / 256
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * WPLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -78,20 +96,20 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   }
   const int ntm = gridDim.x / ntn;
   const int mt = p.nmajor ? bid % ntm : bid / ntn, n0 = (p.nmajor ? bid / ntm : bid % ntn) << 7;
-  const int tpr = p.W >> 4, tpi = (p.H >> 4) * tpr;
+  const int tpr = p.W >> 4, tpi = (p.H / TR) * tpr;
   const int img = mt / tpi, trem = mt - img * tpi;
-  const int y0 = (trem / tpr) << 4, x0 = (trem % tpr) << 4;
+  const int y0 = (trem / tpr) * TR, x0 = (trem % tpr) << 4;
   const int HW = p.H * p.W;
   const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
   const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
 
-  // ---- staging tasks of this thread: (patch row wave + 4j, pair sp, channel quad c4), j = 0..4
+  // ---- staging tasks of this thread: (patch row wave + 4j, pair sp, channel quad c4), j = 0..NTASK-1
   const int c4 = tid & 7, sp = (tid >> 3) & 7;
-  int rowoff[5], wbase[5];
+  int rowoff[NTASK], wbase[NTASK];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
+  for (int j = 0; j < NTASK; ++j) {
     int row = wave + 4 * j;
-    if (row >= 18) row -= 2;  // task slots beyond the patch repeat rows 16 / 17 (identical values, identical addresses)
+    if (row >= TR + 2) row -= 2;  // task slots beyond the patch repeat its last two rows (identical values, identical addresses)
     const int y = y0 + row - 1;
     rowoff[j] = (unsigned)y < (unsigned)p.H ? (p.ups ? y >> 1 : y) * Ws * p.lda : -1;
     wbase[j] = row * WROW + sp * 32 + (((c4 >> 1) + row) & 3) * 8 + (c4 & 1) * 4;
@@ -114,11 +132,11 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   const long bstride_nb = (long)nchunk * (WSTEPS * 2 * 64);
   const uint4* __restrict__ Bw0 = Bg + (long)(nb0 < nbN ? nb0 : nbN - 1) * bstride_nb + lane;
 
-  wf32x16 acc[4][4];  // [position][block]
+  wf32x16 acc[4][NB];  // [position][block]
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[x][b][e] = 0.f;
 
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   {                                                                                                  \
     const int ky_ = (Q) >> 3, xi_ = ((Q) >> 1) & 3, ks_ = (Q) & 1;                                   \
     const int o_ = fro[(2 * ks_ + ky_) & 3] + ky_ * WROW + xi_ * 256;                                \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                  \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                                 \
       DST[b][0] = *(const wbf16x8*)&(SRCB)[o_ + b * (4 * WROW)];                                     \
       DST[b][1] = *(const wbf16x8*)&(SRCB)[WPLANE + o_ + b * (4 * WROW)];                            \
     }                                                                                                \
@@ -189,26 +207,26 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   }
 #define W_MFMA12(XI, AQ, BQ)                                                                         \
   {                                                                                                  \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                   \
         acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[0]), AQ[b][1], acc[XI][b], 0, 0, 0); \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                   \
         acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[1]), AQ[b][0], acc[XI][b], 0, 0, 0); \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                    \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                   \
         acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[0]), AQ[b][0], acc[XI][b], 0, 0, 0); \
   }
 
-  wbf16x8 af[2][4][2];   // [pipeline slot][block][plane]
+  wbf16x8 af[2][NB][2];  // [pipeline slot][block][plane]
   uint4 bq[WRING][2];    // [ring slot][plane]
   {
     // prologue: stage chunk 0 completely, start the weight ring
     W_GN_LOAD(0);
 #pragma unroll
     for (int q = 0; q < WDIST; ++q) W_B_LOAD(bq[q], Bw0, q);
-    wf32x4 pro[5][4];  // all five tasks in flight (the accumulators are not live yet)
+    wf32x4 pro[NTASK][4];  // all tasks in flight (the accumulators are not live yet)
 #pragma unroll
-    for (int j = 0; j < 5; ++j) W_TASK_LOAD(pro[j], j, 0);
+    for (int j = 0; j < NTASK; ++j) W_TASK_LOAD(pro[j], j, 0);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < NTASK; ++j) {
       W_TASK_P1(lds, pro[j], j);
       W_TASK_P2(lds, pro[j], j);
       W_TASK_P3(lds, pro[j], j);
@@ -233,20 +251,26 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
         const uint4* __restrict__ base = (q + WDIST < WSTEPS) ? cb : nb;
         W_B_LOAD(bq[(q + WDIST) % WRING], base, q2);
       }
-      if ((q & 3) == 0 && q < 20) W_TASK_LOAD(pr[(q >> 2) & 1], q >> 2, cn);
+      if (w_load_task<NB>(q) >= 0) W_TASK_LOAD(pr[w_load_task<NB>(q) & 1], (w_load_task<NB>(q) < 0 ? 0 : w_load_task<NB>(q)), cn);
       W_MFMA12((q >> 1) & 3, af[q & 1], bq[q % WRING]);
-      // task k is loaded at step 4k and transformed at steps 4k + 5 .. 4k + 7
-      if (q >= 5 && ((q - 5) & 3) == 0) W_TASK_P1(nxt, pr[((q - 5) >> 2) & 1], (q - 5) >> 2);
-      if (q >= 6 && ((q - 6) & 3) == 0) W_TASK_P2(nxt, pr[((q - 6) >> 2) & 1], (q - 6) >> 2);
-      if (q >= 7 && ((q - 7) & 3) == 0) W_TASK_P3(nxt, pr[((q - 7) >> 2) & 1], (q - 7) >> 2);
+      {
+        const int k1 = w_proc_task<NB>(q, 0), k2 = w_proc_task<NB>(q, 1), k3 = w_proc_task<NB>(q, 2);
+        if (k1 >= 0) W_TASK_P1(nxt, pr[k1 & 1], (k1 < 0 ? 0 : k1));
+        if (k2 >= 0) W_TASK_P2(nxt, pr[k2 & 1], (k2 < 0 ? 0 : k2));
+        if (k3 >= 0) W_TASK_P3(nxt, pr[k3 & 1], (k3 < 0 ? 0 : k3));
+      }
+      {
+        const bool loads = w_load_task<NB>(q) >= 0;
+        const bool puts = w_proc_task<NB>(q, 0) >= 0 || w_proc_task<NB>(q, 1) >= 0 || w_proc_task<NB>(q, 2) >= 0;
 #pragma unroll
-      for (int r = 0; r < 12; ++r) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
-        if (r < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        // DS read (8 per step)
-        if (r == 8 || r == 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // VMEM read (2 weight fragments)
-        if ((q & 3) == 0 && q < 20 && (r & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // patch loads (4)
-        __builtin_amdgcn_sched_group_barrier(0x002, GN ? 6 : 3, 0);                          // VALU
-        if (q >= 5 && (q & 3) != 0 && (r % 3) == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (<= 4 per step)
+        for (int r = 0; r < 3 * NB; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       // MFMA
+          if (r < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read (2 NB per step)
+          if (NB == 4 ? (r == 8 || r == 10) : (r == 4 || r == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 2 weight fragments
+          if (loads && (NB == 4 ? (r & 1) : r < 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                // 4 patch loads
+          __builtin_amdgcn_sched_group_barrier(0x002, (GN ? 6 : 3) * (NB == 4 ? 1 : 2), 0);       // VALU
+          if (puts && (NB == 4 ? (r % 3) == 2 : r >= 2)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (<= 4 per step)
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   const int cb0 = nb0 * 32;
   if (cb0 >= p.N) return;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < NB; ++b) {
     const long m_even = (long)img * HW + (long)(y0 + 4 * b + lr) * p.W + x0 + 2 * lp;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -334,27 +358,43 @@ int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w, float* out, int Co, int 
   return 0;
 }
 
+// blocks of 4 tile rows per workgroup: 16-row tiles while they give every CU a workgroup, 8-row tiles otherwise (the 128x128 level)
+int cgd_wconv_nb(const cgd_ctx* ctx, const GemmParams& p) {
+  if (ctx->wino_mode == 2) return 4;  // A/B knob: 16-row tiles everywhere
+  if (ctx->wino_mode == 3) return 2;  //           8-row tiles everywhere
+  const long t16 = (long)(p.M / (p.H * p.W)) * (p.H >> 4) * (p.W >> 4) * cdiv(p.N, 128);
+  return (!(p.H & 15) && t16 >= ctx->num_cu) ? 4 : 2;
+}
+
 bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
   if (!p.conv || !p.Bwk || ctx->precision != CGD_PREC_BF16X3 || p.nbatch != 1 || p.splitk > 1) return false;
   if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
-  if (p.H <= 0 || p.W <= 0 || (p.H & 15) || (p.W & 15) || p.M % (p.H * p.W)) return false;
+  if (p.H <= 0 || p.W <= 0 || (p.H & 7) || (p.W & 15) || p.M % (p.H * p.W)) return false;
+  if ((p.H & 15) && ctx->wino_mode == 2) return false;
   if (p.ups && ((p.H | p.W) & 1)) return false;
   if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
   if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
   return true;
 }
 
-long cgd_wconv_tiles_m(const GemmParams& p) { return (long)(p.M / (p.H * p.W)) * (p.H >> 4) * (p.W >> 4); }
+long cgd_wconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p) {
+  return (long)(p.M / (p.H * p.W)) * (p.H / (4 * cgd_wconv_nb(ctx, p))) * (p.W >> 4);
+}
 
 int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   WConvParams p;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.alpha = g.alpha;
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 12L * g.N >= g.M)) ? 1 : 0;
-  dim3 grid((int)cgd_wconv_tiles_m(g) * cdiv(g.N, 128));
-  if (g.gn_ab)
-    hipLaunchKernelGGL((wconv_kernel<true>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p);
-  else
-    hipLaunchKernelGGL((wconv_kernel<false>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p);
+  dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128));
+  const int nb = cgd_wconv_nb(ctx, g);
+#define WC_LAUNCH(GN_, NB_) \
+  hipLaunchKernelGGL((wconv_kernel<GN_, NB_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
+  if (g.gn_ab) {
+    if (nb == 4) WC_LAUNCH(true, 4); else WC_LAUNCH(true, 2);
+  } else {
+    if (nb == 4) WC_LAUNCH(false, 4); else WC_LAUNCH(false, 2);
+  }
+#undef WC_LAUNCH
   return 0;
 }

@@ -42,10 +42,10 @@ int cgd_set_tiles(cgd_ctx* ctx, int large_tile, int small_tile);
 int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks);
 /* HIP-event timing of the profiled launches on their own stream (measurement only; bench.py roofline / hbm legs).
  * cgd_profile_read: out[3k .. 3k+2] = {summed ms, algorithmic work, launches} of kind k: 0 = igemm_kernel / hgemm_kernel launches
- * incl. their split-K reduce [FLOP], 1 = hconv2_kernel launches alone (the dominant kernel) [FLOP], 2 = GroupNorm forward /
- * backward ops, all launches of one norm [algorithmic HBM bytes]; synchronises the device and resets. */
+ * incl. their split-K reduce [FLOP], 1 = hconv2_kernel launches alone [FLOP], 2 = GroupNorm forward / backward ops, all launches
+ * of one norm [algorithmic HBM bytes], 3 = wconv_kernel launches alone (the dominant kernel) [FLOP]; synchronises the device and resets. */
 int cgd_profile(cgd_ctx* ctx, int enable);
-int cgd_profile_read(cgd_ctx* ctx, double* out9);
+int cgd_profile_read(cgd_ctx* ctx, double* out12);
 
 /* ---- UNet epsilon/sigma predictor: replaces guided_diffusion.unet.UNetModel built at
  *      /root/reference/cgd/script_util.py:316 from /root/reference/data/diffusion_model_flags.py ---- */
@@ -207,8 +207,8 @@ int cgd_op_conv3x3(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_pa
 /* Winograd F(2,3)-along-W variant of the halo conv (wconv.hip; H, W multiples of 16, bf16x3 only): w_wino = the torch weights
  * transformed and packed by cgd_op_pack_conv3x3_wino (Co*Ci*12 floats of storage).  gn_ab (optional): per-(sample, channel) pairs
  * {a, b} [Bn][Cin][2]; the kernel then convolves SiLU(x * a + b) (the fused GroupNorm of the UNet's ResBlocks).
- * cgd_set_wino: mode 1 = the UNet's 3x3 convs of >= min_m pixels run on this kernel (set BEFORE cgd_unet_finalize, which packs the
- * transformed weights; default off, environment CGD_WINO="1[,min_m]"). */
+ * cgd_set_wino: mode 1 (default) = the UNet's 3x3 convs of >= min_m (default 16384) pixels run on this kernel, 0 = off, 2 / 3 = 16- / 8-row
+ * tiles everywhere; set BEFORE cgd_unet_finalize, which packs the transformed weights (environment CGD_WINO="<mode>[,min_m]"). */
 int cgd_op_pack_conv3x3_wino(cgd_ctx* ctx, const float* w_torch, float* out, int Co, int Ci, int dgrad, void* stream);
 int cgd_op_conv3x3_wino(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_wino, float* y_nhwc, int ldy, const float* bias,
                         const float* R, int ldr, const float* gn_ab, int Bn, int H, int W, int Cin, int Cout, int upsample_input,

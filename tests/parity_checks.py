@@ -206,33 +206,38 @@ def check_wconv():
     from cgd_amd import ops
     ctx = _ctx(1)
     out = []
-    for (Bn, H, W, Ci, Co, ups, gn) in [(1, 16, 16, 32, 32, 0, 0), (1, 32, 48, 64, 160, 0, 0), (2, 16, 32, 96, 128, 0, 1),
-                                        (1, 64, 64, 64, 96, 1, 0), (1, 32, 32, 128, 256, 1, 1), (1, 128, 128, 32, 64, 0, 1),
-                                        (1, 256, 256, 32, 32, 0, 0)]:
-        Hs, Ws = (H // 2, W // 2) if ups else (H, W)
-        x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
-        w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)
-        b = 0.3 * th.randn(Co, generator=g(7))
-        r = 0.3 * th.randn(Bn, H, W, Co, generator=g(17))
-        xa = x.double()
-        ab = None
-        if gn:  # per-(sample, channel) affine + SiLU applied by the kernel while staging
-            ab = th.stack([0.5 + th.rand(Bn, Ci, generator=g(18)), 0.5 * th.randn(Bn, Ci, generator=g(19))], dim=2).contiguous()
-            xa = F.silu(xa * ab[:, :, 0, None, None].double() + ab[:, :, 1, None, None].double())
-        xin = F.interpolate(xa, scale_factor=2, mode="nearest") if ups else xa
-        ref = F.conv2d(xin, w.double(), b.double(), padding=1).float() + r.permute(0, 3, 1, 2)
-        ww = ops.pack_conv3x3_wino(ctx, w.to(DEV), dgrad=False)
-        got = ops.conv3x3_wino(ctx, x.permute(0, 2, 3, 1).contiguous().to(DEV), ww, Co, b.to(DEV), R=r.to(DEV), upsample_input=bool(ups),
-                               gn_ab=None if ab is None else ab.to(DEV))
-        out.append(rec(f"wconv B{Bn} {H}x{W} {Ci}->{Co} ups{ups} gn{gn}", got.permute(0, 3, 1, 2), ref))
-        if not ups and not gn:
-            dy = th.randn(Bn, Co, H, W, generator=g(8))
-            xr = x.double().requires_grad_()
-            (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
-            sd = unit_seed(xr.grad)
-            wwd = ops.pack_conv3x3_wino(ctx, w.to(DEV), dgrad=True)
-            got = ops.conv3x3_wino(ctx, (dy * sd).permute(0, 2, 3, 1).contiguous().to(DEV), wwd, Ci)
-            out.append(rec(f"wconv dgrad {H}x{W} {Ci}<-{Co}", got.permute(0, 3, 1, 2), (xr.grad * sd).float()))
+    for mode in (2, 3):  # 2: 16x16-pixel tiles (4 column blocks per wavefront), 3: 8x16-pixel tiles (2 blocks)
+        ctx.check(ctx.lib.cgd_set_wino(ctx.h, mode, 0))
+        for (Bn, H, W, Ci, Co, ups, gn) in [(1, 16, 16, 32, 32, 0, 0), (1, 32, 48, 64, 160, 0, 0), (2, 16, 32, 96, 128, 0, 1),
+                                            (1, 64, 64, 64, 96, 1, 0), (1, 32, 32, 128, 256, 1, 1), (1, 128, 128, 32, 64, 0, 1),
+                                            (1, 256, 256, 32, 32, 0, 0), (2, 24, 32, 64, 64, 0, 1)]:
+            if mode == 2 and H % 16:
+                continue
+            Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+            x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
+            w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)
+            b = 0.3 * th.randn(Co, generator=g(7))
+            r = 0.3 * th.randn(Bn, H, W, Co, generator=g(17))
+            xa = x.double()
+            ab = None
+            if gn:  # per-(sample, channel) affine + SiLU applied by the kernel while staging
+                ab = th.stack([0.5 + th.rand(Bn, Ci, generator=g(18)), 0.5 * th.randn(Bn, Ci, generator=g(19))], dim=2).contiguous()
+                xa = F.silu(xa * ab[:, :, 0, None, None].double() + ab[:, :, 1, None, None].double())
+            xin = F.interpolate(xa, scale_factor=2, mode="nearest") if ups else xa
+            ref = F.conv2d(xin, w.double(), b.double(), padding=1).float() + r.permute(0, 3, 1, 2)
+            ww = ops.pack_conv3x3_wino(ctx, w.to(DEV), dgrad=False)
+            got = ops.conv3x3_wino(ctx, x.permute(0, 2, 3, 1).contiguous().to(DEV), ww, Co, b.to(DEV), R=r.to(DEV), upsample_input=bool(ups),
+                                   gn_ab=None if ab is None else ab.to(DEV))
+            out.append(rec(f"wconv m{mode} B{Bn} {H}x{W} {Ci}->{Co} ups{ups} gn{gn}", got.permute(0, 3, 1, 2), ref))
+            if not ups and not gn:
+                dy = th.randn(Bn, Co, H, W, generator=g(8))
+                xr = x.double().requires_grad_()
+                (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
+                sd = unit_seed(xr.grad)
+                wwd = ops.pack_conv3x3_wino(ctx, w.to(DEV), dgrad=True)
+                got = ops.conv3x3_wino(ctx, (dy * sd).permute(0, 2, 3, 1).contiguous().to(DEV), wwd, Ci)
+                out.append(rec(f"wconv m{mode} dgrad {H}x{W} {Ci}<-{Co}", got.permute(0, 3, 1, 2), (xr.grad * sd).float()))
+    ctx.check(ctx.lib.cgd_set_wino(ctx.h, 1, 0))  # back to the default (automatic tile height)
     return out
 
 

@@ -76,7 +76,7 @@ def _plan(handle, **kw):
     a.update(kw)
     out = (C.c_int * 4)()
     rc = handle.cgd_op_plan(a["conv"], a["M"], a["N"], a["K"], a["H"], a["W"], a["Cin"], a["weight"], a["precision"], a["num_cu"], out)
-    return rc, tuple(out)  # (kernel: 0 igemm / 1 hconv2 / 2 hgemm, tile code, split-K, workgroups)
+    return rc, tuple(out)  # (kernel: 0 igemm / 1 hconv2 or wconv (tile code 515) / 2 hgemm, tile code, split-K, workgroups)
 
 
 def test_dispatch_policy_of_the_contraction_launcher():
@@ -87,12 +87,14 @@ def test_dispatch_policy_of_the_contraction_launcher():
     def conv(H, ci, co, **kw):
         return _plan(handle, conv=1, M=H * H, N=co, H=H, W=H, Cin=ci, **kw)
 
-    # 3x3 convs: the halo kernel from 16^2 pixels up; split-K over 32-channel chunks once there are fewer tiles than CUs
-    # (about one workgroup per CU, >= 4 chunks per slice); 8x8 maps fall back to the 64x64 igemm tile (the halo kernel supports
-    # them with half-filled tiles, CGD_HCONV_W8=1, but is no faster there)
-    assert conv(256, 256, 256) == (0, (1, 512, 1, 1024))
-    assert conv(256, 512, 256) == (0, (1, 512, 1, 1024))
-    assert conv(128, 256, 256) == (0, (1, 512, 1, 256))
+    # 3x3 convs: the halo kernels from 16^2 pixels up — the Winograd F(2,3) variant (tile code 515) from 128^2 pixels, with 16x16-pixel
+    # tiles while they give every CU a workgroup and 8x16 below; the direct kernel (512) with split-K over 32-channel chunks once
+    # there are fewer tiles than CUs (about one workgroup per CU, >= 4 chunks per slice); 8x8 maps fall back to the 64x64 igemm
+    # tile (the halo kernel supports them with half-filled tiles, CGD_HCONV_W8=1, but is no faster there)
+    assert conv(256, 256, 256) == (0, (1, 515, 1, 512))
+    assert conv(256, 512, 256) == (0, (1, 515, 1, 512))
+    assert conv(256, 256, 512) == (0, (1, 515, 1, 1024))
+    assert conv(128, 256, 256) == (0, (1, 515, 1, 256))
     assert conv(64, 512, 512) == (0, (1, 512, 2, 256))
     assert conv(32, 512, 512) == (0, (1, 512, 4, 128))
     assert conv(16, 1024, 1024) == (0, (1, 512, 8, 128))

@@ -77,17 +77,24 @@ def test_launch_plan_agrees_with_the_committed_bench_line():
     import json
     from tests import plan_dump
     rows = plan_dump.step_plan()
-    hconv = [r for r in rows if r[6] == "hconv2"]
-    assert len(hconv) == 136 and all(r[1] == "conv3x3" and r[3] >= 256 for r in hconv)
-    gflop = sum(r[10] for r in hconv)
-    assert gflop == pytest.approx(4179.5, abs=0.5)
+    wconv = [r for r in rows if r[6] == "wconv"]    # Winograd halo kernel: the >= 128x128-pixel levels
+    hconv = [r for r in rows if r[6] == "hconv2"]   # direct halo kernel: 64x64 .. 16x16
+    assert len(wconv) == 52 and all(r[1] == "conv3x3" and r[3] >= 16384 and r[8] == 1 for r in wconv)
+    assert len(hconv) == 84 and all(r[1] == "conv3x3" and 256 <= r[3] < 16384 for r in hconv)
+    gflop = sum(r[10] for r in wconv + hconv)
+    assert gflop == pytest.approx(4179.5, abs=0.5)   # 4.18 of the 4.775 TFLOP of a step run on the two halo kernels
+    assert sum(r[10] for r in wconv) == pytest.approx(3247.0, abs=0.5)
     assert sum(1 for r in hconv if r[8] > 1) == 82  # 64^2 and smaller maps: split-K over channel chunks
+    # 16-row tiles while they fill the chip (256x256: 512 / 1024 workgroups), 8-row tiles on the 128x128 level (256 / 384)
+    assert {(r[3], r[9]) for r in wconv} == {(65536, 512), (65536, 1024), (16384, 256), (16384, 384)}
     import bench
-    algo_bytes = sum(4 * r[3] * (r[5][2] + r[4]) + 4 * 9 * r[5][2] * r[4] for r in hconv) / len(hconv)
-    assert algo_bytes == pytest.approx(bench.HCONV_ALGO_BYTES_PER_LAUNCH, rel=1e-3)
+    algo_w = sum(4 * r[3] * (r[5][2] + r[4]) + 4 * 12 * r[5][2] * r[4] for r in wconv) / len(wconv)
+    algo_h = sum(4 * r[3] * (r[5][2] + r[4]) + 4 * 9 * r[5][2] * r[4] for r in hconv) / len(hconv)
+    assert algo_w == pytest.approx(bench.WCONV_ALGO_BYTES_PER_LAUNCH, rel=1e-3)
+    assert algo_h == pytest.approx(bench.HCONV_ALGO_BYTES_PER_LAUNCH, rel=1e-3)
     with open(os.path.join(ROOT, "profiles", "r1_bench_1gpu.json")) as f:
         roof = json.loads(f.read().strip().splitlines()[-1])["roofline"]
-    assert roof["launches_per_step"] == pytest.approx(136.0)
+    assert roof["launches_per_step"] == pytest.approx(136.0)  # round 1: every one of them on hconv2_kernel
     assert roof["flop_per_launch"] * roof["launches_per_step"] == pytest.approx(gflop * 1e9, rel=1e-3)
     # every ViT linear (16 cutouts = 800 token rows) goes to the weight GEMM kernel; the 8x8-pixel convs and M = 1 embeddings do not
     vit = [r for r in rows if r[0] == "vit" and r[1] == "linear" and r[3] == 800]
