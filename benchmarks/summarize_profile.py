@@ -65,19 +65,29 @@ def traffic_json(root, out_path):
     ks = {short(r["Name"]): r for r in kernel_stats(root)}
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, benchmarks/run_profile.sh",
            "correction": "hbm_bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024", "kernels": {}}
+    # all template variants of a kernel (e.g. wconv_kernel<GN, NB>) are merged, weighted by their launches: the figure is the
+    # mean over the same population of launches as bench.py's `algorithmic_bytes_per_launch`
+    merged = {}
     for k in fetch:
         f = fetch[k].get("FETCH_SIZE")
         w = write.get(k, {}).get("WRITE_SIZE")
         if not f or not w:
             continue
-        fb, wb = f[0] / max(f[1], 1) * 1024 * 2, w[0] / max(w[1], 1) * 1024
         key = k.split("<")[0]
-        rec = {"full_name": k, "launches_sampled": f[1], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
-               "hbm_bytes_per_launch": fb + wb}
+        m = merged.setdefault(key, {"variants": [], "n": 0, "fetch": 0.0, "write": 0.0, "ns": 0.0, "calls": 0})
+        m["variants"].append(k)
+        m["n"] += f[1]
+        m["fetch"] += f[0] / max(f[1], 1) * f[1] * 1024 * 2
+        m["write"] += w[0] / max(w[1], 1) * f[1] * 1024
         if k in ks:
-            rec["avg_us_kernel_trace"] = float(ks[k]["AverageNs"]) / 1e3
-        if key not in out["kernels"] or out["kernels"][key]["launches_sampled"] < f[1]:
-            out["kernels"][key] = rec
+            m["ns"] += float(ks[k]["TotalDurationNs"])
+            m["calls"] += int(ks[k]["Calls"])
+    for key, m in merged.items():
+        rec = {"variants": sorted(m["variants"]), "launches_sampled": m["n"], "fetch_bytes_per_launch": m["fetch"] / m["n"],
+               "write_bytes_per_launch": m["write"] / m["n"], "hbm_bytes_per_launch": (m["fetch"] + m["write"]) / m["n"]}
+        if m["calls"]:
+            rec["avg_us_kernel_trace"] = m["ns"] / m["calls"] / 1e3
+        out["kernels"][key] = rec
     with open(out_path, "w") as fh:
         json.dump(out, fh, indent=1)
 
