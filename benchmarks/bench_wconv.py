@@ -27,7 +27,10 @@ def timed(fn):
     return a.elapsed_time(b) / reps * 1e3
 
 
-for (H, ci, co) in [(256, 256, 256), (256, 512, 256), (128, 256, 256), (128, 512, 256), (64, 512, 512)]:
+SHAPES = [(256, 256, 256), (256, 512, 256), (128, 256, 256), (128, 512, 256), (64, 512, 512)]
+if len(sys.argv) > 2:  # "H,ci,co;H,ci,co"
+    SHAPES = [tuple(int(v) for v in s.split(",")) for s in sys.argv[2].split(";")]
+for (H, ci, co) in SHAPES:
     g = th.Generator(device="cuda").manual_seed(1)
     x = th.randn(1, H, H, ci, device="cuda", generator=g)
     wt = th.randn(co, ci, 3, 3, device="cuda", generator=g) * (9 * ci) ** -0.5
