@@ -348,6 +348,15 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
 
 }  // namespace
 
+// host-only view of the staging schedule for the CPU tests: out4 = {task loaded at step q, tasks whose piece 1 / 2 / 3 is
+// transformed at step q} (-1 = none) for nb = 4 (16-row tiles) or 2 (8-row tiles)
+extern "C" int cgd_op_wconv_schedule(int nb, int q, int* out4) {
+  if (!out4 || (nb != 4 && nb != 2) || q < 0 || q >= WSTEPS) return -3;
+  out4[0] = nb == 4 ? w_load_task<4>(q) : w_load_task<2>(q);
+  for (int piece = 0; piece < 3; ++piece) out4[1 + piece] = nb == 4 ? w_proc_task<4>(q, piece) : w_proc_task<2>(q, piece);
+  return 0;
+}
+
 size_t cgd_wconv_packed_floats(int Co, int Ci) { return (size_t)Co * Ci * 12; }  // 2 bf16 planes = one float per transformed weight
 
 int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, hipStream_t s) {
