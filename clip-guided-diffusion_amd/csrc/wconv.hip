@@ -24,7 +24,11 @@
 //     transforms, splits and writes 8 x 8 B; 5 such tasks per thread and chunk (18 rows x 8 pairs x 8 channel quads = 1152
 //     tasks; the last 128 slots repeat rows 16-17: same values to the same addresses), spread over the 24 steps.
 //   * weights: [N/32][Cin/32][ky 3][position 4][kstep 2][plane 2][lane 64][8 bf16], 8-deep register ring.
-// No split-K, W and H multiples of 16 only: the launcher (gemm.hip) uses it for M >= ctx->wino_min_m pixels when enabled.
+//   * NB = 2: the same kernel on 8 x 16-pixel tiles (2 column blocks, 128 accumulators, 10 patch rows = 81,920 B of LDS, 3 staging
+//     tasks, 6 MFMAs per step) for maps whose 16-row tiles would not give every CU a workgroup (the 128 x 128 level: 1.22x the
+//     direct kernel instead of 0.9x, profiles/r2_wconv_microbench.txt).
+// No split-K; W a multiple of 16, H of 8: the launcher (gemm.hip) uses it for M >= ctx->wino_min_m pixels (default 16384).
+// benchmarks/emulate_wconv.py replays the index plumbing below on the CPU (tests/test_wconv_layout.py).
 #include "common.h"
 
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
