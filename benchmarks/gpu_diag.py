@@ -13,7 +13,7 @@ from tests import parity_checks as pc  # noqa: E402
 
 GROUPS = {
     "gemm": [lambda: pc.check_gemm(0), lambda: pc.check_gemm(1), lambda: pc.check_gemm(2)],
-    "conv": [lambda: pc.check_conv(0), lambda: pc.check_conv(1)],
+    "conv": [lambda: pc.check_conv(0), lambda: pc.check_conv(1), pc.check_wconv],
     "norm": [pc.check_norm],
     "elem": [pc.check_elem],
     "attn": [lambda: pc.check_attn(0), lambda: pc.check_attn(1)],

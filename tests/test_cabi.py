@@ -54,6 +54,9 @@ def test_null_handles_are_rejected_not_dereferenced():
     assert handle.cgd_get_precision(None) == -3
     assert handle.cgd_profile(None, 1) == -3
     assert handle.cgd_set_hconv(None, 1, 256) == -3
+    assert handle.cgd_set_wino(None, 1, 0) == -3
+    assert handle.cgd_op_pack_conv3x3_wino(None, None, None, 32, 32, 0, None) == -3
+    assert handle.cgd_op_conv3x3_wino(None, None, 32, None, None, 32, None, None, 0, None, 1, 16, 16, 32, 32, 0, None) == -3
     assert handle.cgd_last_error(None) == b"null context"
     for net in ("unet", "vit", "rn", "lpips"):
         assert getattr(handle, f"cgd_{net}_num_params")(None) == -3
