@@ -79,8 +79,42 @@ typedef float am_f32x16 __attribute__((ext_vector_type(16)));
 typedef float am_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int AM_P68 = 68, AM_P72 = 72, AM_PS = 132, AM_P40 = 40;
 
+// ---- X3 = true: the same contractions on v_mfma_f32_32x32x16_bf16 with the bf16x3 split (al*bh + ah*bl + ah*bh), reading the SAME
+// fp32 LDS tiles with the SAME addresses: a 16-deep k-step takes this lane's 8 values of two consecutive groups m (k = 8m + 4hh + e,
+// any k -> slot assignment is valid as long as both operands use it), splits them in registers and issues 3 MFMAs of 32 cycles
+// where the exact path issues 8 of 64: 5.3x fewer MFMA cycles for ~48 VALU ops per step.  Staged for round 3 (knob CGD_ATTN_X3,
+// default off: not yet validated on the GPU); the exact instantiations are unchanged.
+typedef __bf16 am_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void am_split8(const float (&v)[8], am_bf16x8& hi, am_bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hi[e] = (__bf16)v[e];
+    lo[e] = (__bf16)(v[e] - (float)hi[e]);
+  }
+}
+__device__ __forceinline__ void am_mma16_x3(am_f32x16& acc, const float (&a)[8], const float (&b)[8]) {
+  am_bf16x8 ah, al, bh, bl;
+  am_split8(a, ah, al);
+  am_split8(b, bh, bl);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 // acc[32x32] += sum_{k<64} A[row][k] * B[col][k]   (both k-contiguous; As/Bs = this lane's row base)
+template <bool X3>
 __device__ __forceinline__ void am_mma_nt64(am_f32x16& acc, const float* As, const float* Bs, int hh) {
+  if constexpr (X3) {
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const am_f32x4 a0 = *(const am_f32x4*)(As + 16 * s2 + 4 * hh), a1 = *(const am_f32x4*)(As + 16 * s2 + 8 + 4 * hh);
+      const am_f32x4 b0 = *(const am_f32x4*)(Bs + 16 * s2 + 4 * hh), b1 = *(const am_f32x4*)(Bs + 16 * s2 + 8 + 4 * hh);
+      const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      am_mma16_x3(acc, av, bv);
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const am_f32x4 a = *(const am_f32x4*)(As + 8 * m + 4 * hh);
@@ -90,8 +124,24 @@ __device__ __forceinline__ void am_mma_nt64(am_f32x16& acc, const float* As, con
   }
 }
 // acc += sum_{k<8*NM} A[row][k] * B[k][col]   (A k-contiguous: As = row base; B lane-contiguous: Bs = &B[0][col])
-template <int NM>
+template <int NM, bool X3>
 __device__ __forceinline__ void am_mma_nn(am_f32x16& acc, const float* As, const float* Bs, int pitchB, int hh) {
+  if constexpr (X3) {
+    static_assert(NM % 2 == 0, "bf16x3 k-steps are 16 deep");
+#pragma unroll
+    for (int s2 = 0; s2 < NM / 2; ++s2) {
+      const am_f32x4 a0 = *(const am_f32x4*)(As + 16 * s2 + 4 * hh), a1 = *(const am_f32x4*)(As + 16 * s2 + 8 + 4 * hh);
+      const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bv[e] = Bs[(16 * s2 + 4 * hh + e) * pitchB];
+        bv[4 + e] = Bs[(16 * s2 + 8 + 4 * hh + e) * pitchB];
+      }
+      am_mma16_x3(acc, av, bv);
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     const am_f32x4 a = *(const am_f32x4*)(As + 8 * m + 4 * hh);
@@ -100,8 +150,25 @@ __device__ __forceinline__ void am_mma_nn(am_f32x16& acc, const float* As, const
   }
 }
 // acc += sum_{k<8*NM} A[k][row] * B[k][col]   (both lane-contiguous: As = &A[0][row], Bs = &B[0][col])
-template <int NM>
+template <int NM, bool X3>
 __device__ __forceinline__ void am_mma_tn(am_f32x16& acc, const float* As, int pitchA, const float* Bs, int pitchB, int hh) {
+  if constexpr (X3) {
+    static_assert(NM % 2 == 0, "bf16x3 k-steps are 16 deep");
+#pragma unroll
+    for (int s2 = 0; s2 < NM / 2; ++s2) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k0 = 16 * s2 + 4 * hh + e, k1 = k0 + 8;
+        av[e] = As[k0 * pitchA];
+        av[4 + e] = As[k1 * pitchA];
+        bv[e] = Bs[k0 * pitchB];
+        bv[4 + e] = Bs[k1 * pitchB];
+      }
+      am_mma16_x3(acc, av, bv);
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < NM; ++m)
 #pragma unroll
@@ -141,6 +208,7 @@ __device__ __forceinline__ void am_sstore(float* dst, int pitch, const am_f32x4 
   }
 }
 
+template <bool X3>
 __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo,
                                                            float* __restrict__ Ocopy, float* __restrict__ P, int T, int Tp, int H,
                                                            long qo, long ko, long vo, long step, float alpha) {
@@ -166,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
     am_f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-    am_mma_nt64(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
+    am_mma_nt64<X3>(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       Ss[((r & 3) + 8 * (r >> 2) + 4 * hh) * AM_PS + 32 * w + l31] = (j * 128 + 32 * w + l31 < T) ? sacc[r] * alpha : -INFINITY;
@@ -220,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
     am_f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-    am_mma_nt64(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
+    am_mma_nt64<X3>(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
     const int key = j * 128 + 32 * w + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -230,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
       if (qb * 32 + row < T && key < Tp) Pg[(long)row * Tp + j * 128] = p;
     }
     __syncthreads();
-    am_mma_nn<8>(oacc, &Ss[l31 * AM_PS + 64 * kh], &Vs[(64 * kh) * AM_P72 + 32 * fh + l31], AM_P72, hh);
+    am_mma_nn<8, X3>(oacc, &Ss[l31 * AM_PS + 64 * kh], &Vs[(64 * kh) * AM_P72 + 32 * fh + l31], AM_P72, hh);
   }
   __syncthreads();
   float* red = Ks;  // [2][32][33]
@@ -253,6 +321,7 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
   }
 }
 
+template <bool X3>
 __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout,
                                                               int lddo, const float* __restrict__ Ocopy, const float* __restrict__ P,
                                                               float* __restrict__ dS, float* __restrict__ dqkv, int lddq, int T, int Tp,
@@ -311,7 +380,7 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
     am_f32x16 dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dp[e] = 0.f;
-    am_mma_nt64(dp, &dOs[l31 * AM_P68], &Vs[(32 * w + l31) * AM_P68], hh);
+    am_mma_nt64<X3>(dp, &dOs[l31 * AM_P68], &Vs[(32 * w + l31) * AM_P68], hh);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -320,7 +389,7 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
       if (qb * 32 + row < T && key < Tp) dS[pbase + (long)row * Tp + j * 128] = ds;
     }
     __syncthreads();
-    am_mma_nn<8>(qacc, &Ss[l31 * AM_PS + 64 * kh], &Ks[(64 * kh) * AM_P72 + 32 * fh + l31], AM_P72, hh);
+    am_mma_nn<8, X3>(qacc, &Ss[l31 * AM_PS + 64 * kh], &Ks[(64 * kh) * AM_P72 + 32 * fh + l31], AM_P72, hh);
   }
   __syncthreads();
   float* red = Vs;  // [2][32][33]
@@ -339,6 +408,7 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
   }
 }
 
+template <bool X3>
 __global__ __launch_bounds__(256) void attn_mid_bwd_dkv_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout,
                                                                int lddo, const float* __restrict__ P, const float* __restrict__ dS,
                                                                float* __restrict__ dqkv, int lddq, int T, int Tp, int H, long qo,
@@ -380,9 +450,9 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dkv_kernel(const float* __re
     __syncthreads();
     if (tb + 1 < ntb) DKV_LOAD(tb + 1);
     if (w < 2)
-      am_mma_tn<16>(acc, &Pt[l31], AM_P40, &dOs[32 * w + l31], AM_P72, hh);
+      am_mma_tn<16, X3>(acc, &Pt[l31], AM_P40, &dOs[32 * w + l31], AM_P72, hh);
     else
-      am_mma_tn<16>(acc, &St[l31], AM_P40, &Qs[32 * (w - 2) + l31], AM_P72, hh);
+      am_mma_tn<16, X3>(acc, &St[l31], AM_P40, &Qs[32 * (w - 2) + l31], AM_P72, hh);
   }
 #undef DKV_LOAD
   const long off = h * step + (w < 2 ? vo : ko) + 32 * (w & 1) + l31;
@@ -407,6 +477,7 @@ __device__ __forceinline__ void am_stage_rows(float* dst, int pitch, const float
   }
 }
 
+template <bool X3>
 __global__ __launch_bounds__(256) void attn_s64_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out, int ldo,
                                                            float* __restrict__ P, int T, int Tp, int H, long qo, long ko, long vo, long step,
                                                            float alpha) {
@@ -422,7 +493,7 @@ __global__ __launch_bounds__(256) void attn_s64_fwd_kernel(const float* __restri
   am_f32x16 sacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-  am_mma_nt64(sacc, &Qs[(32 * ri + l31) * AM_P68], &Ks[(32 * ci + l31) * AM_P68], hh);
+  am_mma_nt64<X3>(sacc, &Qs[(32 * ri + l31) * AM_P68], &Ks[(32 * ci + l31) * AM_P68], hh);
 #pragma unroll
   for (int r = 0; r < 16; ++r) Ss[(32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh) * AM_P68 + 32 * ci + l31] = sacc[r] * alpha;
   __syncthreads();
@@ -460,7 +531,7 @@ __global__ __launch_bounds__(256) void attn_s64_fwd_kernel(const float* __restri
   am_f32x16 oacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
-  am_mma_nn<8>(oacc, &Ss[(32 * ri + l31) * AM_P68], &Vs[32 * fh + l31], AM_P72, hh);
+  am_mma_nn<8, X3>(oacc, &Ss[(32 * ri + l31) * AM_P68], &Vs[32 * fh + l31], AM_P72, hh);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -468,6 +539,7 @@ __global__ __launch_bounds__(256) void attn_s64_fwd_kernel(const float* __restri
   }
 }
 
+template <bool X3>
 __global__ __launch_bounds__(256) void attn_s64_bwd_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout, int lddo,
                                                            float* __restrict__ dqkv, int lddq, const float* __restrict__ P, int T, int Tp,
                                                            int H, long qo, long ko, long vo, long step, float alpha) {
@@ -493,7 +565,7 @@ __global__ __launch_bounds__(256) void attn_s64_bwd_kernel(const float* __restri
     am_f32x16 dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dp[e] = 0.f;
-    am_mma_nt64(dp, &Gs[(32 * ri + l31) * AM_P68], &Vs[(32 * ci + l31) * AM_P68], hh);
+    am_mma_nt64<X3>(dp, &Gs[(32 * ri + l31) * AM_P68], &Vs[(32 * ci + l31) * AM_P68], hh);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Ds[(32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh) * AM_P68 + 32 * ci + l31] = dp[r];
   }
@@ -518,7 +590,7 @@ __global__ __launch_bounds__(256) void attn_s64_bwd_kernel(const float* __restri
   // dQ[t][c] = alpha * sum_s dS[t][s] K[s][c]
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  am_mma_nn<8>(acc, &Ds[(32 * ri + l31) * AM_P68], &Ks[32 * ci + l31], AM_P72, hh);
+  am_mma_nn<8, X3>(acc, &Ds[(32 * ri + l31) * AM_P68], &Ks[32 * ci + l31], AM_P72, hh);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -527,7 +599,7 @@ __global__ __launch_bounds__(256) void attn_s64_bwd_kernel(const float* __restri
   // dK[s][c] = alpha * sum_t dS[t][s] Q[t][c]
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  am_mma_tn<8>(acc, &Ds[32 * ri + l31], AM_P68, &Qs[32 * ci + l31], AM_P72, hh);
+  am_mma_tn<8, X3>(acc, &Ds[32 * ri + l31], AM_P68, &Qs[32 * ci + l31], AM_P72, hh);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -536,7 +608,7 @@ __global__ __launch_bounds__(256) void attn_s64_bwd_kernel(const float* __restri
   // dV[s][c] = sum_t P[t][s] dO[t][c]
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  am_mma_tn<8>(acc, &Ps[32 * ri + l31], AM_P68, &Gs[32 * ci + l31], AM_P68, hh);
+  am_mma_tn<8, X3>(acc, &Ps[32 * ri + l31], AM_P68, &Gs[32 * ci + l31], AM_P68, hh);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = 32 * ri + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -563,17 +635,28 @@ int cgd_launch_softmax_bwd_rows(cgd_ctx* ctx, const float* P, float* dP, long ro
 int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, float* out, int ldo, const AttnBufs& bufs,
                  hipStream_t s) {
   const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
+  const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;  // bf16x3 products in the fused kernels (A/B knob, off)
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
   const HeadOff ho = head_off(sh);
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3)) {
-    hipLaunchKernelGGL(attn_s64_fwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
+    if (x3) {
+      hipLaunchKernelGGL((attn_s64_fwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
                        1.f / sqrtf((float)d));
+    } else {
+      hipLaunchKernelGGL((attn_s64_fwd_kernel<false>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
+                       1.f / sqrtf((float)d));
+    }
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
   if (attn_mid_ok(sh, ldq, ldo)) {
-    hipLaunchKernelGGL(attn_mid_fwd_kernel, dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
+    if (x3) {
+      hipLaunchKernelGGL((attn_mid_fwd_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, 1.f / sqrtf((float)d));
+    } else {
+      hipLaunchKernelGGL((attn_mid_fwd_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
+                       ho.v, ho.step, 1.f / sqrtf((float)d));
+    }
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
@@ -611,18 +694,34 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
   const HeadOff ho = head_off(sh);
   const float alpha = 1.f / sqrtf((float)d);
+  const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;
   const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3)) {
-    hipLaunchKernelGGL(attn_s64_bwd_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
+    if (x3) {
+      hipLaunchKernelGGL((attn_s64_bwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, alpha);
+    } else {
+      hipLaunchKernelGGL((attn_s64_bwd_kernel<false>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
+                       ho.v, ho.step, alpha);
+    }
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
   if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3)) {
-    hipLaunchKernelGGL(attn_mid_bwd_dq_kernel, dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
+    if (x3) {
+      hipLaunchKernelGGL((attn_mid_bwd_dq_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
                        dqkv, lddq, T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
-    hipLaunchKernelGGL(attn_mid_bwd_dkv_kernel, dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq,
+    } else {
+      hipLaunchKernelGGL((attn_mid_bwd_dq_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
+                       dqkv, lddq, T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
+    }
+    if (x3) {
+      hipLaunchKernelGGL((attn_mid_bwd_dkv_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq,
                        T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
+    } else {
+      hipLaunchKernelGGL((attn_mid_bwd_dkv_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq,
+                       T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
+    }
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
