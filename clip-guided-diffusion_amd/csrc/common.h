@@ -74,9 +74,6 @@ struct cgd_ctx {
                                           // pixels whose transformed weights were packed (2 / 3: force 16- / 8-row tiles; A/B knob
                                           // CGD_WINO="<mode>[,<min pixels>]"; same-box A/B: 21.96 -> 20.37 ms/step, 4096: 20.35)
   int wino_occ2 = 0;   // 1: wconv_kernel's 8-row tile variant at two workgroups per CU (register diet; staged, CGD_WINO_OCC2=1, not yet run)
-  int splitk_fixup = 0;  // 1: split-K launches of the halo conv kernel reduce their own slices (last-arriving workgroup; hconv.hip FIX);
-                         // staged, CGD_SPLITK_FIXUP=1, not yet run on a GPU
-  int* tile_cnt = nullptr;  // arrival counters of that scheme (4096 ints, allocated on first use, zero between launches)
   int attn_x3 = 0;     // 1: the fused attention kernels contract on bf16x3 MFMA products instead of exact-fp32 MFMA (attn.hip; staged
                        // for round 3, CGD_ATTN_X3=1: NOT yet validated on the GPU, hence off)
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
@@ -189,7 +186,6 @@ struct GemmParams {
   int ld_act = 0, act = 0;  // act: 1 SiLU, 2 QuickGELU
   const float* gn_ab = nullptr;  // conv on the halo kernel only: apply SiLU(x * a + b) to the input while staging it; {a, b} pairs
                                  // [B][Cin][2] of the GroupNorm(+FiLM) that precedes the conv (kernels.h cgd_gn_ab)
-  int fixup = 0;       // set by cgd_launch_gemm: this split-K launch of the halo kernel finishes its own output (ctx->splitk_fixup)
   int defer = 0;       // 1: if the launch splits K, leave the slices in the workspace (ctx->pending): the caller guarantees that the
                        // next kernel reading C is one that consumes a SplitSrc (cgd_take_pending); anything else flushes first
 };

@@ -16,7 +16,6 @@
 // blockIdx -> tile mapping is XCD aware: the 8 XCDs each get a contiguous run of tiles so that the
 // N-tiles of one M-panel and the halo rows of neighbouring M-panels hit the same L2.
 #include "common.h"
-#include "kernels.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -557,17 +556,6 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if ((p.act_out || p.act_in) && !(use_g && p.splitk == 1 && ctx->hgemm_var != 0))
     CGD_FAIL(ctx, "cgd_launch_gemm: only hgemm2 in one slice fuses an activation into its epilogue (cgd_gemm_fuses_act)");
   if (p.splitk > 1) p.ws = ctx->ws;
-  // staged: the direct halo kernel finishes its own split-K output unless a consumer was promised the slices (defer)
-  // (defer: the GroupNorm that follows sums the slices in its statistics sweep, but only on maps above its single-launch size)
-  const bool consumer_takes = p.defer && ctx->defer_mode && (ctx->defer_mode >= 2 || (long)p.H * p.W > cgd_gn_small_hw());
-  if (use_h && tile == 512 && p.splitk > 1 && ctx->splitk_fixup && !consumer_takes && ctx->hconv_var == 0 &&
-      cgd_hconv_tiles_m(ctx, p) * cdiv(p.N, 128) <= 4096) {
-    if (!ctx->tile_cnt) {
-      CGD_HIP(ctx, hipMalloc((void**)&ctx->tile_cnt, 4096 * sizeof(int)));
-      CGD_HIP(ctx, hipMemsetAsync(ctx->tile_cnt, 0, 4096 * sizeof(int), s));
-    }
-    p.fixup = 1;
-  }
   ProfRec pr;
   CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? (tile == 515 ? CGD_PROF_WCONV : CGD_PROF_HCONV) : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));
   if (use_h) {
@@ -585,7 +573,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
       default: CGD_TRY(launch_mode<2>(ctx, p, tile, s)); break;
     }
   }
-  if (p.splitk > 1 && !p.fixup) {
+  if (p.splitk > 1) {
     PendingReduce& q = ctx->pending;
     q.valid = true;
     q.src.ws = p.ws; q.src.bias = p.bias; q.src.R = p.R; q.src.stride = (long)p.M * p.N; q.src.n = p.splitk; q.src.N = p.N;

@@ -50,7 +50,6 @@ struct HConvParams {
   const float* gn;  // GN variant: {a, b} pairs [B][Cin][2] of the GroupNorm(+FiLM) in front of this conv (GemmParams::gn_ab)
   int nmajor;  // 1: channel-tile major order within an XCD's run of tiles (the <= 64x64-pixel levels, where the packed weights
                // are the larger operand: an XCD then owns a few output-channel panels and keeps their weights in its L2)
-  int* cnt;    // FIX instantiations only: one arrival counter per (pixel tile, channel panel), all zero between launches
 };
 
 
@@ -85,11 +84,7 @@ constexpr int NPASS2 = 6;   // staging passes (both tile heights)
 //     registers anyway (4 VALU + 2 transcendental ops per element, in the shadow of the MFMAs), so the normalised tensor is
 //     never written nor re-read: one read + one write of the tensor and one launch less per ResBlock conv.  Padding positions
 //     stay exact zeros (they are padding of the ACTIVATED tensor).
-//   * FIX = true (staged for round 3, knob CGD_SPLITK_FIXUP, off: not yet run on a GPU): a split-K launch finishes its own output.
-//     Every slice stores its partial tile, fences and takes a ticket on the tile's counter; the workgroup that draws the last
-//     ticket re-reads ALL slices in slice order (so the sum does not depend on which one came last), applies alpha / bias /
-//     residual and writes C: no splitk_reduce_kernel launch (5.1 us each, ~130 per step) and no second pass over C.
-template <int MODE, int TH, int NJ, bool GN, bool FIX>
+template <int MODE, int TH, int NJ, bool GN>
 __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                          const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                          const float* __restrict__ gng, const HConvParams p) {
@@ -320,37 +315,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
                 f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         }
       }
-    if constexpr (!FIX) {
-      return;
-    } else {
-      int* const flag = (int*)lds;  // the patch buffers are dead after the loop's last barrier
-      __threadfence();              // release: this workgroup's partial tile is visible device-wide before its ticket is
-      __syncthreads();
-      if (tid == 0) flag[0] = atomicAdd(&p.cnt[blockIdx.x], 1) == (int)gridDim.z - 1;
-      __syncthreads();
-      if (!flag[0]) return;
-      __threadfence();              // acquire: the other slices' stores (L1 invalidated) before they are read below
-      if (tid == 0) p.cnt[blockIdx.x] = 0;  // ready for the next launch on the stream
-      const long slab = (long)p.M * p.N;
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int cb0 = (nb0 + j) * 32;
-          if (cb0 >= p.N || mrow[i] < 0) continue;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int col = cb0 + 8 * g + 4 * hh;
-            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < p.splitk; ++k) sum += *(const f32x4*)&wsg[k * slab + mrow[i] * p.N + col];
-            f32x4 o = sum * p.alpha;
-            if (biasg) o += f32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
-            if (Rg) o += *(const f32x4*)&Rg[mrow[i] * p.ldr + col];
-            *(f32x4*)&Cg[mrow[i] * p.ldc + col] = o;
-          }
-        }
-      return;
-    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -446,26 +411,16 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   p.gn = g.gn_ab;
-  p.cnt = nullptr;
-  if (g.fixup) {  // cgd_launch_gemm decided that this split-K launch finishes its own output (ctx->tile_cnt is allocated and zero)
-    if (cgd_hconv_tile_m(ctx, g) != 128 || (ctx->hconv_var & 4)) CGD_FAIL(ctx, "hconv split-K fix-up: default tile variant only");
-    p.cnt = ctx->tile_cnt;
-  }
   // weights 9 * Cin * N against activations M * Cin (both x 4 B): weight-panel major when the weights are larger
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 9L * g.N >= g.M)) ? 1 : 0;
   const int tm = cgd_hconv_tile_m(ctx, g);
   dim3 grid((int)cgd_hconv_tiles_m(ctx, g) * cdiv(g.N, HB_N), 1, g.splitk > 1 ? g.splitk : 1);
 #define HC2_LAUNCH(M_, TH_, NJ_)                                                                                                   \
   {                                                                                                                                \
-    if (p.cnt) { /* staged in-kernel split-K fix-up (8 x 16 tile, 128 x 32 sub-tile only) */                                      \
-      if (p.gn)                                                                                                                    \
-        hipLaunchKernelGGL((hconv2_kernel<M_, 8, 1, true, true>), grid, dim3(256), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p);   \
-      else                                                                                                                         \
-        hipLaunchKernelGGL((hconv2_kernel<M_, 8, 1, false, true>), grid, dim3(256), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p);  \
-    } else if (p.gn)                                                                                                               \
-      hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_, true, false>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p);  \
+    if (p.gn)                                                                                                                      \
+      hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_, true>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p);  \
     else                                                                                                                           \
-      hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_, false, false>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p); \
+      hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_, false>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p); \
   }
 #define HC2_LAUNCH_T(M_, NJ_)  \
   {                            \

@@ -5,7 +5,6 @@
 
 // ---- norm.hip ---------------------------------------------------------------------------------------------
 size_t cgd_gn_scratch_floats(int B, int HW, int C);
-int cgd_gn_small_hw();  // GroupNorm on maps of at most this many pixels runs in one launch and does not consume deferred split-K slices
 // y = act(GN(x)*gamma+beta [*(1+scale)+shift]);  film = [B][ldfilm] rows (scale | shift, 2C used) or null;  act: 0 none, 1 SiLU.
 // `scratch` (cgd_gn_scratch_floats) keeps the statistics and folded coefficients for the backward pass.
 int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, int B, int HW, int C, const float* gamma,

@@ -1011,8 +1011,6 @@ int pick_chunk(int HW, int B) {
 
 }  // namespace
 
-int cgd_gn_small_hw() { return GN_SMALL_HW; }  // maps of at most this many pixels take the single-launch GroupNorm kernels
-
 size_t cgd_gn_scratch_floats(int B, int HW, int C) {
   const int chunk = pick_chunk(HW, B);
   const int nchunk = cdiv(HW, chunk);
