@@ -82,8 +82,8 @@ constexpr int AM_P68 = 68, AM_P72 = 72, AM_PS = 132, AM_P40 = 40;
 // ---- X3 = true: the same contractions on v_mfma_f32_32x32x16_bf16 with the bf16x3 split (al*bh + ah*bl + ah*bh), reading the SAME
 // fp32 LDS tiles with the SAME addresses: a 16-deep k-step takes this lane's 8 values of two consecutive groups m (k = 8m + 4hh + e,
 // any k -> slot assignment is valid as long as both operands use it), splits them in registers and issues 3 MFMAs of 32 cycles
-// where the exact path issues 8 of 64: 5.3x fewer MFMA cycles for ~48 VALU ops per step.  Staged for round 3 (knob CGD_ATTN_X3,
-// default off: not yet validated on the GPU); the exact instantiations are unchanged.
+// where the exact path issues 8 of 64: 5.3x fewer MFMA cycles for ~48 VALU ops per step.  Default for bf16x3 contexts since round 3
+// (strict parity on the GPU, -0.2 ms/step: profiles/r3_staged_ab.txt); CGD_ATTN_X3=0 selects the exact instantiations.
 typedef __bf16 am_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void am_split8(const float (&v)[8], am_bf16x8& hi, am_bf16x8& lo) {
 #pragma unroll
@@ -635,7 +635,7 @@ int cgd_launch_softmax_bwd_rows(cgd_ctx* ctx, const float* P, float* dP, long ro
 int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, float* out, int ldo, const AttnBufs& bufs,
                  hipStream_t s) {
   const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
-  const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;  // bf16x3 products in the fused kernels (A/B knob, off)
+  const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;  // bf16x3 products in the fused kernels (CGD_ATTN_X3=0: exact)
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
   const HeadOff ho = head_off(sh);
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3)) {

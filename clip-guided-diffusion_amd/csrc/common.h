@@ -73,9 +73,9 @@ struct cgd_ctx {
   int wino_mode = 1, wino_min_m = 16384;  // Winograd F(2,3) variant of the halo conv (wconv.hip): 0 off, 1 for convs of >= wino_min_m
                                           // pixels whose transformed weights were packed (2 / 3: force 16- / 8-row tiles; A/B knob
                                           // CGD_WINO="<mode>[,<min pixels>]"; same-box A/B: 21.96 -> 20.37 ms/step, 4096: 20.35)
-  int wino_occ2 = 0;   // 1: wconv_kernel's 8-row tile variant at two workgroups per CU (register diet; staged, CGD_WINO_OCC2=1, not yet run)
-  int attn_x3 = 0;     // 1: the fused attention kernels contract on bf16x3 MFMA products instead of exact-fp32 MFMA (attn.hip; staged
-                       // for round 3, CGD_ATTN_X3=1: NOT yet validated on the GPU, hence off)
+  int attn_x3 = 1;     // 1 (default since round 3): the fused attention kernels contract on bf16x3 MFMA products when the context precision
+                       // is bf16x3 (attn.hip); 0 = exact-fp32 MFMA (CGD_ATTN_X3=0).  GPU-validated: strict parity, -0.2 ms/step
+                       // (profiles/r3_staged_ab.txt)
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
   int fuse_gn_max_m = 1 << 30, fuse_gn_min_m = 0;  // ... only for convs of at most / at least this many pixels (A/B knob,
                                                    // CGD_FUSE_GN="1,<max pixels>,<min pixels>")

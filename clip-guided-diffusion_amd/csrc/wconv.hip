@@ -40,24 +40,21 @@ namespace {
 
 constexpr int WROW = 1024;            // bf16 elements per patch row: 4 positions x 8 pairs x 32 channels
 constexpr int WSTEPS = 24;            // (ky, position, kstep) per 32-channel chunk
+constexpr int WRING = 8, WDIST = WRING - 1;
 
 // staging schedule (steps of a chunk): task k of the NEXT chunk is loaded at step w_load_task == k into slot k & 1 and transformed
 // in three pieces at the steps w_proc_task(q, piece) == k.  NB = 4 (16 tile rows, 12 MFMAs per step): 5 tasks, loaded every 4th
 // step, transformed 5..7 steps (1920 MFMA cycles) later.  NB = 2 (8 tile rows, 6 MFMAs per step): 3 tasks, loads at steps 0, 4 and
 // 13 (slot 0 is free after step 12), transformed from steps 10, 14 and 21.
-// OCC = 2 (NB = 2 only; staged for round 3, not yet run on a GPU): register diet for TWO workgroups per CU — one task slot, loads at
-// steps 0, 8, 16, transformed 5..7 steps later (two wavefronts share a SIMD, so a step lasts twice as long), 4-deep weight ring.
-template <int NB, int OCC = 1>
+template <int NB>
 __host__ __device__ constexpr int w_load_task(int q) {
   if (NB == 4) return ((q & 3) == 0 && q < 20) ? (q >> 2) : -1;
-  if (OCC == 2) return (q & 7) == 0 ? (q >> 3) : -1;
   return q == 0 ? 0 : q == 4 ? 1 : q == 13 ? 2 : -1;
 }
-template <int NB, int OCC = 1>
+template <int NB>
 __host__ __device__ constexpr int w_proc_task(int q, int piece) {
   const int s = q - piece;
   if (NB == 4) return (s >= 5 && ((s - 5) & 3) == 0) ? ((s - 5) >> 2) : -1;
-  if (OCC == 2) return (s >= 5 && ((s - 5) & 7) == 0) ? ((s - 5) >> 3) : -1;
   return s == 10 ? 0 : s == 14 ? 1 : s == 21 ? 2 : -1;
 }
 
@@ -84,16 +81,13 @@ __device__ __forceinline__ float w_silu(float x, float a, float b) {
   return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));  // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
 }
 
-template <bool GN, int NB, int OCC>
-__global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+template <bool GN, int NB>
+__global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg,
                                                     const float* __restrict__ gng, const WConvParams p) {
   constexpr int TR = 4 * NB;               // tile rows (16 or 8); the tile is 16 pixels wide
   constexpr int WPLANE = (TR + 2) * WROW;  // elements per plane
   constexpr int NTASK = NB == 4 ? 5 : 3;   // staging tasks per thread and chunk: (TR + 2) rows x 8 pairs x 8 channel quads / 256
-  constexpr int WRING = OCC == 2 ? 4 : 8, WDIST = WRING - 1;  // weight-fragment ring (divides the 24 steps)
-  constexpr int PSLOT = OCC == 2 ? 1 : 2;  // staging tasks in flight
-  static_assert(OCC == 1 || NB == 2, "two workgroups per CU only with the 8-row tile (LDS)");
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * WPLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -150,7 +144,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[x][b][e] = 0.f;
 
-  wf32x4 pr[PSLOT][4];  // tasks in flight
+  wf32x4 pr[2][4];  // two tasks in flight
   wf32x4 ga[2];     // GN: {a0, b0, a1, b1}, {a2, b2, a3, b3} of this thread's channels in the chunk being staged
   const wf32x4 z4 = wf32x4{0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ gnimg = GN ? gng + ((long)img * p.Cin + c4 * 4) * 2 : nullptr;
@@ -261,20 +255,17 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
         const uint4* __restrict__ base = (q + WDIST < WSTEPS) ? cb : nb;
         W_B_LOAD(bq[(q + WDIST) % WRING], base, q2);
       }
-      {
-        const int lt = w_load_task<NB, OCC>(q);
-        if (lt >= 0) W_TASK_LOAD(pr[lt & (PSLOT - 1)], (lt < 0 ? 0 : lt), cn);
-      }
+      if (w_load_task<NB>(q) >= 0) W_TASK_LOAD(pr[w_load_task<NB>(q) & 1], (w_load_task<NB>(q) < 0 ? 0 : w_load_task<NB>(q)), cn);
       W_MFMA12((q >> 1) & 3, af[q & 1], bq[q % WRING]);
       {
-        const int k1 = w_proc_task<NB, OCC>(q, 0), k2 = w_proc_task<NB, OCC>(q, 1), k3 = w_proc_task<NB, OCC>(q, 2);
-        if (k1 >= 0) W_TASK_P1(nxt, pr[k1 & (PSLOT - 1)], (k1 < 0 ? 0 : k1));
-        if (k2 >= 0) W_TASK_P2(nxt, pr[k2 & (PSLOT - 1)], (k2 < 0 ? 0 : k2));
-        if (k3 >= 0) W_TASK_P3(nxt, pr[k3 & (PSLOT - 1)], (k3 < 0 ? 0 : k3));
+        const int k1 = w_proc_task<NB>(q, 0), k2 = w_proc_task<NB>(q, 1), k3 = w_proc_task<NB>(q, 2);
+        if (k1 >= 0) W_TASK_P1(nxt, pr[k1 & 1], (k1 < 0 ? 0 : k1));
+        if (k2 >= 0) W_TASK_P2(nxt, pr[k2 & 1], (k2 < 0 ? 0 : k2));
+        if (k3 >= 0) W_TASK_P3(nxt, pr[k3 & 1], (k3 < 0 ? 0 : k3));
       }
       {
-        const bool loads = w_load_task<NB, OCC>(q) >= 0;
-        const bool puts = w_proc_task<NB, OCC>(q, 0) >= 0 || w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 2) >= 0;
+        const bool loads = w_load_task<NB>(q) >= 0;
+        const bool puts = w_proc_task<NB>(q, 0) >= 0 || w_proc_task<NB>(q, 1) >= 0 || w_proc_task<NB>(q, 2) >= 0;
 #pragma unroll
         for (int r = 0; r < 3 * NB; ++r) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       // MFMA
@@ -364,10 +355,9 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
 // host-only view of the staging schedule for the CPU tests: out4 = {task loaded at step q, tasks whose piece 1 / 2 / 3 is
 // transformed at step q} (-1 = none) for nb = 4 (16-row tiles) or 2 (8-row tiles)
 extern "C" int cgd_op_wconv_schedule(int nb, int q, int* out4) {
-  if (!out4 || (nb != 4 && nb != 2 && nb != 22) || q < 0 || q >= WSTEPS) return -3;  // 22: the 8-row tile at two workgroups per CU
-  out4[0] = nb == 4 ? w_load_task<4>(q) : nb == 2 ? w_load_task<2>(q) : w_load_task<2, 2>(q);
-  for (int piece = 0; piece < 3; ++piece)
-    out4[1 + piece] = nb == 4 ? w_proc_task<4>(q, piece) : nb == 2 ? w_proc_task<2>(q, piece) : w_proc_task<2, 2>(q, piece);
+  if (!out4 || (nb != 4 && nb != 2) || q < 0 || q >= WSTEPS) return -3;
+  out4[0] = nb == 4 ? w_load_task<4>(q) : w_load_task<2>(q);
+  for (int piece = 0; piece < 3; ++piece) out4[1 + piece] = nb == 4 ? w_proc_task<4>(q, piece) : w_proc_task<2>(q, piece);
   return 0;
 }
 
@@ -411,13 +401,12 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 12L * g.N >= g.M)) ? 1 : 0;
   dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128));
   const int nb = cgd_wconv_nb(ctx, g);
-#define WC_LAUNCH(GN_, NB_, OCC_) \
-  hipLaunchKernelGGL((wconv_kernel<GN_, NB_, OCC_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
-  const bool occ2 = nb == 2 && ctx->wino_occ2;  // staged A/B knob (CGD_WINO_OCC2=1): two workgroups per CU on the 8-row tile
+#define WC_LAUNCH(GN_, NB_) \
+  hipLaunchKernelGGL((wconv_kernel<GN_, NB_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
   if (g.gn_ab) {
-    if (nb == 4) WC_LAUNCH(true, 4, 1); else if (occ2) WC_LAUNCH(true, 2, 2); else WC_LAUNCH(true, 2, 1);
+    if (nb == 4) WC_LAUNCH(true, 4); else WC_LAUNCH(true, 2);
   } else {
-    if (nb == 4) WC_LAUNCH(false, 4, 1); else if (occ2) WC_LAUNCH(false, 2, 2); else WC_LAUNCH(false, 2, 1);
+    if (nb == 4) WC_LAUNCH(false, 4); else WC_LAUNCH(false, 2);
   }
 #undef WC_LAUNCH
   return 0;

@@ -215,8 +215,8 @@ int cgd_op_conv3x3_wino(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float*
                         void* stream);
 int cgd_set_wino(cgd_ctx* ctx, int mode, int min_m);
 /* host-only (no GPU, no context): the software pipeline of wconv_kernel's patch staging inside one 24-step channel chunk, nb = 4 (16-row
- * tiles), 2 (8-row tiles) or 22 (8-row tiles at two workgroups per CU, staged): out4 = {task whose 4 pixel loads are issued at step q, tasks whose transform piece 1 / 2 / 3 runs at step
- * q}, -1 = none; task k lives in register slot k & 1 (22: one slot).  CPU tests check that no slot is reloaded while its task is still live. */
+ * tiles) or 2 (8-row tiles): out4 = {task whose 4 pixel loads are issued at step q, tasks whose transform piece 1 / 2 / 3 runs at step
+ * q}, -1 = none; task k lives in register slot k & 1.  CPU tests check that no slot is reloaded while its task is still live. */
 int cgd_op_wconv_schedule(int nb, int q, int* out4);
 int cgd_op_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w, const float* bias, float* y_nhwc, int Bn, int H, int W, int Cin,
                    int Cout, void* stream);
