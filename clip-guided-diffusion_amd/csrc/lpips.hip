@@ -202,6 +202,11 @@ struct Lpips : NetBase {
   DevBuf xs, dxs, n0[5], dtap[5], part;
   int B = 0, H = 0, W = 0;
   bool have_ref = false;
+  // test support (cgd_lpips_debug_replay): when set, the trunk pass of the NEXT loss_grad call overwrites the post-ReLU activation of
+  // conv l with replay[l] ([M][cout] rows on the device) right after computing it, so that the taps, the ReLU masks and the pooling
+  // arg-max of the backward pass are taken from the caller's (the oracle's) activations
+  const float* replay[NCONV] = {};
+  bool replay_on = false, in_loss_grad = false;
 
   int build();
   int finalize(hipStream_t s);
@@ -284,6 +289,8 @@ int Lpips::features(const float* x, int Bn, int Hh, int Ww, hipStream_t s) {
       CGD_TRY(cgd_launch_gemm(ctx, g, s));
     }
     hipLaunchKernelGGL(lp_relu_kernel, dim3(grid_of(M * c.cout / 4)), dim3(256), 0, s, c.a.p, M * c.cout / 4);
+    if (replay_on && in_loss_grad && replay[l])
+      CGD_HIP(ctx, hipMemcpyAsync(c.a.p, replay[l], (size_t)M * c.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -311,7 +318,10 @@ int Lpips::loss_grad(const float* x, float gscale, float* loss, float* g, int ac
   if (!have_ref) CGD_FAIL(ctx, "lpips: no reference image set (cgd_lpips_set_reference)");
   ExactScope exact(ctx);
   const int Bn = B, Hh = H, Ww = W;
-  CGD_TRY(features(x, Bn, Hh, Ww, s));
+  in_loss_grad = true;
+  const int frc = features(x, Bn, Hh, Ww, s);
+  in_loss_grad = false;
+  CGD_TRY(frc);
   CGD_HIP(ctx, hipMemsetAsync(loss, 0, (size_t)B * sizeof(float), s));
   // taps: per-pixel loss and the gradient w.r.t. each tapped activation
   int hs[NCONV], ws_[NCONV];
@@ -430,6 +440,15 @@ int cgd_lpips_set_reference(cgd_lpips* v, const float* ref_nchw, int B, int H, i
   if (!v) return -3;
   DeviceScope dev_scope(v->net.ctx);
   return v->net.set_reference(ref_nchw, B, H, W, LS(stream));
+}
+// test support: mask replay (tests/parity_checks.py check_lpips_mask_replay; same idea as cgd_rn_debug_relu_set).  acts: 13 device
+// pointers ([M_l][cout_l] NHWC rows of the post-ReLU activations conv1_1 .. conv5_3 for the image the next loss_grad call is given),
+// or NULL to switch the replay off.  The caller keeps the buffers alive until that call has run.  Not used by the product path.
+int cgd_lpips_debug_replay(cgd_lpips* v, const float* const* acts) {
+  if (!v) return -3;
+  v->net.replay_on = acts != nullptr;
+  for (int l = 0; l < NCONV; ++l) v->net.replay[l] = acts ? acts[l] : nullptr;
+  return 0;
 }
 int cgd_lpips_loss_grad(cgd_lpips* v, const float* x_nchw, float grad_scale, float* loss, float* g_nchw, int accumulate, void* stream) {
   if (!v) return -3;

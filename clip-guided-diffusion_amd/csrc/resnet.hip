@@ -267,6 +267,28 @@ struct ResNet : NetBase {
     g.M = Bn * H * W; g.N = co; g.conv = 1; g.H = H; g.W = W; g.Cin = ci;
     return cgd_launch_gemm(ctx, g, s);
   }
+  // test support (cgd_rn_debug_relu_*): the saved post-ReLU activations of the last forward in call order (stem a1..a3, then o1, o2,
+  // out of every Bottleneck), with their unpadded channel counts
+  struct ReluBuf {
+    float* p;
+    long rows;
+    int channels, ld;
+  };
+  std::vector<ReluBuf> relu_bufs() {
+    std::vector<ReluBuf> v;
+    const int R2 = R / 2;
+    const long M2 = (long)N * R2 * R2;
+    v.push_back({a1.p, M2, s1.cout, s1.coutP});
+    v.push_back({a2.p, M2, s2.cout, s2.coutP});
+    v.push_back({a3.p, M2, s3.cout, s3.coutP});
+    for (Block& b : blocks) {
+      const long Mi = (long)N * b.H * b.W, Mo = Mi / (b.stride * b.stride);
+      v.push_back({b.o1.p, Mi, b.c1.cout, b.planes});
+      v.push_back({b.o2.p, Mi, b.c2.cout, b.planes});
+      v.push_back({b.out.p, Mo, b.c3.cout, b.c4});
+    }
+    return v;
+  }
   void relu(float* x, long n, hipStream_t s) { hipLaunchKernelGGL(rn_relu_kernel, dim3(rn_grid(n / 4)), dim3(256), 0, s, x, n / 4); }
   void relu_bwd(const float* a, float* da, long n, hipStream_t s) {
     hipLaunchKernelGGL(rn_relu_bwd_kernel, dim3(rn_grid(n / 4)), dim3(256), 0, s, a, da, n / 4);
@@ -556,6 +578,35 @@ int cgd_rn_create(cgd_ctx* ctx, const cgd_rn_config* cfg, cgd_rn** out) {
   }
   *out = v;
   return 0;
+}
+// ---- test support: mask replay (tests/parity_checks.py check_resnet_mask_replay) -----------------------------------------------
+// The input gradient of a ReLU network is discontinuous in the activations, so two fp32 implementations disagree wherever a
+// pre-activation changes sign in its last bits.  These entry points let a test overwrite the saved post-ReLU activations of the
+// last forward (the only state the backward masks are taken from) with the oracle's, after which cgd_rn_dgrad must agree with the
+// oracle's autograd at the literal tolerance.  Not used by the product path.
+int cgd_rn_debug_relu_count(cgd_rn* v) {
+  if (!v) return -3;
+  if (!v->net.have_fwd) return 0;
+  return (int)v->net.relu_bufs().size();
+}
+int cgd_rn_debug_relu_info(cgd_rn* v, int index, int64_t* rows, int* channels) {
+  if (!v || !rows || !channels) return -3;
+  if (!v->net.have_fwd) return -2;
+  const auto bufs = v->net.relu_bufs();
+  if (index < 0 || index >= (int)bufs.size()) return -2;
+  *rows = bufs[index].rows;
+  *channels = bufs[index].channels;
+  return 0;
+}
+// src: [rows][channels] fp32 on the device (NHWC rows, unpadded channels)
+int cgd_rn_debug_relu_set(cgd_rn* v, int index, const float* src, void* stream) {
+  if (!v || !src) return -3;
+  DeviceScope dev_scope(v->net.ctx);
+  if (!v->net.have_fwd) return -2;
+  const auto bufs = v->net.relu_bufs();
+  if (index < 0 || index >= (int)bufs.size()) return -2;
+  const auto& b = bufs[index];
+  return cgd_launch_copy2d(v->net.ctx, src, b.channels, nullptr, 0, b.p, b.ld, b.rows, b.channels, (hipStream_t)stream);
 }
 // host-only: parameter manifest (OpenAI `visual.*` names without the prefix, BatchNorm statistics included); no GPU, no context
 int cgd_rn_manifest(const cgd_rn_config* cfg, void (*cb)(const char*, int64_t, void*), void* user) {

@@ -84,6 +84,9 @@ _SIGS = {
     "cgd_rn_finalize": (i32, [vp]),
     "cgd_rn_forward": (i32, [vp, vp, i32, vp, vp]),
     "cgd_rn_dgrad": (i32, [vp, vp, vp, vp]),
+    "cgd_rn_debug_relu_count": (i32, [vp]),
+    "cgd_rn_debug_relu_info": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i32)]),
+    "cgd_rn_debug_relu_set": (i32, [vp, i32, vp, vp]),
     "cgd_lpips_create": (i32, [vp, C.POINTER(vp)]),
     "cgd_lpips_destroy": (None, [vp]),
     "cgd_lpips_num_params": (i32, [vp]),
@@ -92,6 +95,7 @@ _SIGS = {
     "cgd_lpips_finalize": (i32, [vp]),
     "cgd_lpips_set_reference": (i32, [vp, vp, i32, i32, i32, vp]),
     "cgd_lpips_loss_grad": (i32, [vp, vp, f32, vp, vp, i32, vp]),
+    "cgd_lpips_debug_replay": (i32, [vp, C.POINTER(vp)]),
     "cgd_cutouts_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cgd_cutouts_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cgd_spherical_loss": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),

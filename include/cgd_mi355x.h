@@ -116,6 +116,13 @@ int cgd_rn_set_param(cgd_rn* v, const char* name, const float* data, int64_t num
 int cgd_rn_finalize(cgd_rn* v);
 int cgd_rn_forward(cgd_rn* v, const float* img, int N, float* emb /* (N,out_dim) */, void* stream);
 int cgd_rn_dgrad(cgd_rn* v, const float* d_emb, float* d_img /* (N,3,res,res) */, void* stream);
+/* Test support, not on the product path (no reference counterpart): mask replay.  The post-ReLU activations saved by the last
+ * forward (call order: stem relu1..3, then relu1, relu2, relu3 of every Bottleneck; [3P] clip/model.py ModifiedResNet) can be
+ * overwritten with the oracle's ([rows][channels] NHWC rows on the device), so that cgd_rn_dgrad takes the oracle's ReLU masks and
+ * the rest of the backward chain is graded at the literal tolerance (tests/parity_checks.py check_resnet_mask_replay). */
+int cgd_rn_debug_relu_count(cgd_rn* v);
+int cgd_rn_debug_relu_info(cgd_rn* v, int index, int64_t* rows, int* channels);
+int cgd_rn_debug_relu_set(cgd_rn* v, int index, const float* src, void* stream);
 
 /* ---- LPIPS-VGG16 init loss: replaces lpips.LPIPS(net='vgg') (cgd/cgd.py:147-148) and `lpips_vgg(x_in, init_tensor)` with its
  *      backward to x_in (cgd.py:220-224,228).  Parameters use the package's names (net.slice{k}.{idx}.weight|bias,
@@ -132,6 +139,10 @@ int cgd_lpips_finalize(cgd_lpips* v);
 int cgd_lpips_set_reference(cgd_lpips* v, const float* ref_nchw, int B, int H, int W, void* stream);
 int cgd_lpips_loss_grad(cgd_lpips* v, const float* x_nchw, float grad_scale, float* loss /* [B] */, float* g_nchw, int accumulate,
                         void* stream);
+/* Test support, not on the product path: mask replay.  acts = 13 device pointers (post-ReLU activations conv1_1 .. conv5_3 of the
+ * image the NEXT cgd_lpips_loss_grad call is given, [B*h_l*w_l][cout_l] NHWC rows) or NULL to switch it off: the trunk pass of that
+ * call continues from these activations, so taps, ReLU masks and max-pool arg-max are the caller's (the oracle's). */
+int cgd_lpips_debug_replay(cgd_lpips* v, const float* const* acts);
 
 /* ---- cutouts: replaces MakeCutouts.forward (cgd/modules.py:50-66) + x.add(1).div(2) (cgd.py:190) + CLIP_NORMALIZE
  *      (clip_util.py:45).  coords: device int32 [cutn][4] = (oy, ox, h, w) of each (possibly truncated) crop. ---- */

@@ -85,6 +85,23 @@ class MakeCutouts(th.nn.Module):
         return th.cat(outs)
 
 
+def gating(total, current_timestep, num_cutouts, reduce_clip=False, progressive_cutout=False):
+    """(guidance skipped on this call, cutouts of this call) — /root/reference/cgd/cgd.py:155-175, as a function of the closure
+    counter `current_timestep` (cgd.py:149,265-267).  `make_cond_fn` below calls it, so it is pinned bit-exactly by the trajectories
+    recorded from the real reference generator (tests/golden/reference_condfn.*: the reduce_clip + progressive_cutout case); the
+    whole-step tests take their per-step tape from here, not from the product's own schedule."""
+    pct = (total - current_timestep) / total
+    if reduce_clip and pct < 0.7:
+        if int((pct - 0.2) * total) % 4 != 0:
+            return True, 0
+    if progressive_cutout:
+        if pct < 0.3:
+            return False, max(4, num_cutouts // 4)
+        if pct < 0.7:
+            return False, max(8, num_cutouts // 2)
+    return False, num_cutouts
+
+
 def make_cond_fn(*, diffusion, clip_model, make_cutouts, target_embeds, weights, num_cutouts,
                  clip_guidance_scale=1000.0, tv_scale=150.0, range_scale=50.0, sat_scale=0.0,
                  use_magnitude=False, reduce_clip=False, progressive_cutout=False, cached_cutouts=False,
@@ -101,15 +118,9 @@ def make_cond_fn(*, diffusion, clip_model, make_cutouts, target_embeds, weights,
         log = {}
         n = x.shape[0]
         cur = state["current_timestep"]
-        total = diffusion.num_timesteps
-        pct = (total - cur) / total
-        if reduce_clip and pct < 0.7:
-            if int((pct - 0.2) * total) % 4 != 0:
-                return th.zeros_like(x)
-        if progressive_cutout:
-            cutn = max(4, num_cutouts // 4) if pct < 0.3 else (max(8, num_cutouts // 2) if pct < 0.7 else num_cutouts)
-        else:
-            cutn = num_cutouts
+        skipped, cutn = gating(diffusion.num_timesteps, cur, num_cutouts, reduce_clip, progressive_cutout)
+        if skipped:
+            return th.zeros_like(x)
         fac = float(diffusion.sqrt_one_minus_alphas_cumprod[cur])
         x_in = out["pred_xstart"] * fac + x * (1 - fac)
         coords = None

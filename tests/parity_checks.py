@@ -540,3 +540,102 @@ def check_resnet(name, precision, N=2, config=None):
     # forward: the literal tolerance; gradient: the named `relu-flips` criterion (see rec_flips).  ReLU towers run their
     # contractions on exact-fp32 MFMA products whatever the context precision is (resnet.hip), so one tolerance serves both.
     return [rec(f"{tag} forward", ed, e.detach().float()), rec_flips(f"{tag} dgrad", di, (ir.grad * sd).float(), 3e-3)]
+
+
+# ---- mask replay: ReLU / max-pool towers graded strictly ----------------------------------------------------------------------------------
+class _CaptureRelu:
+    """Records every F.relu output of an oracle forward pass, in call order (the oracle modules call torch.nn.functional.relu)."""
+
+    def __enter__(self):
+        self.acts, self._orig = [], F.relu
+
+        def relu(x, inplace=False):
+            y = self._orig(x)
+            self.acts.append(y.detach())
+            return y
+
+        F.relu = relu
+        return self
+
+    def __exit__(self, *exc):
+        F.relu = self._orig
+        return False
+
+
+def _nhwc_rows(a):
+    """(N,C,H,W) oracle activation -> contiguous fp32 [N*H*W][C] rows on the device."""
+    return a.permute(0, 2, 3, 1).reshape(-1, a.shape[1]).float().contiguous().to(DEV)
+
+
+def check_resnet_mask_replay(name, precision, N=2, config=None):
+    """CLIP ModifiedResNet tower, input gradient at the LITERAL tolerance: the post-ReLU activations the device saved in its forward
+    pass are overwritten with the oracle's (cgd_rn_debug_relu_set), so both sides differentiate through the same ReLU masks and what
+    is graded is the rest of the backward chain (1x1 / 3x3 dgrad GEMMs, pooling adjoints, attention-pool backward).  Complements
+    `check_resnet`, whose gradient record is judged by the looser named criterion `relu-flips` because its masks are the device's."""
+    import ctypes as C
+    from cgd_amd import nets
+    from oracle import clip_resnet as ocr
+    ctx = _ctx(precision)
+    ref = ocr.synthetic_init_(ocr.ClipResNetImageModel(name, config)).double().eval()
+    for prm in ref.parameters():
+        prm.requires_grad_(False)
+    dev = nets.ClipResNetTower(ctx, name, config)
+    dev.load_clip_state_dict({k: v.float().to(DEV) for k, v in ref.state_dict().items() if "num_batches_tracked" not in k})
+    res = ref.visual.input_resolution
+    img = th.randn(N, 3, res, res, generator=g(75))
+    de = th.randn(N, ref.visual.output_dim, generator=g(76))
+    ir = img.double().requires_grad_()
+    with _CaptureRelu() as cap:
+        e = ref.encode_image(ir)
+    (e * de.double()).sum().backward()
+    sd = unit_seed(ir.grad)
+    ed = dev.encode_image(img.to(DEV))
+    lib = ctx.lib
+    n = lib.cgd_rn_debug_relu_count(dev.h)
+    assert n == len(cap.acts), f"device saves {n} ReLU activations, the oracle ran {len(cap.acts)}"
+    keep = []
+    for i, a in enumerate(cap.acts):
+        rows, ch = C.c_int64(), C.c_int()
+        ctx.check(lib.cgd_rn_debug_relu_info(dev.h, i, C.byref(rows), C.byref(ch)))
+        src = _nhwc_rows(a)
+        assert tuple(src.shape) == (rows.value, ch.value), (i, tuple(src.shape), rows.value, ch.value)
+        keep.append(src)
+        ctx.check(lib.cgd_rn_debug_relu_set(dev.h, i, src.data_ptr(), ctx.stream()))
+    di = dev.dgrad((de * sd).to(DEV))
+    th.cuda.synchronize()
+    tag = f"resnet mask-replay[{name if config is None else config} p{precision} N{N}]"
+    return [rec(f"{tag} forward", ed, e.detach().float()), rec(f"{tag} dgrad (oracle masks)", di, (ir.grad * sd).float())]
+
+
+def check_lpips_mask_replay(precision, shapes=((2, 64, 64), (1, 96, 128))):
+    """LPIPS-VGG16 gradient at the literal tolerance with the oracle's ReLU masks and max-pool arg-max: the trunk pass of the graded
+    call continues from the oracle's post-ReLU activations (cgd_lpips_debug_replay); graded: tap kernels, ReLU / max-pool adjoints,
+    conv dgrads, scaling layer."""
+    import ctypes as C
+    from cgd_amd import nets
+    from oracle import lpips_vgg as olp
+    ctx = _ctx(precision)
+    out = []
+    orc = olp.synthetic_init_(olp.LpipsVGG()).double().eval()
+    dev_net = nets.LpipsVGG(ctx)
+    dev_net.load_state_dict({k: v.float().to(DEV) for k, v in orc.lpips_state_dict().items()})
+    for (B, H, W) in shapes:
+        ref = (th.rand(B, 3, H, W, generator=g(70)) * 2 - 1)
+        x = (ref + 0.3 * th.randn(B, 3, H, W, generator=g(71))).clamp(-1.2, 1.2)
+        xr = x.double().requires_grad_()
+        with _CaptureRelu() as cap:
+            val = orc(xr, ref.double()).flatten()
+        val.sum().backward()
+        gs = unit_seed(xr.grad)
+        acts = [_nhwc_rows(a) for a in cap.acts[:13]]  # the first 13 calls are the trunk pass over in0 = x
+        dev_net.set_reference(ref.to(DEV))
+        table = (C.c_void_p * 13)(*[a.data_ptr() for a in acts])
+        ctx.check(ctx.lib.cgd_lpips_debug_replay(dev_net.h, table))
+        try:
+            loss, gx = dev_net.loss_grad(x.to(DEV), grad_scale=gs)
+            th.cuda.synchronize()
+        finally:
+            ctx.check(ctx.lib.cgd_lpips_debug_replay(dev_net.h, None))
+        out.append(rec(f"lpips mask-replay loss[p{precision}] B{B} {H}x{W}", loss, val.float()))
+        out.append(rec(f"lpips mask-replay grad (oracle masks)[p{precision}] B{B} {H}x{W}", gx, (xr.grad * gs).float()))
+    return out

@@ -116,3 +116,18 @@ def test_clip_modified_resnet(name, precision, config):
     # (parity_checks.rec_flips explains why); the tower runs on exact-fp32 MFMA products in either context precision;
     # the x4 / x16 widths (80 / 96, stems 40 / 48) exercise the zero-padded channel layout
     _assert_all(pc.check_resnet(name, precision, config=config), allowed=("strict", "relu-flips"))
+
+
+@pytest.mark.parametrize("name,precision,config", [("tiny", 1, (64, 64, (1, 1, 1, 1), 128, 32)), ("RN50", 1, None),
+                                                   ("x4-tiny", 1, (96, 80, (1, 1, 1, 1), 64, 40))])
+def test_clip_modified_resnet_gradient_strict_with_replayed_masks(name, precision, config):
+    """with the ORACLE's ReLU masks forced on the device (saved activations overwritten through the test-support
+    ABI), the ResNet tower's input gradient meets north_star's literal tolerance — what `relu-flips` tolerates in
+    test_clip_modified_resnet is mask flips only, not a kernel error."""
+    _assert_all(pc.check_resnet_mask_replay(name, precision, config=config))
+
+
+def test_lpips_vgg16_gradient_strict_with_replayed_masks():
+    """Same for LPIPS-VGG16 (ReLU masks and max-pool arg-max taken from the oracle's activations), at the shapes of
+    test_lpips_vgg16_loss_and_grad and at 256x256, the per-sample shape of a config-4-style init-image run."""
+    _assert_all(pc.check_lpips_mask_replay(1, shapes=((2, 64, 64), (1, 96, 128), (1, 256, 256))))

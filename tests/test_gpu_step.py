@@ -78,6 +78,49 @@ def test_config5_nonsquare_256x288_step():
     _assert_all(sc.check_step("cfg256", 1, steps=1, hw=(256, 288), respacing="500", P=3, cutn=4))
 
 
+def test_config3_full_shape_ddim250_vit_b16_cutn32_step():
+    """BASELINE configs[2] at its full per-GPU shape: 256x256 class-cond UNet (554 M), ddim250, cutn 32, CLIP
+    ViT-B/16 (197 tokens), 4 prompts; the batch of 4 is sharded one sample per GPU, so the per-GPU step is B = 1
+    against the 4 weighted prompts.  Also separates the yielded (unconditioned) pred_xstart from the x0' that builds the DDIM sample."""
+    _assert_all(sc.check_step("cfg256", 1, ddim=True, respacing="250", steps=1, cutn=32, vit_name="ViT-B/16", P=4,
+                              weights=[1.0, 0.7, 0.5, 0.3], scales=(1000.0, 150.0, 50.0), head_scale=1.0))
+
+
+def test_config4_full_shape_512_cutn64_lpips_skip500_step():
+    """BASELINE configs[3] at its full per-GPU shape: 512x512 UNet (559 M, rescale_timesteps), respace 1000, cutn 64, ViT-B/32, init
+    image + skip_timesteps 500 + init_scale 1000 (LPIPS-VGG16 on 512x512), with the closure-counter quirk of the reference generator
+    (cgd.py:149,265-267: the counter starts at 999 while t starts at 499, so fac = sqrt(1 - abar_999)).  g and x_{t-1} contain the
+    LPIPS leg: named `relu-flips` criterion (strict on the LPIPS backward chain: test_lpips_vgg16_gradient_strict_with_replayed_masks)."""
+    _assert_all(sc.check_step("cfg512", 1, respacing="1000", steps=1, cutn=64, vit_name="ViT-B/32", init_scale=1000.0, t_first=499,
+                              counter_quirk=True, rescale_timesteps=True, scales=(1000.0, 150.0, 50.0), head_scale=1.0),
+                allowed=("strict", "relu-flips"))
+
+
+def test_config5_full_shape_256x288_rn50_plus_vit_l14_step():
+    """BASELINE configs[4] at its full per-GPU shape: 256x288 (width_offset 32), respace 500, three weighted prompts (one negative),
+    RN50 + ViT-L/14 dual CLIP, cutn 16.  The RN50 leg makes g discontinuous (ReLU masks): `relu-flips` for g, its legs and x_{t-1};
+    strict on the RN50 backward chain: test_clip_modified_resnet_gradient_strict_with_replayed_masks."""
+    _assert_all(sc.check_step("cfg256", 1, hw=(256, 288), respacing="500", steps=1, cutn=16, P=3, rn_name="RN50", dual=True,
+                              vit2_name="ViT-L/14", scales=(1000.0, 150.0, 50.0), head_scale=1.0), allowed=("strict", "relu-flips"))
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_early_schedule_step_eps_consistent_unet(precision):
+    """the FIRST step of the schedule (t = T-1, no skip), where x0-hat = 157 (x - eps-hat), with a synthetic UNet made
+    eps-consistent at the test input (step_checks.make_eps_consistent_): x0-hat is O(1) although both of its terms are 157 times
+    larger, and the two legs of g cancel 157-fold.  x_{t-1}, the loss scalars, eps-hat and every leg at unit peak are graded at the
+    literal tolerance; x0-hat and g carry the named criteria `amplified` / `cancelling-legs` with their strict verdicts reported
+    (benchmarks/early_schedule_report.py prints the numbers)."""
+    _assert_all(sc.check_step("mini", precision, respacing="50", steps=1, t_first=49, head_scale=1.0, eps_consistent=True),
+                allowed=("strict", "amplified", "cancelling-legs"))
+
+
+def test_early_schedule_step_headline_shape():
+    """The same at BASELINE configs[1]'s shape: 256x256, respace 250, t = 249, cutn 16, ViT-B/32, bf16x3."""
+    _assert_all(sc.check_step("cfg256", 1, respacing="250", steps=1, t_first=249, cutn=16, vit_name="ViT-B/32", head_scale=1.0,
+                              scales=(1000.0, 150.0, 50.0), eps_consistent=True), allowed=("strict", "amplified", "cancelling-legs"))
+
+
 def test_dropin_generator_yields_batch_idx_path(tmp_path, monkeypatch):
     """reference test.py:159-168 (yield order for batch_size=2) and :139-143 (first item not None), on synthetic weights."""
     monkeypatch.setenv("CGD_SYNTHETIC_WEIGHTS", "1")

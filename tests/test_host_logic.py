@@ -134,11 +134,14 @@ def test_reduce_clip_and_progressive_cutout_schedule():
     assert dg.guidance_schedule(N, N - 1, 8, progressive_cutout=True) == (False, 4)      # max(4, 8 // 4)
     assert dg.guidance_schedule(N, N - 100, 8, progressive_cutout=True) == (False, 8)    # max(8, 8 // 2)
     assert dg.guidance_schedule(N, N - 1, 64, progressive_cutout=True) == (False, 16)
-    # the oracle's closure gates identically (same expression, tests/step_checks.py compares the trajectories on the GPU)
+    # the product's schedule against the oracle's restatement (`og.gating`, the function the oracle's cond_fn closure calls and
+    # that the real-reference trajectories of tests/golden/reference_condfn.* pin): every counter value, all four flag combinations
     from oracle import guidance as og
-    import inspect
-    src = inspect.getsource(og.make_cond_fn)
-    assert "int((pct - 0.2) * total) % 4 != 0" in src and "max(4, num_cutouts // 4)" in src and "max(8, num_cutouts // 2)" in src
+    for total, n in ((250, 16), (50, 16), (25, 4), (1000, 64), (500, 8)):
+        for rc in (False, True):
+            for pcut in (False, True):
+                for cur in range(total):
+                    assert dg.guidance_schedule(total, cur, n, rc, pcut) == og.gating(total, cur, n, rc, pcut), (total, n, rc, pcut, cur)
 
 
 def test_cached_cutouts_reuse_and_argument_order_quirk():
