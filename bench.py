@@ -294,11 +294,13 @@ def main():
     for _ in range(args.warmup):
         next(steps)
     sync()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     for _ in range(args.steps):
         out = next(steps)
+    t_enq = time.perf_counter() - t0  # the host has ENQUEUED the K steps (it runs ahead of the GPU until a queue limit stalls it)
     sync()
     dt = time.perf_counter() - t0
+    cpu_s = time.process_time() - c0  # CPU seconds (user + sys, all threads of this rank) spent driving the K steps
     finite = bool(th.isfinite(out["sample"]).all().item())
     peak = float(out["sample"].abs().max().item())
 
@@ -356,13 +358,18 @@ def main():
                    "algorithmic_gbytes_per_step": round(gn_bytes / ps / 1e9, 3), "ms_per_step": round(gn_ms / ps, 3), "ops_per_step": gn_n / ps,
                    "kernel_time_share": round(gn_ms * 1e-3 / dtp, 4)}
     assert finite, "non-finite sample"
-    tmax = th.tensor([dt], device=dev if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl" else "cpu", dtype=th.float64)
-    per_rank = [dt]
+    tdev = dev if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
+    tmax = th.tensor([dt], device=tdev, dtype=th.float64)
+    per_rank, host = [dt], [(cpu_s, t_enq)]
     if world > 1:
         gathered = [th.zeros_like(tmax) for _ in range(world)]
         dist.all_gather(gathered, tmax)
         per_rank = [float(t.item()) for t in gathered]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        hv = th.tensor([cpu_s, t_enq], device=tdev, dtype=th.float64)
+        hg = [th.zeros_like(hv) for _ in range(world)]
+        dist.all_gather(hg, hv)
+        host = [(float(h[0].item()), float(h[1].item())) for h in hg]
     tmax = tmax.item()
 
     if rank == 0:
@@ -383,6 +390,12 @@ def main():
                        "parallelism": f"{world} independent samples (1/GPU), weights broadcast once over RCCL, no per-step collective",
                        "world_size_checked": dist.get_world_size() if world > 1 else 1,
                        "ms_per_step_per_rank": [round(t / args.steps * 1e3, 3) for t in per_rank],
+                       # multi-GPU host readiness: CPU time each rank's driver process burns per step (user + sys,
+                       # all threads) and the wall time it needs to ENQUEUE a step; the host keeps N ranks fed while
+                       # N * host_cpu_ms_per_step / ms_per_step stays below the cores it has
+                       "host_cpu_ms_per_step_per_rank": [round(c / args.steps * 1e3, 3) for c, _ in host],
+                       "host_enqueue_ms_per_step_per_rank": [round(e / args.steps * 1e3, 3) for _, e in host],
+                       "host_cores": usable_cores(1 << 20),
                        "trajectory": f"chained: every step consumes the previous step's sample; chains of {start + 1} steps from "
                                      f"x_t = q_sample(x0*, t={start}) down to t = 0 (init-image prologue, skip_timesteps {N - 1 - start})",
                        "timed_seconds": round(tmax, 3), "last_sample_peak": round(peak, 3),

@@ -39,7 +39,11 @@ def main():
         row = {"H": H, "cin": ci, "cout": co, "count": cnt, "flop": flop, "us": {}}
         line = f"{H:>3d}^2 {ci:>4d}->{co:<4d} x{cnt:<3d}"
         for t in TILES:
-            if ((t % 1000) >= 128 and (H * H < 128 or co < 128)) or (t >= 5120 and H * H < 256):
+            if t == 516:
+                if H * H > 4096:
+                    line += f"{'-':>14s}"
+                    continue
+            elif ((t % 1000) >= 128 and (H * H < 128 or co < 128)) or (t >= 5120 and H * H < 256):
                 line += f"{'-':>14s}"
                 continue
             tcode = t
@@ -69,6 +73,10 @@ def main():
     with open(f"gpurun_out/ops_{tag}.json", "w") as f:
         json.dump(res, f, indent=1)
     # best-per-shape projection
+    if "516" in [str(t) for t in TILES]:
+        tk = sum((r["us"].get("516") or 0) * r["count"] for r in res if r["us"].get("516"))
+        t0 = sum((r["us"].get("0") or 0) * r["count"] for r in res if r["us"].get("516"))
+        print(f"small-map layers: weight-streaming kernel (516) {tk / 1e3:.2f} ms/step vs automatic selection (0) {t0 / 1e3:.2f} ms/step")
     tot_best = sum(min([v for v in r["us"].values() if v] or [0]) * r["count"] for r in res)
     tot_cur = sum((r["us"].get("1256") or r["us"].get("128") or r["us"].get("64") or 0) * r["count"] for r in res)
     for code in [str(t) for t in TILES if t >= 5120]:

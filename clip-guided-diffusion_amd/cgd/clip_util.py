@@ -119,17 +119,21 @@ def load_clip(model_name="ViT-B/32", device="cpu"):
     ctx = script_util.get_context(device)
     model_path = download_clip_model(model_name) if model_name in CLIP_MODEL_URLS else model_name
     if os.path.isfile(model_path):
-        try:
-            jit = th.jit.load(model_path, map_location="cpu")
-            sd = jit.state_dict()
-        except RuntimeError:
-            sd = th.load(model_path, map_location="cpu")
-        if "visual.proj" in sd:
-            tower = _nets.ClipImageTower(ctx, config=_vit_config_from_state_dict(sd))
-        else:
-            tower = _nets.ClipResNetTower(ctx, config=_rn_config_from_state_dict(sd))
-        _shard.load_broadcast(tower, lambda: {k: v.float() for k, v in sd.items() if k.startswith("visual.")}, f"cuda:{ctx.device}",
-                              prefix="visual.")
+        held = {}
+
+        def probe():  # rank 0 only (multi-GPU runs): un-pickle the archive once, infer the tower like clip.model.build_model
+            try:
+                sd = th.jit.load(model_path, map_location="cpu").state_dict()
+            except RuntimeError:
+                sd = th.load(model_path, map_location="cpu")
+            held["sd"] = sd
+            return ("vit", _vit_config_from_state_dict(sd)) if "visual.proj" in sd else ("rn", _rn_config_from_state_dict(sd))
+
+        kind, cfg = _shard.on_rank0(probe)  # the other ranks receive the configuration, never the file
+        tower = _nets.ClipImageTower(ctx, config=cfg) if kind == "vit" else _nets.ClipResNetTower(ctx, config=cfg)
+        _shard.load_broadcast(tower, lambda: {k: v.float() for k, v in held["sd"].items() if k.startswith("visual.")},
+                              f"cuda:{ctx.device}", prefix="visual.")
+        held.clear()
         text_model = None
         try:
             import clip  # optional, setup-time only

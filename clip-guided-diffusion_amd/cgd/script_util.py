@@ -93,7 +93,13 @@ def log_image(image: th.Tensor, base_path: str, txts: list, current_step: int, b
 
 
 def download(url: str, filename: str, root: str = CACHE_PATH, max_retries: int = 3) -> str:
-    """Cached download: returns the target immediately when it exists; otherwise streams to a .tmp and renames."""
+    """Cached download: returns the target immediately when it exists; otherwise streams to a per-process temporary file and moves it
+    into place atomically.  In a multi-GPU run (cgd_amd.launch: one process per GPU) only rank 0 downloads; the other ranks wait for it
+    and then find the finished file in the cache."""
+    return _shard.on_rank0(lambda: _download(url, filename, root, max_retries))
+
+
+def _download(url: str, filename: str, root: str, max_retries: int) -> str:
     os.makedirs(root, exist_ok=True)
     target = Path(root) / filename
     if target.exists() and not target.is_file():
@@ -101,7 +107,7 @@ def download(url: str, filename: str, root: str = CACHE_PATH, max_retries: int =
     if target.is_file():
         return str(target)
     import requests
-    tmp = target.with_suffix(".tmp")
+    tmp = target.with_name(f"{target.name}.tmp.{os.getpid()}")  # never shared between processes (two launches on one cache directory)
     last = None
     for attempt in range(max_retries):
         try:
@@ -116,7 +122,7 @@ def download(url: str, filename: str, root: str = CACHE_PATH, max_retries: int =
             got = tmp.stat().st_size
             if expected and got != expected:  # a connection that closed early without raising must not reach the cache
                 raise OSError(f"download incomplete: expected {expected} bytes, got {got}")
-            os.rename(tmp, target)
+            os.replace(tmp, target)  # atomic: a reader sees the old state or the complete file
             return str(target)
         except (requests.exceptions.RequestException, OSError) as e:
             last = e
@@ -130,9 +136,12 @@ def download(url: str, filename: str, root: str = CACHE_PATH, max_retries: int =
 def download_guided_diffusion(image_size: int, class_cond: bool, checkpoints_dir: str = CACHE_PATH, overwrite: bool = False) -> str:
     info = DIFFUSION_LOOKUP["cond" if class_cond else "uncond"][image_size]
     target = Path(checkpoints_dir) / info["filename"]
-    if synthetic_weights_enabled() or (not overwrite and target.exists()):
+    if synthetic_weights_enabled():
         return str(target)
-    return download(info["url"], info["filename"], checkpoints_dir)
+    # the cache check is part of what rank 0 decides for everybody: a rank that arrived late and found the freshly downloaded file must
+    # not skip the collective the others are waiting in
+    return _shard.on_rank0(lambda: str(target) if (not overwrite and target.exists()) else
+                           _download(info["url"], info["filename"], checkpoints_dir, 3))
 
 
 _CTX = {}

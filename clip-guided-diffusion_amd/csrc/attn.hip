@@ -634,6 +634,7 @@ int cgd_launch_softmax_bwd_rows(cgd_ctx* ctx, const float* P, float* dP, long ro
 
 int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, float* out, int ldo, const AttnBufs& bufs,
                  hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
   const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;  // bf16x3 products in the fused kernels (CGD_ATTN_X3=0: exact)
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
@@ -691,6 +692,7 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
 
 int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, const float* dout, int lddo, float* dqkv, int lddq,
                  const AttnBufs& bufs, hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   const int T = sh.T, Tp = attn_tp(T), d = sh.d, C = sh.C, H = sh.heads;
   const HeadOff ho = head_off(sh);
   const float alpha = 1.f / sqrtf((float)d);

@@ -44,6 +44,7 @@ struct PendingReduce {  // a deferred reduction (GemmParams::defer) that has not
   SplitSrc src;
   float* C = nullptr;
   int ldc = 0, M = 0;
+  hipStream_t stream = nullptr;  // the stream the slices were produced on: only a consumer on the same stream may take them
 };
 
 struct FragEntry {  // fragment-order copy of a persistent weight (hgemm.hip)
@@ -70,6 +71,9 @@ struct cgd_ctx {
                        // parity-tested (tile code 512), but no faster than igemm 64x64 + split-K on the step (22.07 vs 22.07-22.11 ms,
                        // same-box A/B round 2), so off by default
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int kconv_mode = 1, kconv_max_m = 1024, kconv_min_chunks = 4;  // weight-streaming variant of the halo conv (kconv.hip, tile code 516): for
+                                          // convs of at most kconv_max_m pixels; split-K slices of at least kconv_min_chunks chunks (A/B knob
+                                          // CGD_KCONV="<mode>[,<max pixels>[,<min chunks>]]")
   int wino_mode = 1, wino_min_m = 16384;  // Winograd F(2,3) variant of the halo conv (wconv.hip): 0 off, 1 for convs of >= wino_min_m
                                           // pixels whose transformed weights were packed (2 / 3: force 16- / 8-row tiles; A/B knob
                                           // CGD_WINO="<mode>[,<min pixels>]"; same-box A/B: 21.96 -> 20.37 ms/step, 4096: 20.35)
@@ -174,7 +178,7 @@ struct GemmParams {
   int no_split = 0;  // 1: never split K automatically (the caller keeps data of its own in the workspace)
   float* ws = nullptr;
   int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel;
-                       // 515 Winograd halo conv kernel (wconv.hip)
+                       // 515 Winograd halo conv kernel (wconv.hip); 516 weight-streaming halo conv kernel (kconv.hip)
   int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
   const void* Bwk = nullptr;  // conv only: Winograd F(2,3)-transformed weights in fragment order (cgd_pack_conv3x3_wino) for wconv.hip
@@ -192,7 +196,10 @@ struct GemmParams {
 
 // deferred split-K reductions: run the reduce kernel for a pending one (no-op otherwise) / hand it to a consumer of tensor `x`
 int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s);
-bool cgd_take_pending(cgd_ctx* ctx, const float* x, long rows, int cols, SplitSrc* out);
+// `ldx`: the consumer's row stride of x (must be the stride the reduction would have written with); `s`: the consumer's stream
+bool cgd_take_pending(cgd_ctx* ctx, const float* x, long rows, int cols, int ldx, hipStream_t s, SplitSrc* out);
+// every launcher that READS an activation without being a SplitSrc consumer calls this first (no-op unless something is pending)
+static inline int cgd_sync_pending(cgd_ctx* ctx, hipStream_t s) { return ctx->pending.valid ? cgd_flush_pending(ctx, s) : 0; }
 
 // ---- halo-staged conv (hconv.hip) ---------------------------------------------------------------------
 size_t cgd_hconv_packed_floats(int Co, int Ci);
@@ -209,6 +216,11 @@ bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_wconv_nb(const cgd_ctx* ctx, const GemmParams& p);
 long cgd_wconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
+
+// ---- weight-streaming halo conv for the small maps (kconv.hip): K split inside the workgroup, one 32-channel output block per workgroup
+bool cgd_kconv_supported(const cgd_ctx* ctx, const GemmParams& p);
+long cgd_kconv_tiles_m(const GemmParams& p);
+int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------
 bool cgd_hgemm_supported(const cgd_ctx* ctx, const GemmParams& p);

@@ -176,6 +176,7 @@ inline int grid_for(long n) { return (int)std::min<long>(cdiv(n, 256), 4096); }
 
 int cgd_launch_pool2x2(cgd_ctx* ctx, const float* in, int ldi, float* out, int ldo, const float* add, int ldadd, int B, int Ho,
                        int Wo, int C, float scale, hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (ldi & 3) || (ldo & 3)) CGD_FAIL(ctx, "pool2x2: C and strides must be multiples of 4");
   hipLaunchKernelGGL(pool2x2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, ldi, out, ldo, add, ldadd, B,
                      Ho, Wo, C, scale);
@@ -185,6 +186,7 @@ int cgd_launch_pool2x2(cgd_ctx* ctx, const float* in, int ldi, float* out, int l
 
 int cgd_launch_upsample2x(cgd_ctx* ctx, const float* in, int ldi, float* out, int ldo, const float* add, int ldadd, int B, int Ho,
                           int Wo, int C, float scale, hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (ldi & 3) || (ldo & 3)) CGD_FAIL(ctx, "upsample2x: C and strides must be multiples of 4");
   hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, ldi, out, ldo, add, ldadd,
                      B, Ho, Wo, C, scale);
@@ -194,6 +196,7 @@ int cgd_launch_upsample2x(cgd_ctx* ctx, const float* in, int ldi, float* out, in
 
 int cgd_launch_copy2d(cgd_ctx* ctx, const float* a, int lda, const float* b, int ldb, float* out, int ldo, long rows, int C,
                       hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (lda & 3) || (ldo & 3) || (b && (ldb & 3))) CGD_FAIL(ctx, "copy2d: C and strides must be multiples of 4");
   hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C);
   CGD_HIP(ctx, hipGetLastError());
@@ -202,6 +205,7 @@ int cgd_launch_copy2d(cgd_ctx* ctx, const float* a, int lda, const float* b, int
 
 int cgd_launch_concat2(cgd_ctx* ctx, const float* a, int lda, int Ca, const float* b, int ldb, int Cb, float* out, int ldo, long rows,
                        hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((Ca & 3) || (Cb & 3) || (lda & 3) || (ldb & 3) || (ldo & 3)) CGD_FAIL(ctx, "concat2: channels and strides must be multiples of 4");
   hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * ((Ca + Cb) / 4))), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, out, ldo, rows);
   CGD_HIP(ctx, hipGetLastError());
@@ -209,11 +213,13 @@ int cgd_launch_concat2(cgd_ctx* ctx, const float* a, int lda, int Ca, const floa
 }
 
 int cgd_launch_act_fwd(cgd_ctx* ctx, const float* x, float* y, long n, int act, hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, act);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 int cgd_launch_act_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx, long n, int act, hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, dy, dx, n, act);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -221,6 +227,7 @@ int cgd_launch_act_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx,
 
 int cgd_launch_transpose(cgd_ctx* ctx, const float* in, int ldi, long si, float* out, int ldo, long so, int R, int Cc, int nb,
                          hipStream_t s) {
+  CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(ldo, 32), nb), dim3(32, 8), 0, s, in, ldi, si, out, ldo, so, R, Cc);
   CGD_HIP(ctx, hipGetLastError());
   return 0;

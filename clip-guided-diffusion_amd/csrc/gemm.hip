@@ -437,6 +437,27 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
     use_h = tile == 512 || (!tile && ctx->hconv_mode && (p.M >= ctx->hconv_min_m || (p.W == 8 && ctx->hconv_w8)));
   }
   if (tile == 512 && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel does not support this problem");
+  // weight-streaming variant for the small maps (kconv.hip): tile code 516; also takes the 8-pixel-wide maps from igemm
+  const bool kc_forced = tile == 516;
+  if (kc_forced || (!tile && ctx->kconv_mode && p.M <= ctx->kconv_max_m && p.M % (p.H > 0 && p.W > 0 ? p.H * p.W : 1) == 0)) {
+    if (cgd_kconv_supported(ctx, p)) {
+      const long tiles = cgd_kconv_tiles_m(p) * (p.N >> 5);
+      const int nchunk = p.Cin / 32;
+      if (auto_split && tiles < ctx->num_cu) {
+        long want = std::min<long>(cdiv(ctx->num_cu, tiles), std::max(1, nchunk / ctx->kconv_min_chunks));
+        while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
+        if (want >= 2) p.splitk = (int)want;
+      }
+      *tile_out = 516;
+      *kernel_out = 1;
+      if (p.splitk > 1) {
+        if (p.nbatch != 1) CGD_FAIL(ctx, "cgd_launch_gemm: split-K with batches is not supported");
+        if ((size_t)p.splitk * p.M * p.N * sizeof(float) > ctx->ws_bytes) CGD_FAIL(ctx, "cgd_launch_gemm: split-K workspace too small");
+      }
+      return 0;
+    }
+    if (kc_forced) CGD_FAIL(ctx, "cgd_launch_gemm: weight-streaming conv kernel does not support this problem");
+  }
   if (use_h && !wino_forced) {
     tile = 512;
     if (p.M % (p.H * p.W)) CGD_FAIL(ctx, "cgd_launch_gemm: conv M must be a whole number of H x W images");
@@ -531,16 +552,17 @@ int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s) {
   const PendingReduce& q = ctx->pending;
   const long total = (long)q.M * q.src.N;
   const int blocks = (int)std::min<long>(cdiv(cdiv(total, 4), 256), 4096);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, q.src.ws, q.src.n, q.M, q.src.N, q.C, q.ldc, q.src.bias,
+  (void)s;  // the reduction is ordered behind its slices: it always runs on the stream that produced them
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, q.stream, q.src.ws, q.src.n, q.M, q.src.N, q.C, q.ldc, q.src.bias,
                      q.src.R, q.src.ldr, q.src.alpha);
   ctx->pending.valid = false;
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 
-bool cgd_take_pending(cgd_ctx* ctx, const float* x, long rows, int cols, SplitSrc* out) {
+bool cgd_take_pending(cgd_ctx* ctx, const float* x, long rows, int cols, int ldx, hipStream_t s, SplitSrc* out) {
   PendingReduce& q = ctx->pending;
-  if (!q.valid || q.C != x || q.M != rows || q.src.N != cols) return false;
+  if (!q.valid || q.C != x || q.M != rows || q.src.N != cols || q.ldc != ldx || q.stream != s) return false;
   *out = q.src;
   q.valid = false;
   return true;
@@ -561,6 +583,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (use_h) {
     if (tile == 515)
       CGD_TRY(cgd_launch_wconv(ctx, p, s));
+    else if (tile == 516)
+      CGD_TRY(cgd_launch_kconv(ctx, p, s));
     else
       CGD_TRY(cgd_launch_hconv(ctx, p, s));
     CGD_TRY(cgd_prof_stamp(ctx, &pr, s));  // the halo conv kernel alone, without its split-K reduce
@@ -578,7 +602,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     q.valid = true;
     q.src.ws = p.ws; q.src.bias = p.bias; q.src.R = p.R; q.src.stride = (long)p.M * p.N; q.src.n = p.splitk; q.src.N = p.N;
     q.src.ldr = p.ldr; q.src.alpha = p.alpha;
-    q.C = p.C; q.ldc = p.ldc; q.M = p.M;
+    q.C = p.C; q.ldc = p.ldc; q.M = p.M; q.stream = s;
     if (!(p.defer && ctx->defer_mode)) CGD_TRY(cgd_flush_pending(ctx, s));
   }
   if (!use_h) CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
@@ -608,7 +632,7 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   if (rc != 0) return rc;
   long wg;
   if (kernel == 1) {
-    wg = (tile == 515 ? cgd_wconv_tiles_m(&ctx, p) : cgd_hconv_tiles_m(&ctx, p)) * cdiv(p.N, 128);
+    wg = tile == 516 ? cgd_kconv_tiles_m(p) * (p.N >> 5) : (tile == 515 ? cgd_wconv_tiles_m(&ctx, p) : cgd_hconv_tiles_m(&ctx, p)) * cdiv(p.N, 128);
   } else if (kernel == 2) {
     wg = cgd_hgemm_tiles(&ctx, p);
   } else {

@@ -1,0 +1,324 @@
+// Weight-streaming 3x3 convolution for the SMALL maps of the UNet (8x8 ... 32x32 pixels at batch 1-2) on gfx950, bf16x3 / bf16 MFMA.
+//
+// Why another kernel: on those levels the layer is a 1024-channel conv over 64-1024 pixels: 2-40 GFLOP against
+// 9-75 MB of packed weights, i.e. bound by how fast the chip can STREAM THE WEIGHTS (~10 B/clk per CU), not by the MFMA pipe.
+// hconv2_kernel (hconv.hip) gives a workgroup 128 output channels (4 wavefronts x 32) and therefore needs 16-32 split-K slices to put
+// one workgroup on every CU: each slice then runs 1-2 chunks (prologue and epilogue dominate), the fp32 partial slabs are 16-32 x the
+// output and the policy of >= 4 chunks per slice leaves half of the CUs idle (128 workgroups at 16x16: each CU streams twice its
+// share).  Here the K dimension is split INSIDE the workgroup instead:
+//   * a workgroup owns one 8x16-pixel tile x ONE 32-channel block of outputs x a run of 32-channel input chunks (split-K across
+//     workgroups only for what is left: 2-8 slices);
+//   * its 4 wavefronts share the halo patch of a chunk in LDS (same layout, staging and double buffering as hconv2) and split the
+//     chunk's 18 k-steps (9 taps x 2) among themselves: wavefront w takes k-steps w, w + 4, w + 8, ...; each streams ONLY its own
+//     weight fragments (1 KiB coalesced loads straight into registers, a ring that runs one whole chunk ahead: 10 loads = 160 B per
+//     lane in flight), and accumulates all 128 pixels x 32 channels in 64 accumulator registers;
+//   * at the end the four partial accumulators are summed through LDS (wavefront w finishes pixel block w) and written like hconv2's
+//     epilogue: bias / residual, or the fp32 slab of a split-K slice (same workspace protocol, same reduce kernel / consumers).
+// Per chunk a wavefront issues 4.5 x 12 MFMAs (1728 cycles) for 9 KB of weights: 21 B/clk per CU of weight fragments, half of which
+// is L2 traffic when two pixel tiles share a weight block: the MFMA pipe keeps up with the HBM stream at 256 pixels and idles below.
+// Supports what hconv2 supports at TH = 8: W multiple of 16 or W = 8 (half-filled tile), nearest-2x upsampled input view, fused
+// GroupNorm+SiLU on the staged input (gn pairs), split-K.  Packed weights: the layout of cgd_pack_conv3x3_frag (hconv.hip).
+#include "common.h"
+
+typedef __bf16 kbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kbf16x4 __attribute__((ext_vector_type(4)));
+typedef float kf32x16 __attribute__((ext_vector_type(16)));
+typedef float kf32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KTH = 8;                 // tile rows; the tile is 16 pixels wide
+constexpr int KPW = 18, KHPH = 40, KHRS = 768;  // patch width, pixel pitch, patch-row pitch (bf16 elements): hconv2's layout
+constexpr int KNP = (KTH + 2) * KPW;   // 180 patch rows
+constexpr int KPLANE = (KTH + 2) * KHRS;
+constexpr int KNPASS = 6;              // staging passes: 32 patch rows per pass
+constexpr int KNQ = 5;                 // k-step slots per wavefront and chunk (wavefronts 2 and 3 use 4)
+
+struct KConvParams {
+  int lda, ldc, ldr;
+  int M, N, H, W, Cin, ups, splitk;
+  float alpha;
+};
+
+__device__ __forceinline__ kbf16x4 k_bf16x4(const kf32x4 v) {
+  kbf16x4 r;
+  r[0] = (__bf16)v.x;
+  r[1] = (__bf16)v.y;
+  r[2] = (__bf16)v.z;
+  r[3] = (__bf16)v.w;
+  return r;
+}
+__device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) {
+  return kf32x4{v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]};
+}
+
+template <int MODE, bool GN>
+__global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+                                                    const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
+                                                    const float* __restrict__ gng, const KConvParams p) {
+  constexpr int NPL = MODE == 1 ? 2 : 1;
+  // one array for everything: the patch double buffer, reused for the final cross-wavefront reduction (4 x 3 slabs of 4 KiB = 48 KiB)
+  constexpr int LDS_ELEMS = 2 * NPL * KPLANE > 24576 ? 2 * NPL * KPLANE : 24576;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: k-step offsets and the 5-vs-4 branch are wave-uniform
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  const int nbN = p.N >> 5;
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // weight-block major within an XCD's run: the pixel tiles that share a 32-channel weight block are neighbours on one XCD
+  const int ntm = gridDim.x / nbN;
+  const int mt = bid % ntm, nb = bid / ntm;
+  const int tpr = (p.W + 15) >> 4, tpi = (p.H / KTH) * tpr;
+  const int img = mt / tpi, trem = mt - img * tpi;
+  const int y0 = (trem / tpr) * KTH, x0 = (trem % tpr) << 4;
+  const int HW = p.H * p.W;
+  const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
+  const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
+
+  const int c4 = tid & 7;
+  int poff[KNPASS], soff[KNPASS];
+#pragma unroll
+  for (int j = 0; j < KNPASS; ++j) {
+    const int prow = (tid >> 3) + 32 * j;
+    poff[j] = -2;
+    soff[j] = KPW * KHPH + c4 * 4;  // unused tail of LDS patch row 0 (see hconv2: keeps the store unconditional)
+    if (prow < KNP) {
+      const int py = prow / KPW, px = prow - py * KPW;
+      soff[j] = py * KHRS + px * KHPH + c4 * 4;
+      int yy = y0 + py - 1, xx = x0 + px - 1;
+      const bool inb = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      if (p.ups) {
+        yy >>= 1;
+        xx >>= 1;
+      }
+      poff[j] = inb ? (yy * Ws + xx) * p.lda + c4 * 4 : -1;
+    }
+  }
+  // this lane's pixel in each of the 4 pixel blocks (all wavefronts cover the same 128 pixels)
+  int fro[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = i * 32 + l31;
+    fro[i] = (pix >> 4) * KHRS + (pix & 15) * KHPH + hh * 8;
+  }
+  // this wavefront's k-steps q = wave + 4 k: LDS offset of (tap, ks) and offset of its fragment pair inside a chunk's weight block
+  int aoff[KNQ], boff[KNQ];
+#pragma unroll
+  for (int k = 0; k < KNQ; ++k) {
+    const int q = wave + 4 * k, qc = q < 18 ? q : 17, tap = qc >> 1, ks = qc & 1;
+    aoff[k] = (tap / 3) * KHRS + (tap % 3) * KHPH + ks * 16;
+    boff[k] = (tap * 4 + ks * 2) * 64;
+  }
+  const bool five = wave < 2;  // wavefronts 0 and 1 own five k-steps of the 18, wavefronts 2 and 3 four
+
+  const int nchunk = p.Cin >> 5;
+  int c0 = 0, c1 = nchunk;
+  if (p.splitk > 1) {
+    const int per = (nchunk + p.splitk - 1) / p.splitk;
+    c0 = blockIdx.z * per;
+    c1 = min(nchunk, c0 + per);
+  }
+  const uint4* __restrict__ Bw0 = Bg + (long)nb * nchunk * (9 * 4 * 64) + lane;
+
+  kf32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  if (c0 < c1) {
+    // staging registers: two sets.  The patch of chunk j + 2 is fetched during chunk j (a whole chunk ~ 1.9k MFMA cycles ahead of its
+    // conversion: the activations come from L2 / MALL behind the weight stream), converted and written during chunk j + 1 into the
+    // LDS buffer chunk j has just released.
+    kf32x4 pr[2][KNPASS];
+    kf32x4 ga[2][GN ? 2 : 1];
+    const kf32x4 z4 = kf32x4{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ gnimg = GN ? gng + ((long)img * p.Cin + c4 * 4) * 2 : nullptr;
+#define K_PATCH_LOAD(S, CH)                                                                         \
+  {                                                                                                 \
+    const int ch_ = (CH) < c1 ? (CH) : c1 - 1; /* clamped: loads stay unconditional */              \
+    const float* __restrict__ Ac = Aimg + ch_ * 32;                                                 \
+    if constexpr (GN) {                                                                             \
+      ga[S][0] = *(const kf32x4*)(gnimg + ch_ * 64);                                                \
+      ga[S][1] = *(const kf32x4*)(gnimg + ch_ * 64 + 4);                                            \
+    }                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < KNPASS; ++j)                                              \
+        pr[S][j] = *(const kf32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4));                         \
+  }
+#define K_SILU(X, A, B) ({ const float u_ = (X) * (A) + (B); u_ * __builtin_amdgcn_rcpf(1.f + __expf(-u_)); })
+#define K_PATCH_STORE(S, DSTB, J0, J1)                                                              \
+  {                                                                                                 \
+    _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                               \
+      kf32x4 v = pr[S][j];                                                                          \
+      if constexpr (GN)                                                                             \
+        v = kf32x4{K_SILU(v.x, ga[S][0].x, ga[S][0].y), K_SILU(v.y, ga[S][0].z, ga[S][0].w), K_SILU(v.z, ga[S][1].x, ga[S][1].y), \
+                   K_SILU(v.w, ga[S][1].z, ga[S][1].w)};                                            \
+      v = poff[j] >= 0 ? v : z4;                                                                    \
+      const kbf16x4 hi = k_bf16x4(v);                                                               \
+      *(kbf16x4*)&(DSTB)[soff[j]] = hi;                                                             \
+      if constexpr (MODE == 1) *(kbf16x4*)&(DSTB)[KPLANE + soff[j]] = k_bf16x4(k_residual4(v, hi)); \
+    }                                                                                               \
+  }
+#define K_A_LOAD(DST, SRCB, K)                                                                      \
+  {                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+      DST[i][0] = *(const kbf16x8*)&(SRCB)[fro[i] + aoff[K]];                                       \
+      if constexpr (MODE == 1) DST[i][1] = *(const kbf16x8*)&(SRCB)[KPLANE + fro[i] + aoff[K]];    \
+    }                                                                                               \
+  }
+#define K_B_LOAD(DST, BASE, K)                                                                      \
+  {                                                                                                 \
+    const uint4* bp_ = (BASE) + boff[K];                                                            \
+    DST[0] = bp_[0];                                                                                \
+    if constexpr (MODE == 1) DST[1] = bp_[64];                                                      \
+  }
+#define K_MFMA(AQ, BQ)                                                                              \
+  {                                                                                                 \
+    if constexpr (MODE == 1) {                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kbf16x8, BQ[0]), AQ[i][1], acc[i], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kbf16x8, BQ[1]), AQ[i][0], acc[i], 0, 0, 0); \
+    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kbf16x8, BQ[0]), AQ[i][0], acc[i], 0, 0, 0); \
+  }
+    // weight-fragment ring: two sets of KNQ slots; set S holds the chunk being multiplied, the other is filled with the next chunk's
+    // fragments meanwhile (one whole chunk of lead: HBM latency under load)
+    kbf16x8 af[2][4][NPL];
+    uint4 bq[2][KNQ][NPL];
+    __bf16* const buf0 = lds;
+    __bf16* const buf1 = lds + NPL * KPLANE;
+    K_PATCH_LOAD(0, c0);
+    K_PATCH_LOAD(1, c0 + 1);
+    {
+      const uint4* __restrict__ cb = Bw0 + (long)c0 * (9 * 4 * 64);
+#pragma unroll
+      for (int k = 0; k < KNQ; ++k) K_B_LOAD(bq[0][k], cb, k);
+    }
+    K_PATCH_STORE(0, buf0, 0, KNPASS);
+    K_PATCH_STORE(1, buf1, 0, KNPASS);
+    __syncthreads();
+    // chunk C (ring set S, LDS buffer CUR): fetch patch C + 2 into staging set S, write patch C + 1 (staging set S ^ 1, fetched during
+    // chunk C - 1; for the first chunk a harmless rewrite of what the prologue stored) into NXT, fetch the fragments of chunk C + 1
+#define K_CHUNK(S, CUR, NXT, C)                                                                     \
+  {                                                                                                 \
+    const uint4* __restrict__ nbp = Bw0 + (long)((C) + 1 < c1 ? (C) + 1 : (C)) * (9 * 4 * 64);      \
+    K_PATCH_LOAD(S, (C) + 2);                                                                       \
+    K_A_LOAD(af[0], CUR, 0);                                                                        \
+    _Pragma("unroll") for (int k = 0; k < KNQ; ++k) {                                               \
+      if (k + 1 < KNQ) K_A_LOAD(af[(k + 1) & 1], CUR, k + 1);                                       \
+      K_B_LOAD(bq[(S) ^ 1][k], nbp, k);                                                             \
+      if (k < 4 || five) K_MFMA(af[k & 1], bq[S][k]);                                               \
+      if (k < 3) K_PATCH_STORE((S) ^ 1, NXT, 2 * k, 2 * k + 2);                                     \
+      _Pragma("unroll") for (int r = 0; r < 12; ++r) {                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+        if (r % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+        if (r % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                          \
+        if (r % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                          \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }                                                                                               \
+    __syncthreads();                                                                                \
+  }
+    int c = c0;
+    for (; c + 1 < c1; c += 2) {
+      K_CHUNK(0, buf0, buf1, c);
+      K_CHUNK(1, buf1, buf0, c + 1);
+    }
+    if (c < c1) K_CHUNK(0, buf0, buf1, c);
+#undef K_PATCH_LOAD
+#undef K_SILU
+#undef K_PATCH_STORE
+#undef K_A_LOAD
+#undef K_B_LOAD
+#undef K_MFMA
+#undef K_CHUNK
+  }
+
+  // ---- cross-wavefront reduction through LDS: wavefront w finishes pixel block w.  Slab (block i, source slot s) = 16 x 64 floats,
+  //      element (r, lane) at r * 64 + lane: conflict-free 4-byte accesses.  The last __syncthreads of the loop (or none, for an empty
+  //      slice) has retired every read of the patch buffers.
+  float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i != wave) {
+      const int slot = wave - (wave > i ? 1 : 0);
+      float* dst = red + ((i * 3 + slot) * 16) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r * 64] = acc[i][r];
+    }
+  }
+  __syncthreads();
+  kf32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i == wave) o = acc[i];  // wave-uniform select of this wavefront's own block
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const float* src = red + ((wave * 3 + s) * 16) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] += src[r * 64];
+  }
+
+  // ---- epilogue for pixel block `wave` (D = W x X^T: column = pixel l31, accumulator quad g = channels 8g + 4hh .. + 3)
+  const int pix = wave * 32 + l31, ty = pix >> 4, tx = pix & 15;
+  if (x0 + tx >= p.W) return;
+  const long mrow = (long)img * HW + (long)(y0 + ty) * p.W + x0 + tx;
+  const int cb0 = nb * 32;
+  if (p.splitk > 1) {
+    float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(kf32x4*)&ws[mrow * p.N + cb0 + 8 * g + 4 * hh] = kf32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    return;
+  }
+  kf32x4 rv[4];
+  if (Rg) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rv[g] = *(const kf32x4*)&Rg[mrow * p.ldr + cb0 + 8 * g + 4 * hh];
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int col = cb0 + 8 * g + 4 * hh;
+    kf32x4 v = kf32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]} * p.alpha;
+    if (biasg) v += kf32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
+    if (Rg) v += rv[g];
+    *(kf32x4*)&Cg[mrow * p.ldc + col] = v;
+  }
+}
+
+}  // namespace
+
+// same problems as hconv2 at TH = 8 (cgd_hconv_supported); the caller (cgd_plan_gemm) restricts it to small maps
+bool cgd_kconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
+  if (!cgd_hconv_supported(ctx, p)) return false;
+  if ((long)cdiv(p.W, 16) * (p.H / KTH) * (p.M / (p.H * p.W)) * (p.N >> 5) > 65535L * 8) return false;
+  return true;
+}
+
+long cgd_kconv_tiles_m(const GemmParams& p) { return (long)(p.M / (p.H * p.W)) * (p.H / KTH) * cdiv(p.W, 16); }
+
+int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
+  KConvParams p;
+  p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
+  p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
+  dim3 grid((int)(cgd_kconv_tiles_m(g) * (g.N >> 5)), 1, g.splitk > 1 ? g.splitk : 1);
+#define KC_LAUNCH(M_, GN_) \
+  hipLaunchKernelGGL((kconv_kernel<M_, GN_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
+  if (ctx->precision == CGD_PREC_BF16X3) {
+    if (g.gn_ab) KC_LAUNCH(1, true); else KC_LAUNCH(1, false);
+  } else {
+    if (g.gn_ab) KC_LAUNCH(2, true); else KC_LAUNCH(2, false);
+  }
+#undef KC_LAUNCH
+  return 0;
+}

@@ -1045,10 +1045,10 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
   // x may still lie in split-K slices (a deferred reduction of the conv that produced it): this op's first sweep sums them
   SplitSrc src;
-  if (!((HW > GN_SMALL_HW || ctx->defer_mode >= 2) && cgd_take_pending(ctx, x, (long)B * HW, C, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
+  if (!((HW > GN_SMALL_HW || ctx->defer_mode >= 2) && cgd_take_pending(ctx, x, (long)B * HW, C, ldx, s, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
   if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.ws & 15) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15)) && HW > GN_SMALL_HW) {
     // the large path reads float4 only: finish the reduction the plain way
-    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)x; ctx->pending.ldc = ldx; ctx->pending.M = B * HW;
+    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)x; ctx->pending.ldc = ldx; ctx->pending.M = B * HW; ctx->pending.stream = s;
     CGD_TRY(cgd_flush_pending(ctx, s));
     src = SplitSrc();
   }
@@ -1085,9 +1085,9 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
   SplitSrc src;  // dz may still lie in split-K slices (the dgrad conv that produced it deferred its reduction)
-  if (!((HW > GN_SMALL_HW || ctx->defer_mode >= 2) && cgd_take_pending(ctx, dz, (long)B * HW, C, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
+  if (!((HW > GN_SMALL_HW || ctx->defer_mode >= 2) && cgd_take_pending(ctx, dz, (long)B * HW, C, lddz, s, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
   if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.ws & 15) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15)) && HW > GN_SMALL_HW) {
-    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)dz; ctx->pending.ldc = lddz; ctx->pending.M = B * HW;
+    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)dz; ctx->pending.ldc = lddz; ctx->pending.M = B * HW; ctx->pending.stream = s;
     CGD_TRY(cgd_flush_pending(ctx, s));
     src = SplitSrc();
   }
@@ -1129,9 +1129,9 @@ int cgd_launch_ln_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   // x may still lie in split-K slices (vit.hip defers the reduction of the residual-stream GEMMs): the vector kernels sum them
   SplitSrc src;
   const bool slices_ok = vec && ctx->defer_mode >= 1;
-  if (!(slices_ok && cgd_take_pending(ctx, x, rows, C, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
+  if (!(slices_ok && cgd_take_pending(ctx, x, rows, C, ldx, s, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
   if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15))) {
-    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)x; ctx->pending.ldc = ldx; ctx->pending.M = rows;
+    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)x; ctx->pending.ldc = ldx; ctx->pending.M = rows; ctx->pending.stream = s;
     CGD_TRY(cgd_flush_pending(ctx, s));
     src = SplitSrc();
   }
@@ -1156,9 +1156,9 @@ int cgd_launch_ln_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dy, in
   const dim3 grid(cdiv(rows, 4)), blk(256);
   SplitSrc src;  // dy may still lie in split-K slices
   const bool slices_ok = vec && ctx->defer_mode >= 1;
-  if (!(slices_ok && cgd_take_pending(ctx, dy, rows, C, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
+  if (!(slices_ok && cgd_take_pending(ctx, dy, rows, C, lddy, s, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
   if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15))) {
-    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)dy; ctx->pending.ldc = lddy; ctx->pending.M = rows;
+    ctx->pending.valid = true; ctx->pending.src = src; ctx->pending.C = (float*)dy; ctx->pending.ldc = lddy; ctx->pending.M = rows; ctx->pending.stream = s;
     CGD_TRY(cgd_flush_pending(ctx, s));
     src = SplitSrc();
   }

@@ -65,7 +65,8 @@ struct ResBlock : Module {
   float *g1 = 0, *b1 = 0, *cw1f = 0, *cw1d = 0, *cb1 = 0, *g2 = 0, *b2 = 0, *cw2f = 0, *cw2d = 0, *cb2 = 0, *skw = 0, *skwT = 0,
         *skb = 0;
   float *cw1fp = 0, *cw1dp = 0, *cw2fp = 0, *cw2dp = 0;  // MFMA-fragment-order bf16 hi/lo copies for the halo conv kernel
-  float *cw1wp = 0, *cw1wd = 0, *cw2wp = 0, *cw2wd = 0;  // Winograd F(2,3)-transformed copies (wconv.hip), only with ctx->wino_mode
+  float *cw1wp = 0, *cw1wd = 0, *cw2wp = 0, *cw2wd = 0;  // Winograd F(2,3)-transformed copies (wconv.hip): packed lazily, the first time
+  bool wino_ready = false;                                //   the block runs at >= ctx->wino_min_m pixels (UNet::ensure_wino)
   // runtime
   int B = 0, H = 0, W = 0, Ho = 0, Wo = 0;
   TV x;
@@ -88,6 +89,7 @@ struct AttnBlock : Module {
 };
 
 struct UNet : NetBase {
+  int ensure_wino(ResBlock* rb, long pixels, hipStream_t s);
   cgd_unet_config cfg;
   int ted = 0, ch0 = 0, ch_last = 0;
   long emb_total = 0;
@@ -118,6 +120,27 @@ struct UNet : NetBase {
   int dgrad(const float* gout, float* gx, hipStream_t s);
 };
 
+// Winograd-transformed weight copies of a ResBlock (4/3 of the plain fragment copies: 4.6 GB for all blocks of the 256x256 model) are
+// only useful on maps of >= wino_min_m pixels: packed on the first call that qualifies (the first step of a run), never for the
+// 8x8 .. 64x64 levels of the supported resolutions.  Both passes use the same copies; the backward pass runs after a
+// forward pass of the same shape, so the forward hook is enough.
+int UNet::ensure_wino(ResBlock* rb, long pixels, hipStream_t s) {
+  if (!ctx->wino_mode || pixels < ctx->wino_min_m || rb->wino_ready) return 0;
+  const std::string& p = rb->pre;
+  if (!rb->cw1wp) {
+    CGD_TRY(alloc(&rb->cw1wp, cgd_wconv_packed_floats(rb->cout, rb->cin)));
+    CGD_TRY(alloc(&rb->cw1wd, cgd_wconv_packed_floats(rb->cout, rb->cin)));
+    CGD_TRY(alloc(&rb->cw2wp, cgd_wconv_packed_floats(rb->cout, rb->cout)));
+    CGD_TRY(alloc(&rb->cw2wd, cgd_wconv_packed_floats(rb->cout, rb->cout)));
+  }
+  CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".in_layers.2.weight"), rb->cw1wp, rb->cout, rb->cin, 0, s));
+  CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".in_layers.2.weight"), rb->cw1wd, rb->cout, rb->cin, 1, s));
+  CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wp, rb->cout, rb->cout, 0, s));
+  CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wd, rb->cout, rb->cout, 1, s));
+  rb->wino_ready = true;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t s) {
   cgd_ctx* ctx = u.ctx;
@@ -132,9 +155,10 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   if (!dst.p) CGD_TRY(u.ensure(out, npo * cout));
   float* const outp = dst.p ? dst.p : out.p;
   const int ldo = dst.p ? dst.ld : cout;
+  CGD_TRY(u.ensure_wino(this, npo, s));
   // conv1 (the nearest-2x upsample of an `up` block is folded into the conv's gather)
   GemmParams c1;
-  c1.B = cw1f; c1.Bpk = cw1fp; c1.Bwk = cw1wp; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
+  c1.B = cw1f; c1.Bpk = cw1fp; c1.Bwk = wino_ready ? cw1wp : nullptr; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
   c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
   c1.defer = 1;  // a split-K launch leaves its slices for the GroupNorm right below (SplitSrc)
   // in_layers: GN -> SiLU.  When conv1 runs on the halo kernel (and nothing else reads the normalised tensor: `down` blocks
@@ -169,7 +193,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
   // out_layers: GN * (1+scale) + shift -> SiLU -> conv2 (+ skip); same on-the-fly application when conv2 runs on the halo kernel
   GemmParams c2;
-  c2.A = h2.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.Bwk = cw2wp; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2;
+  c2.A = h2.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.Bwk = wino_ready ? cw2wp : nullptr; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   c2.defer = 1;  // the next module starts with a GroupNorm of this tensor (or the launcher flushes: concat inputs, the head)
   const bool fuse2 = cgd_conv_uses_hconv(ctx, c2);
@@ -210,7 +234,7 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   CGD_TRY(u.ensure(dx, npi * cin));
   // conv2 dgrad (a split-K launch leaves its slices for the GroupNorm backward right below)
   GemmParams c2;
-  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.Bwk = cw2wd; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
+  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.Bwk = wino_ready ? cw2wd : nullptr; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   c2.defer = 1;
   CGD_TRY(cgd_launch_gemm(ctx, c2, s));
@@ -239,7 +263,7 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   }
   // conv1 dgrad (at the conv's own resolution)
   GemmParams c1;
-  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.Bwk = cw1wd; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
+  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.Bwk = wino_ready ? cw1wd : nullptr; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
   c1.M = (int)npo; c1.N = cin; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cout;
   c1.defer = (up || down) ? 0 : 1;  // plain blocks: GN1's backward below consumes the slices; resampling blocks read d1 first
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
@@ -466,18 +490,7 @@ int UNet::finalize(hipStream_t s) {
     CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".in_layers.2.weight"), rb->cw1dp, rb->cout, rb->cin, 1, s));
     CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".out_layers.3.weight"), rb->cw2fp, rb->cout, rb->cout, 0, s));
     CGD_TRY(cgd_pack_conv3x3_frag(ctx, P(p + ".out_layers.3.weight"), rb->cw2dp, rb->cout, rb->cout, 1, s));
-    if (ctx->wino_mode) {  // transformed copies for the large-map Winograd kernel (A/B knob CGD_WINO, off by default)
-      if (!rb->cw1wp) {
-        CGD_TRY(alloc(&rb->cw1wp, cgd_wconv_packed_floats(rb->cout, rb->cin)));
-        CGD_TRY(alloc(&rb->cw1wd, cgd_wconv_packed_floats(rb->cout, rb->cin)));
-        CGD_TRY(alloc(&rb->cw2wp, cgd_wconv_packed_floats(rb->cout, rb->cout)));
-        CGD_TRY(alloc(&rb->cw2wd, cgd_wconv_packed_floats(rb->cout, rb->cout)));
-      }
-      CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".in_layers.2.weight"), rb->cw1wp, rb->cout, rb->cin, 0, s));
-      CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".in_layers.2.weight"), rb->cw1wd, rb->cout, rb->cin, 1, s));
-      CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wp, rb->cout, rb->cout, 0, s));
-      CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wd, rb->cout, rb->cout, 1, s));
-    }
+    rb->wino_ready = false;  // new weights: the Winograd copies (if this block ever needed them) are repacked on the next large-map call
     CGD_TRY(cgd_pack_conv3x3(ctx, P(p + ".in_layers.2.weight"), rb->cw1f, rb->cw1d, rb->cout, rb->cin, s));
     CGD_TRY(cgd_pack_conv3x3(ctx, P(p + ".out_layers.3.weight"), rb->cw2f, rb->cw2d, rb->cout, rb->cout, s));
     if (rb->skip_conv) {
@@ -707,13 +720,19 @@ int cgd_unet_finalize(cgd_unet* u) {
 int cgd_unet_forward(cgd_unet* u, const float* x, const float* t, const int64_t* y, float* out, int B, int H, int W, void* stream) {
   if (!u) return -3;
   DeviceScope dev_scope(u->net.ctx);
-  CGD_TRY(u->net.forward(x, t, y, out, B, H, W, (hipStream_t)stream));
+  if (const int rc = u->net.forward(x, t, y, out, B, H, W, (hipStream_t)stream)) {
+    u->net.ctx->pending.valid = false;  // failed pass: its deferred slices must not be reduced into a stale tensor later
+    return rc;
+  }
   return cgd_flush_pending(u->net.ctx, (hipStream_t)stream);  // nothing deferred may outlive the call
 }
 int cgd_unet_dgrad(cgd_unet* u, const float* g_out, float* g_x, void* stream) {
   if (!u) return -3;
   DeviceScope dev_scope(u->net.ctx);
-  CGD_TRY(u->net.dgrad(g_out, g_x, (hipStream_t)stream));
+  if (const int rc = u->net.dgrad(g_out, g_x, (hipStream_t)stream)) {
+    u->net.ctx->pending.valid = false;  // failed pass: its deferred slices must not be reduced into a stale tensor later
+    return rc;
+  }
   return cgd_flush_pending(u->net.ctx, (hipStream_t)stream);
 }
 }

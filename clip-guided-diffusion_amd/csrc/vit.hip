@@ -289,13 +289,19 @@ int cgd_vit_finalize(cgd_vit* v) {
 int cgd_vit_forward(cgd_vit* v, const float* img, int layout, int N, float* emb, void* stream) {
   if (!v) return -3;
   DeviceScope dev_scope(v->net.ctx);
-  CGD_TRY(v->net.forward(img, layout, N, emb, (hipStream_t)stream));
+  if (const int rc = v->net.forward(img, layout, N, emb, (hipStream_t)stream)) {
+    v->net.ctx->pending.valid = false;  // failed pass: its deferred slices must not be reduced into a stale tensor later
+    return rc;
+  }
   return cgd_flush_pending(v->net.ctx, (hipStream_t)stream);
 }
 int cgd_vit_dgrad(cgd_vit* v, const float* d_emb, float* d_img, void* stream) {
   if (!v) return -3;
   DeviceScope dev_scope(v->net.ctx);
-  CGD_TRY(v->net.dgrad(d_emb, d_img, (hipStream_t)stream));
+  if (const int rc = v->net.dgrad(d_emb, d_img, (hipStream_t)stream)) {
+    v->net.ctx->pending.valid = false;  // failed pass: its deferred slices must not be reduced into a stale tensor later
+    return rc;
+  }
   return cgd_flush_pending(v->net.ctx, (hipStream_t)stream);
 }
 }

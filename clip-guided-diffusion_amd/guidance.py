@@ -44,14 +44,15 @@ def _sample_grid(x, xi, yi, mode):
 
 def aug_affine(x, angle_deg, tx, ty):
     """torchvision.transforms.functional.affine(x, angle, (tx, ty), scale=1, shear=0), NEAREST, fill 0: rotation about the image
-    centre (positive = counter-clockwise), then translation; expressed as the inverse map output pixel -> input pixel."""
+    centre (positive angle = clockwise, like torchvision), then translation; expressed as the inverse map output pixel -> input
+    pixel, i.e. torchvision's _get_inverse_affine_matrix with shear 0: [[cos a, sin a], [-sin a, cos a]] applied to (xo - tx, yo - ty)."""
     _, _, H, W = x.shape
     ys, xs = th.meshgrid(th.arange(H, device=x.device, dtype=th.float32) + 0.5 - H / 2,
                          th.arange(W, device=x.device, dtype=th.float32) + 0.5 - W / 2, indexing="ij")
     a = math.radians(angle_deg)
     xo, yo = xs - tx, ys - ty
-    xi = math.cos(a) * xo - math.sin(a) * yo
-    yi = math.sin(a) * xo + math.cos(a) * yo
+    xi = math.cos(a) * xo + math.sin(a) * yo
+    yi = -math.sin(a) * xo + math.cos(a) * yo
     return _sample_grid(x, xi, yi, "nearest")
 
 
@@ -367,11 +368,14 @@ class ClipGuidance:
             if k == 0:
                 self.emb = emb
         nblk = lib.cgd_guidance_part_blocks(B, H, W)
+        # the saturation term is a mean over the WHOLE batch (cgd.py:214-218): a rank that holds B of the run's shard[1] samples scales
+        # it so that its per-sample gradient equals the batched run's (the logged value is then this rank's share of the loss)
+        sats = self.sats if self.shard is None else self.sats * (B / float(self.shard[1]))
         gdir = self._b("gdir", (B, 3, H, W), dev)
         seed6 = self._b("seed6", (B, 6, H, W), dev)
         lpart = self._b("lpart", (nblk, 3), dev)
         ctx.check(lib.cgd_guidance_combine(ctx.h, gclip.data_ptr(), x_in.data_ptr(), x0.data_ptr(), gdir.data_ptr(), seed6.data_ptr(),
-                                           lpart.data_ptr(), B, H, W, coef, self.tvs, self.rs, self.sats, s))
+                                           lpart.data_ptr(), B, H, W, coef, self.tvs, self.rs, sats, s))
         gunet = self.unet.dgrad(seed6, self._b("gunet", (B, 3, H, W), dev))
         g = self._b("g", (B, 3, H, W), dev)
         gpart = self._b("gpart", (nblk, 2), dev)

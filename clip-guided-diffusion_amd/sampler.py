@@ -26,8 +26,10 @@ class GuidedSampler:
         self.timestep_map = tables.timestep_map
         self.tape = None  # optional {'x_T','noise':[...],'y':[...]} replay (tests)
         # multi-GPU sharding: (indices of the global batch this rank owns, global batch size).  Every rank draws
-        # the GLOBAL (B,3,H,W) tensors from the same seed, exactly like the batched reference run, and keeps its slice: the
-        # samples are bit-for-bit those of the batched run, and there is no per-step collective.
+        # the GLOBAL (B,3,H,W) tensors from the same seed, exactly like the batched reference run, and keeps its slice, and there is
+        # no per-step collective.  The samples equal those of the batched run (up to the tile / split-K choices of a different batch
+        # size) EXCEPT with `use_magnitude`: its RMS clamp (cgd.py:229-232) is taken over the rank's own samples, not over the
+        # global batch — a documented deviation for batch > 1; `sat_scale` is normalised by the global batch.
         self.shard = None
 
     def step_coef(self, i, fac_index=None):

@@ -26,6 +26,30 @@ def broadcast_flat(make_flat, numel, device, src=0, dtype=th.float32):
     return flat
 
 
+def on_rank0(fn):
+    """Run `fn()` on rank 0 only and hand its (picklable, small) result to every rank; the other ranks wait, so whatever rank 0 wrote to a
+    shared cache directory is complete when they carry on.  An exception on rank 0 is raised on EVERY rank (no rank is left waiting in a
+    collective).  Single-process: a plain call.  Used for checkpoint downloads and for probing a checkpoint's architecture: N ranks
+    streaming into one cache file, or N ranks each un-pickling a multi-GB archive, is the failure mode this removes."""
+    rank, n = world()
+    if n == 1:
+        return fn()
+    result, err = None, None
+    if rank == 0:
+        try:
+            result = fn()
+        except Exception as e:  # noqa: BLE001 - re-raised below, on every rank
+            err = e
+    box = [(result, None if err is None else f"{type(err).__name__}: {err}")]
+    dist.broadcast_object_list(box, src=0)
+    result, msg = box[0]
+    if msg is not None:
+        if err is not None:
+            raise err
+        raise RuntimeError(f"rank 0 failed: {msg}")
+    return result
+
+
 def flat_pack(sd, names):
     return th.cat([sd[n].reshape(-1).float() for n in names])
 

@@ -200,6 +200,40 @@ def check_conv(precision):
     return out
 
 
+def check_kconv(precision=1):
+    """Weight-streaming halo conv kernel for the small maps (csrc/kconv.hip, tile code 516: K split among the wavefronts of a workgroup,
+    cross-wavefront reduction through LDS) against a float64 convolution: 8-pixel-wide maps (half-filled tiles), 16x16 / 32x32 / non-
+    square maps, batch, odd chunk counts (3, 5: the 5-vs-4 k-step split and the single-chunk tail), output widths that are not
+    multiples of 128, bias + residual, nearest-2x upsampled input, explicit and automatic split-K, forward and backward-to-input."""
+    from cgd_amd import ops
+    ctx = _ctx(precision)
+    out = []
+    for (Bn, H, W, Ci, Co, ups, sk) in [(1, 8, 8, 64, 96, 0, 1), (2, 8, 8, 128, 160, 0, 2), (1, 16, 8, 96, 64, 0, 1), (1, 16, 16, 160, 32, 0, 1),
+                                        (1, 16, 16, 256, 256, 0, 0), (2, 16, 16, 64, 160, 0, 3), (1, 32, 32, 128, 128, 0, 2), (1, 16, 32, 64, 64, 1, 1),
+                                        (1, 32, 32, 32, 96, 0, 1), (1, 8, 8, 1024, 512, 0, 0), (1, 48, 32, 96, 64, 0, 4), (1, 64, 64, 64, 64, 1, 1)]:
+        Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+        x = th.randn(Bn, Ci, Hs, Ws, generator=g(5))
+        w = th.randn(Co, Ci, 3, 3, generator=g(6)) / math.sqrt(9 * Ci)
+        b = 0.3 * th.randn(Co, generator=g(7))
+        r = 0.3 * th.randn(Bn, H, W, Co, generator=g(17))
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+        ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).float() + r.permute(0, 3, 1, 2)
+        wf, wd = ops.pack_conv3x3(w)
+        wfrag = ops.pack_conv3x3_frag(ctx, w.to(DEV), dgrad=False)
+        got = ops.conv3x3(ctx, x.permute(0, 2, 3, 1).contiguous().to(DEV), wf.to(DEV), b.to(DEV), R=r.to(DEV), upsample_input=bool(ups),
+                          force_tile=516, splitk=sk, w_frag=wfrag)
+        out.append(rec(f"kconv[p{precision}] B{Bn} {H}x{W} {Ci}->{Co} ups{ups} sk{sk}", got.permute(0, 3, 1, 2), ref))
+        if not ups:
+            dy = th.randn(Bn, Co, H, W, generator=g(8))
+            xr = x.double().requires_grad_()
+            (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
+            wdfrag = ops.pack_conv3x3_frag(ctx, w.to(DEV), dgrad=True)
+            sd = unit_seed(xr.grad)
+            got = ops.conv3x3(ctx, (dy * sd).permute(0, 2, 3, 1).contiguous().to(DEV), wd.to(DEV), None, force_tile=516, splitk=sk, w_frag=wdfrag)
+            out.append(rec(f"kconv dgrad[p{precision}] {H}x{W} {Ci}<-{Co} sk{sk}", got.permute(0, 3, 1, 2), (xr.grad * sd).float()))
+    return out
+
+
 def check_wconv():
     """Winograd F(2,3) halo conv kernel (csrc/wconv.hip, bf16x3 only) against a float64 convolution: plain, bias + residual, batch,
     nearest-upsampled input, the fused GroupNorm+SiLU input (gn_ab), multi-tile maps with several weight panels, and dgrad."""

@@ -191,8 +191,12 @@ class Scenario:
                 f"{' augs' if self.use_augs else ''}{' eps-consistent' if self.eps_consistent else ''}]")
 
     # ---- oracle ----------------------------------------------------------------------------------------------------------------
-    def run_oracle(self):
-        """[(sample, pred_xstart, log, legs or None)] per step."""
+    def run_oracle(self, forced_x0=None):
+        """[(sample, pred_xstart, log, legs or None)] per step.  `forced_x0` (list of per-step tensors): teacher forcing — the value of
+        the oracle's pred_xstart (and of the mean built from it) is replaced by the given one while its autograd path through the
+        oracle UNet is kept, so everything downstream (cond_fn, its gradient legs, the sample) is evaluated at the device's
+        linearisation point.  Used by the early-schedule scenario, where x0-hat = 157 (x - eps-hat) carries the rounding of eps-hat 157
+        times and the comparison of the DOWNSTREAM chain would otherwise measure that input difference, not the kernels."""
         og, B, H, W, N = self.og, self.B, self.H, self.W, self.N
         mk = og.MakeCutouts(self.res, self.cutn)
         if self.use_augs:
@@ -226,6 +230,20 @@ class Scenario:
                 th.manual_seed(777 + st["calls"])
                 return plain_cond(x, t, out, y)
         mkw = {"y": th.zeros(B, dtype=th.long)} if self.kw.get("num_classes") else {}
+        if forced_x0 is not None:
+            from oracle import diffusion as od
+            plain_pmv, calls = self.o_diff.p_mean_variance, [0]
+
+            def forced_pmv(model, x, t, clip_denoised=True, model_kwargs=None):
+                out = plain_pmv(model, x, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
+                target = forced_x0[calls[0]].to(out["pred_xstart"])
+                calls[0] += 1
+                out["pred_xstart"] = out["pred_xstart"] + (target - out["pred_xstart"]).detach()
+                out["mean"] = (od._extract(self.o_diff.posterior_mean_coef1, t, x.shape) * out["pred_xstart"]
+                               + od._extract(self.o_diff.posterior_mean_coef2, t, x.shape) * x)
+                return out
+
+            self.o_diff.p_mean_variance = forced_pmv
         loop = self.o_diff.ddim_sample_loop_progressive if self.ddim else self.o_diff.p_sample_loop_progressive
         gen = loop(self.ref_unet, (B, 3, H, W), clip_denoised=False, cond_fn=o_cond, model_kwargs=dict(mkw), device="cpu",
                    skip_timesteps=self.skip, init_image=self.x0_star.expand(B, -1, -1, -1), randomize_class=bool(mkw),
@@ -246,6 +264,8 @@ class Scenario:
                         "g_unet": -lg["g_raw"] - g_direct}  # g = -(g_direct + UNet^T seed): the UNet-dgrad leg on its own
             st["current_timestep"] -= 1
             out.append((o["sample"].clone(), o["pred_xstart"].clone(), dict(st.get("log", {})), legs))
+        if forced_x0 is not None:
+            self.o_diff.p_mean_variance = plain_pmv
         return out
 
     # ---- device ----------------------------------------------------------------------------------------------------------------
@@ -325,17 +345,34 @@ def compare(sc, precision, o_out, d_iter):
         if sc.eps_consistent:
             # x0-hat = sqrt(1/abar) x - A eps-hat with A = sqrt(1/abar - 1) (157 at t = T-1): what the kernels compute is eps-hat, and
             # an eps-hat error at the literal tolerance is an x0-hat error of A (atol + rtol |eps-hat|).  Graded: eps-hat (implied by
-            # x0-hat, same x on both sides) at the literal tolerance — the named criterion `amplified` for x0-hat — with the strict
-            # verdict of x0-hat itself reported beside it in `ok_strict`.
+            # x0-hat, same x on both sides) at the literal tolerance — the named criterion `amplified` for x0-hat and for the
+            # free-running sample that is built from it — with their strict verdicts reported beside it in `ok_strict`.
+            recs.pop()  # the free-running sample is re-judged below
             A = sc.amp
             x_t = sc.o_diff.q_sample(sc.x0_star, th.tensor([sc.t_first]), sc.tape["x_T"]).double()
             a_ = float(sc.o_diff.sqrt_recip_alphas_cumprod[sc.t_first])
             e_dev, e_ref = (a_ * x_t - out["pred_xstart"].double().cpu()) / A, (a_ * x_t - o_x0.double()) / A
             r_eps = rec(f"{tag} step{k} eps-hat (implied by pred_xstart)", e_dev, e_ref)
-            r_x0 = rec(f"{tag} step{k} pred_xstart", out["pred_xstart"], o_x0)
-            r_x0.update(criterion="amplified", ok=r_eps["ok"], reason=f"x0-hat = {a_:.1f} x - {A:.1f} eps-hat: eps-hat is graded strictly, "
-                        f"x0-hat carries its error {A:.0f} times (strict verdict in ok_strict)")
-            recs += [r_eps, r_x0]
+            why = (f"x0-hat = {a_:.1f} x - {A:.1f} eps-hat: eps-hat is graded strictly, x0-hat carries its error {A:.0f} times "
+                   "(strict verdict in ok_strict)")
+            r_x0 = rec(f"{tag} step{k} pred_xstart (free-running)", out["pred_xstart"], o_x0)
+            r_x0.update(criterion="amplified", ok=r_eps["ok"], reason=why)
+            r_s = rec(f"{tag} step{k} sample (free-running)", out["sample"], o_s)
+            r_s.update(criterion="amplified", ok=r_eps["ok"], reason=why)
+            recs += [r_eps, r_x0, r_s]
+            # everything downstream of x0-hat against the TEACHER-FORCED oracle (run_oracle(forced_x0=...)): same linearisation point
+            f_s, f_x0, o_log, o_legs = sc.forced[k]
+            # x_{t-1} = mean + variance * g + noise: it inherits variance * (error of g), and g is the sum of two legs that cancel
+            # (below).  Strict when it passes; otherwise the named criterion `cancelling-legs` with the atol of g scaled by the
+            # largest variance of the step (beta_t, the upper end of the learned range), strict verdict in ok_strict.
+            r_fs = rec(f"{tag} step{k} sample (oracle at the device's x0-hat)", out["sample"], f_s)
+            if not r_fs["ok"] and o_legs is not None:
+                beta = float(sc.o_diff.betas[sc.t_first - k])
+                leg_peak = max(1.0, o_legs["g_unet"].abs().max().item())
+                r_c = rec(r_fs["name"], out["sample"], f_s, atol=pc.ATOL * (1.0 + beta * leg_peak))
+                r_fs.update(criterion="cancelling-legs", ok=r_c["ok"], reason=f"x_(t-1) carries beta_t = {beta:.3f} times the error of g, "
+                            f"whose two legs of peak {leg_peak:.3g} cancel (strict verdict in ok_strict)")
+            recs.append(r_fs)
         else:
             recs.append((vec if (relu and k > 0) else rec)(f"{tag} step{k} pred_xstart", out["pred_xstart"], o_x0))
         if sc.gate[k][0]:  # guidance skipped on this step (the reference returns zeros_like(x)): no new scalars, no gradient
@@ -373,7 +410,25 @@ def compare(sc, precision, o_out, d_iter):
 
 def check_step(case="mini", precision=1, **kw):
     sc = Scenario(case, **kw)
-    return compare(sc, precision, sc.run_oracle(), sc.run_device(precision))
+    if not sc.eps_consistent:
+        return compare(sc, precision, sc.run_oracle(), sc.run_device(precision))
+    # early-schedule scenario: the device runs first; the oracle then runs twice, free (grades eps-hat; reports x0-hat and x_{t-1}) and
+    # teacher-forced to the device's x0-hat (grades the loss scalars, every gradient leg, g and x_{t-1} at the same linearisation point)
+    d_steps = []
+    for out, guid, legs in sc.run_device(precision):
+        d_steps.append(({k: v.clone() for k, v in out.items() if th.is_tensor(v)}, _FrozenLog(guid.log()), legs))
+    sc.forced = sc.run_oracle(forced_x0=[d[0]["pred_xstart"].cpu() for d in d_steps])
+    return compare(sc, precision, sc.run_oracle(), iter(d_steps))
+
+
+class _FrozenLog:
+    """Stands in for the guidance object after the run: compare() only asks for log()."""
+
+    def __init__(self, log):
+        self._log = dict(log)
+
+    def log(self):
+        return self._log
 
 
 def check_headline_step(precision=1, steps=1):

@@ -182,3 +182,80 @@ def test_prompt_weight_rows_follow_the_global_batch():
     assert th.equal(full, th.eye(4) * w.sum())
     assert th.equal(full[[2]], th.tensor([[0.0, 0.0, 1.0, 0.0]]) * w.sum())
     assert th.equal(dg.prompt_weight_matrix(w, 1, "cpu"), w.view(1, 4))     # what a naive per-rank B = 1 would have used instead
+
+
+def _download_worker(rank, world, port, cache, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    import requests
+    import cgd_amd  # noqa: F401
+    from cgd import script_util
+
+    class Resp:
+        headers = {"Content-Length": str(4 << 20)}
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def raise_for_status(self):
+            pass
+
+        def iter_content(self, chunk_size=0):
+            for i in range(64):  # 4 MiB in 64 slow chunks: a concurrent writer on the same file would interleave or truncate
+                time.sleep(0.005)
+                yield bytes([i]) * (64 << 10)
+
+    fetched = []
+
+    def fake_get(url, **kw):
+        fetched.append(url)
+        return Resp()
+
+    requests.get = fake_get
+    if rank == 1:
+        time.sleep(0.3)  # a rank that arrives late must still take part (and not re-download)
+    path = script_util.download("http://example.invalid/ckpt.pt", "ckpt.pt", root=cache)
+    data = open(path, "rb").read()
+    ok = len(data) == 4 << 20 and all(data[i * (64 << 10)] == i and data[(i + 1) * (64 << 10) - 1] == i for i in range(64))
+    # second call: cache hit decided by rank 0 for everybody, no fetch anywhere
+    path2 = script_util.download("http://example.invalid/ckpt.pt", "ckpt.pt", root=cache)
+    # failure on rank 0 surfaces on every rank instead of leaving the others in a collective
+    def boom(url, **kw):
+        raise requests.exceptions.ConnectionError("no route")
+    requests.get = boom
+    os.environ["CGD_DOWNLOAD_BACKOFF"] = "0"
+    try:
+        script_util.download("http://example.invalid/other.pt", "other.pt", root=cache)
+        failed = None
+    except RuntimeError as e:
+        failed = str(e)
+    q.put((rank, len(fetched), ok, path == path2, failed, sorted(os.listdir(cache))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_checkpoint_download_runs_on_rank0_only_world2(tmp_path):
+    """under the multi-GPU launcher every rank used to stream into the same `<target>.tmp`.  Now rank 0 downloads
+    (per-process temporary name, atomic os.replace), the other ranks wait and read the finished file; a failure on rank 0 is raised
+    on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    cache = str(tmp_path / "cache")
+    procs = [ctx.Process(target=_download_worker, args=(r, 2, port, cache, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, n0, ok0, same0, f0, ls0), (r1, n1, ok1, same1, f1, ls1) = res
+    assert (n0, n1) == (1, 0)            # one fetch in total, on rank 0
+    assert ok0 and ok1 and same0 and same1
+    assert f0 and "Download failed" in f0 and f1 and "rank 0 failed" in f1
+    assert ls0 == ["ckpt.pt"] == ls1     # no temporary files left behind

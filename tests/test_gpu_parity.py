@@ -39,6 +39,22 @@ def test_conv(precision):
     _assert_all(pc.check_conv(precision))
 
 
+@pytest.mark.parametrize("precision", [1, 2])
+def test_conv_weight_streaming_small_map_variant(precision):
+    recs = pc.check_kconv(precision)
+    if precision == 2:  # single-bf16 speed mode: sanity-bounded only (same rule as test_gemm_bf16_single_product_is_bf16_accurate)
+        assert all(r["err_rel"] < 1e-2 for r in recs)
+    else:
+        _assert_all(recs)
+
+
+def test_unet_small_maps_on_the_previous_kernels(monkeypatch):
+    """CGD_KCONV=0 keeps the round-2 routing (hconv2 / igemm on the <= 32x32 maps) selectable: grade it as well."""
+    monkeypatch.setenv("CGD_KCONV", "0")
+    _assert_all(pc.check_unet("mini", 1))
+    _assert_all(pc.check_unet("cfg64", 1))
+
+
 def test_conv_winograd_variant():
     _assert_all(pc.check_wconv())
 

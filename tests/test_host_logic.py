@@ -543,7 +543,23 @@ def test_use_augs_pipeline_ops_match_their_torchvision_definitions():
     assert th.allclose(dg.aug_affine(x, 0.0, 0, 0), x, atol=1e-6)
     t = dg.aug_affine(x, 0.0, 3, -2)                                   # output[y][x] = input[y + 2][x - 3], zeros shifted in
     assert th.allclose(t[:, :, 5, 10], x[:, :, 7, 7]) and float(t[:, :, :, :3].abs().max()) == 0.0
-    assert th.allclose(dg.aug_affine(x, 90.0, 0, 0), th.rot90(x, 1, (2, 3)), atol=1e-6)  # positive angle = counter-clockwise
+    assert th.allclose(dg.aug_affine(x, 90.0, 0, 0), th.rot90(x, -1, (2, 3)), atol=1e-6)  # positive angle = CLOCKWISE (torchvision)
+    # angle 10 deg, translate (2, 1) on an 8x8 ramp against torchvision's documented inverse matrix (_get_inverse_affine_matrix, shear 0,
+    # scale 1, centre of the image): M = [[cos a, sin a], [-sin a, cos a]], applied in pixel-centre coordinates, NEAREST, fill 0 —
+    # evaluated here with plain Python loops, independently of the grid_sample formulation under test
+    import math
+    ramp8 = th.arange(64.0).view(1, 1, 8, 8)
+    got = dg.aug_affine(ramp8, 10.0, 2, 1)[0, 0]
+    ca, sa = math.cos(math.radians(10.0)), math.sin(math.radians(10.0))
+    for yo in range(8):
+        for xo in range(8):
+            u, v = xo + 0.5 - 4 - 2, yo + 0.5 - 4 - 1                   # output pixel centre relative to the image centre, minus translate
+            xi, yi = ca * u + sa * v + 4 - 0.5, -sa * u + ca * v + 4 - 0.5  # input pixel index (real-valued)
+            ix, iy = math.floor(xi + 0.5), math.floor(yi + 0.5)
+            if min(abs(xi + 0.5 - round(xi + 0.5)), abs(yi + 0.5 - round(yi + 0.5))) < 1e-3:
+                continue                                                 # a tie of the nearest-neighbour rounding: either is right
+            want = float(ramp8[0, 0, iy, ix]) if 0 <= ix < 8 and 0 <= iy < 8 else 0.0
+            assert float(got[yo, xo]) == want, (yo, xo, float(got[yo, xo]), want)
     corners = [[0, 0], [39, 0], [39, 39], [0, 39]]
     assert th.allclose(dg.aug_perspective(x, corners, corners), x, atol=1e-4)
     ramp = (th.arange(40.0).view(1, 1, 1, 40) / 40).expand(1, 3, 40, 40).contiguous()
