@@ -303,6 +303,18 @@ def main():
     cpu_s = time.process_time() - c0  # CPU seconds (user + sys, all threads of this rank) spent driving the K steps
     finite = bool(th.isfinite(out["sample"]).all().item())
     peak = float(out["sample"].abs().max().item())
+    # host cost of ONE step in isolation (untimed, after the timed region): the queue is empty and the 4-slot upload ring is free, so the
+    # call returns as soon as the step is enqueued — wall time and main-thread CPU time of the enqueue, without any waiting on the GPU
+    # (inside the timed loop the host is held back by that ring: it may run at most 4 steps ahead of the GPU)
+    iso_wall, iso_cpu = [], []
+    for _ in range(6):
+        th.cuda.synchronize()
+        w0, u0 = time.perf_counter(), time.thread_time()
+        next(steps)
+        iso_wall.append(time.perf_counter() - w0)
+        iso_cpu.append(time.thread_time() - u0)
+    th.cuda.synchronize()
+    iso_wall, iso_cpu = sorted(iso_wall)[len(iso_wall) // 2], sorted(iso_cpu)[len(iso_cpu) // 2]
 
     roof = hbm = None
     if not args.no_profile and rank == 0:
@@ -360,16 +372,16 @@ def main():
     assert finite, "non-finite sample"
     tdev = dev if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
     tmax = th.tensor([dt], device=tdev, dtype=th.float64)
-    per_rank, host = [dt], [(cpu_s, t_enq)]
+    per_rank, host = [dt], [(cpu_s, t_enq, iso_wall, iso_cpu)]
     if world > 1:
         gathered = [th.zeros_like(tmax) for _ in range(world)]
         dist.all_gather(gathered, tmax)
         per_rank = [float(t.item()) for t in gathered]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        hv = th.tensor([cpu_s, t_enq], device=tdev, dtype=th.float64)
+        hv = th.tensor([cpu_s, t_enq, iso_wall, iso_cpu], device=tdev, dtype=th.float64)
         hg = [th.zeros_like(hv) for _ in range(world)]
         dist.all_gather(hg, hv)
-        host = [(float(h[0].item()), float(h[1].item())) for h in hg]
+        host = [tuple(float(v) for v in h.tolist()) for h in hg]
     tmax = tmax.item()
 
     if rank == 0:
@@ -393,8 +405,12 @@ def main():
                        # multi-GPU host readiness: CPU time each rank's driver process burns per step (user + sys,
                        # all threads) and the wall time it needs to ENQUEUE a step; the host keeps N ranks fed while
                        # N * host_cpu_ms_per_step / ms_per_step stays below the cores it has
-                       "host_cpu_ms_per_step_per_rank": [round(c / args.steps * 1e3, 3) for c, _ in host],
-                       "host_enqueue_ms_per_step_per_rank": [round(e / args.steps * 1e3, 3) for _, e in host],
+                       "host_cpu_ms_per_step_per_rank": [round(h[0] / args.steps * 1e3, 3) for h in host],
+                       "host_enqueue_ms_per_step_per_rank": [round(h[1] / args.steps * 1e3, 3) for h in host],
+                       # one step enqueued on an idle queue (median of 6): wall time until the call returns / CPU time of the
+                       # enqueuing thread — the host work a step really needs
+                       "host_isolated_enqueue_ms_per_rank": [round(h[2] * 1e3, 3) for h in host],
+                       "host_isolated_enqueue_cpu_ms_per_rank": [round(h[3] * 1e3, 3) for h in host],
                        "host_cores": usable_cores(1 << 20),
                        "trajectory": f"chained: every step consumes the previous step's sample; chains of {start + 1} steps from "
                                      f"x_t = q_sample(x0*, t={start}) down to t = 0 (init-image prologue, skip_timesteps {N - 1 - start})",

@@ -11,7 +11,9 @@ pick='import sys, json
 r = json.loads([l for l in sys.stdin.read().splitlines() if l.startswith("{")][-1]); c = r["config"]
 print(json.dumps({"n_ranks": r["n_gpus"], "value_steps_per_s": r["value"], "ms_per_step_max_rank": r["ms_per_step"],
                   "ms_per_step_per_rank": c["ms_per_step_per_rank"], "host_cpu_ms_per_step_per_rank": c["host_cpu_ms_per_step_per_rank"],
-                  "host_enqueue_ms_per_step_per_rank": c["host_enqueue_ms_per_step_per_rank"], "host_cores": c["host_cores"]}))'
+                  "host_enqueue_ms_per_step_per_rank": c["host_enqueue_ms_per_step_per_rank"],
+                  "host_isolated_enqueue_ms_per_rank": c["host_isolated_enqueue_ms_per_rank"],
+                  "host_isolated_enqueue_cpu_ms_per_rank": c["host_isolated_enqueue_cpu_ms_per_rank"], "host_cores": c["host_cores"]}))'
 nproc
 timeout 300 python bench.py --gpus 1 --steps $((STEPS * 2)) --warmup 5 --no-cpu-baseline --no-profile 2>/dev/null | python -c "$pick"
 for n in 2 4 8; do

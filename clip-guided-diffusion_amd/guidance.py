@@ -292,7 +292,10 @@ class ClipGuidance:
         host.copy_(th.as_tensor(geo, dtype=th.int32).view(n, 4))
         out = ring["dev"][k, :n]
         out.copy_(host, non_blocking=True)
-        ev = th.cuda.Event()
+        # blocking=True: a host that has run four steps ahead SLEEPS until the slot is free instead of spinning on the event — with one
+        # driver process per GPU the spin would keep 8 cores busy doing nothing (36 ms of CPU per 20 ms step per rank measured,
+        # profiles/r3_host_contention.txt; the enqueue itself needs 4 ms)
+        ev = th.cuda.Event(blocking=True)
         ev.record(th.cuda.current_stream(dev))
         ring["done"][k] = ev
         return out

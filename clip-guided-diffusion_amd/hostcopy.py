@@ -32,7 +32,7 @@ class HostCopy:
             with th.cuda.stream(side):
                 side.wait_event(produced)
                 self.host.copy_(t, non_blocking=True)
-                self.done = th.cuda.Event()
+                self.done = th.cuda.Event(blocking=True)  # get() sleeps, it does not spin: one driver process per GPU shares the host
                 self.done.record()
             t.record_stream(side)  # the caching allocator must not hand t's block out before the side-stream copy has read it
         self._src = t
