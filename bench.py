@@ -45,10 +45,11 @@ U256 = dict(image_size=256, model_channels=256, num_res_blocks=2, attention_reso
 U512 = dict(image_size=512, model_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_classes=1000, num_head_channels=64)
 # mean algorithmic HBM bytes of a 3x3-conv launch in config 2: 4 B * M * (Cin + Cout) activations + 4 B * taps * Cin * Cout packed
 # weights (taps = 12 transformed filter taps for the Winograd kernel, 9 for the direct one), averaged over the kernel's launches of
-# a step: 52 wconv_kernel launches (>= 128x128 pixels), 84 hconv2_kernel launches (tests/plan_dump.py; checked by
-# tests/test_flop_accounting.py)
+# a step: 52 wconv_kernel launches (>= 128x128 pixels), 28 hconv2_kernel launches (the 64x64 level) and 88 kconv_kernel launches
+# (8x8 .. 32x32; weight-streaming: the 36 MB are almost all packed weights) (tests/plan_dump.py; checked by tests/test_flop_accounting.py)
 WCONV_ALGO_BYTES_PER_LAUNCH = 97.64e6
-HCONV_ALGO_BYTES_PER_LAUNCH = 29.77e6
+HCONV_ALGO_BYTES_PER_LAUNCH = 26.55e6
+KCONV_ALGO_BYTES_PER_LAUNCH = 36.48e6
 METRIC = "diffusion steps/sec (UNet+CLIP+grad) at 256x256 cutn=16"
 
 # BASELINE.json configs[1..4]; tflop = algorithmic TFLOP per sample-step (SURVEY.md 8d / BASELINE.md section 2).
@@ -324,11 +325,11 @@ def main():
         tp = time.perf_counter()
         for _ in range(args.profile_steps):
             next(steps)
-        buf = (C.c_double * 12)()
+        buf = (C.c_double * 15)()
         ctx.check(ctx.lib.cgd_profile_read(ctx.h, buf))
         dtp = time.perf_counter() - tp
         ctx.check(ctx.lib.cgd_profile(ctx.h, 0))
-        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n, gn_ms, gn_bytes, gn_n, w_ms, w_flop, w_n = list(buf)
+        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n, gn_ms, gn_bytes, gn_n, w_ms, w_flop, w_n, k_ms, k_flop, k_n = list(buf)
         ps = args.profile_steps
         nprod = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
 
@@ -354,6 +355,16 @@ def main():
             roof["measured_in"] = f"untimed pass of {ps} steps after the timed region"
             if len(legs) > 1:
                 roof["other_conv_kernel"] = legs[1]
+            if k_n > 0:  # weight-streaming kernel of the <= 32x32 maps: bound by the weight stream (HBM), not by the MFMA pipe
+                kb = k_n / ps * KCONV_ALGO_BYTES_PER_LAUNCH if args.config == 2 else None
+                roof["small_map_conv_kernel"] = {
+                    "kernel": f"kconv_kernel<{args.precision}> (weight-streaming halo conv, K split inside the workgroup, kconv.hip)",
+                    "bound": "hbm (packed weights)", "launches_per_step": k_n / ps, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
+                    "achieved_tflops": round(k_flop / (k_ms * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(k_flop / (k_ms * 1e-3) / 2.5e15, 4),
+                    "algorithmic_bytes_per_launch": KCONV_ALGO_BYTES_PER_LAUNCH if args.config == 2 else None,
+                    "achieved_gbs": None if kb is None else round(kb / (k_ms / ps * 1e-3) / 1e9, 1),
+                    "frac_of_hbm_peak": None if kb is None else round(kb / (k_ms / ps * 1e-3) / 8e12, 4),
+                    "kernel_time_share": round(k_ms * 1e-3 / dtp, 4)}
             roof["other_mfma_kernel"] = {"kernel": "igemm_kernel / hgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / ps,
                                          "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
                                          "ms_per_step": round(ig_ms / ps, 3), "kernel_time_share": round(ig_ms * 1e-3 / dtp, 4)}

@@ -108,7 +108,8 @@ int cgd_profile(cgd_ctx* ctx, int enable) {
 }
 
 // out[3k .. 3k+2] = {summed time (ms), algorithmic work, launches} of kind k (common.h: 0 GEMM kernels with their split-K reduce
-// [FLOP], 1 hconv2_kernel alone [FLOP], 2 GroupNorm forward / backward ops [bytes], 3 wconv_kernel alone [FLOP]).  Resets the records.
+// [FLOP], 1 hconv2_kernel alone [FLOP], 2 GroupNorm forward / backward ops [bytes], 3 wconv_kernel alone [FLOP], 4 kconv_kernel alone [FLOP]):
+// 15 doubles.  Resets the records.
 int cgd_profile_read(cgd_ctx* ctx, double* out) {
   CGD_NEED_CTX(ctx);
   if (!out) CGD_FAIL(ctx, "cgd_profile_read: out is null");

@@ -15,8 +15,8 @@ enum { CGD_PREC_F32 = 0, CGD_PREC_BF16X3 = 1, CGD_PREC_BF16 = 2 };
 
 // kinds of profiled launches (bench.py): MFMA GEMM kernels (igemm / hgemm incl. their split-K reduce), the direct halo conv kernel
 // alone, GroupNorm forward / backward (all launches of one norm; `work` = algorithmic HBM bytes), the Winograd halo conv kernel
-// (the dominant kernel of the step: the 3x3 convs of the >= 128x128-pixel levels)
-enum { CGD_PROF_GEMM = 0, CGD_PROF_HCONV = 1, CGD_PROF_GN = 2, CGD_PROF_WCONV = 3, CGD_PROF_KINDS = 4 };
+// (the dominant kernel of the step: the 3x3 convs of the >= 128x128-pixel levels), the weight-streaming halo conv kernel of the <= 32x32 maps
+enum { CGD_PROF_GEMM = 0, CGD_PROF_HCONV = 1, CGD_PROF_GN = 2, CGD_PROF_WCONV = 3, CGD_PROF_KCONV = 4, CGD_PROF_KINDS = 5 };
 
 struct ProfRec {
   hipEvent_t a = nullptr, b = nullptr;

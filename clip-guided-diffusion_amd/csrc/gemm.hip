@@ -579,7 +579,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     CGD_FAIL(ctx, "cgd_launch_gemm: only hgemm2 in one slice fuses an activation into its epilogue (cgd_gemm_fuses_act)");
   if (p.splitk > 1) p.ws = ctx->ws;
   ProfRec pr;
-  CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? (tile == 515 ? CGD_PROF_WCONV : CGD_PROF_HCONV) : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));
+  CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? (tile == 515 ? CGD_PROF_WCONV : (tile == 516 ? CGD_PROF_KCONV : CGD_PROF_HCONV)) : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));
   if (use_h) {
     if (tile == 515)
       CGD_TRY(cgd_launch_wconv(ctx, p, s));

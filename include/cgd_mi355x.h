@@ -43,9 +43,10 @@ int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks);
 /* HIP-event timing of the profiled launches on their own stream (measurement only; bench.py roofline / hbm legs).
  * cgd_profile_read: out[3k .. 3k+2] = {summed ms, algorithmic work, launches} of kind k: 0 = igemm_kernel / hgemm_kernel launches
  * incl. their split-K reduce [FLOP], 1 = hconv2_kernel launches alone [FLOP], 2 = GroupNorm forward / backward ops, all launches
- * of one norm [algorithmic HBM bytes], 3 = wconv_kernel launches alone (the dominant kernel) [FLOP]; synchronises the device and resets. */
+ * of one norm [algorithmic HBM bytes], 3 = wconv_kernel launches alone (the dominant kernel) [FLOP], 4 = kconv_kernel launches alone
+ * (the weight-streaming conv kernel of the <= 32x32-pixel maps) [FLOP]: 15 doubles; synchronises the device and resets. */
 int cgd_profile(cgd_ctx* ctx, int enable);
-int cgd_profile_read(cgd_ctx* ctx, double* out12);
+int cgd_profile_read(cgd_ctx* ctx, double* out15);
 
 /* ---- UNet epsilon/sigma predictor: replaces guided_diffusion.unet.UNetModel built at
  *      /root/reference/cgd/script_util.py:316 from /root/reference/data/diffusion_model_flags.py ---- */

@@ -73,7 +73,8 @@ def step_plan(cutn=16):
                 else:
                     n_, k_ = (N, K) if direction == "fwd" else (K, N)
                 rc, (kern, tile, sk, wg) = plan(handle, kind, M, n_, k_)
-                name = ("wconv" if tile == 515 else KERNELS[kern]) if rc == 0 else f"n/a({rc})"  # 515: the Winograd halo kernel
+                # 515: the Winograd halo kernel, 516: the weight-streaming halo kernel of the small maps
+                name = ("wconv" if tile == 515 else "kconv" if tile == 516 else KERNELS[kern]) if rc == 0 else f"n/a({rc})" 
                 rows.append((net, kind, direction, M, n_, k_, name, tile, sk, wg, 2.0 * M * N * kk / 1e9))
     return rows
 

@@ -90,18 +90,18 @@ def test_dispatch_policy_of_the_contraction_launcher():
     def conv(H, ci, co, **kw):
         return _plan(handle, conv=1, M=H * H, N=co, H=H, W=H, Cin=ci, **kw)
 
-    # 3x3 convs: the halo kernels from 16^2 pixels up — the Winograd F(2,3) variant (tile code 515) from 128^2 pixels, with 16x16-pixel
-    # tiles while they give every CU a workgroup and 8x16 below; the direct kernel (512) with split-K over 32-channel chunks once
-    # there are fewer tiles than CUs (about one workgroup per CU, >= 4 chunks per slice); 8x8 maps fall back to the 64x64 igemm
-    # tile (the halo kernel supports them with half-filled tiles, CGD_HCONV_W8=1, but is no faster there)
+    # 3x3 convs: the Winograd F(2,3) halo kernel (tile code 515) from 128^2 pixels, with 16x16-pixel tiles while they give every CU a
+    # workgroup and 8x16 below; the direct halo kernel (512) on the 64^2 level, split-K over 32-channel chunks once there are fewer
+    # tiles than CUs; the weight-streaming kernel (516: one 32-channel output block per workgroup, K split among its wavefronts) on the
+    # <= 32^2 levels incl. the 8x8 maps, with the inter-workgroup split-K it still needs to put one workgroup on every CU
     assert conv(256, 256, 256) == (0, (1, 515, 1, 512))
     assert conv(256, 512, 256) == (0, (1, 515, 1, 512))
     assert conv(256, 256, 512) == (0, (1, 515, 1, 1024))
     assert conv(128, 256, 256) == (0, (1, 515, 1, 256))
     assert conv(64, 512, 512) == (0, (1, 512, 2, 256))
-    assert conv(32, 512, 512) == (0, (1, 512, 4, 128))
-    assert conv(16, 1024, 1024) == (0, (1, 512, 8, 128))
-    assert conv(8, 1024, 1024) == (0, (0, 64, 32, 512))
+    assert conv(32, 512, 512) == (0, (1, 516, 2, 256))
+    assert conv(16, 1024, 1024) == (0, (1, 516, 4, 256))
+    assert conv(8, 1024, 1024) == (0, (1, 516, 8, 256))
     assert conv(256, 256, 256, precision=0) == (0, (0, 1256, 1, 512))  # exact-fp32 mode: the halo kernel is bf16-only
     # weight GEMMs (ViT-B/32 on 16 cutouts = 800 tokens): hgemm with the cached fragment copy; 128-row tiles would leave CUs idle, so
     # the 64-row tile is used: the N >= 2304 linears fill the chip without split-K, the N = 768 ones split 3 ways
@@ -116,7 +116,9 @@ def test_dispatch_policy_of_the_contraction_launcher():
     assert _plan(handle, M=256, N=3072, K=1024, weight=1)[1][0] == 2
     assert _plan(handle, M=1, N=1024, K=256, weight=1)[1][0] == 0
     # fewer CUs -> fewer slices; argument validation happens before any launch
-    assert _plan(handle, conv=1, M=32 * 32, N=512, H=32, W=32, Cin=512, num_cu=64)[1][2] == 2
+    assert _plan(handle, conv=1, M=64 * 64, N=512, H=64, W=64, Cin=512, num_cu=256)[1][2] == 2
+    assert _plan(handle, conv=1, M=64 * 64, N=512, H=64, W=64, Cin=512, num_cu=64)[1][2] == 1
+    assert _plan(handle, conv=1, M=16 * 16, N=1024, H=16, W=16, Cin=1024, num_cu=64) == (0, (1, 516, 1, 64))
     assert _plan(handle, M=800, N=768, K=770, weight=1)[0] == -2   # K must be a multiple of 4
     assert _plan(handle, conv=1, M=64 * 64, N=64, H=64, W=64, Cin=48)[0] == -2  # conv Cin must be a multiple of 32
 

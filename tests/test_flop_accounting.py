@@ -73,30 +73,38 @@ def test_flop_per_step_of_the_other_configs():
 
 def test_launch_plan_agrees_with_the_committed_bench_line():
     """tests/plan_dump.py (oracle shapes + the launcher's own selection code, both on the CPU) against what the GPU run recorded in
-    profiles/r1_bench_1gpu.json: the halo conv kernel gets 136 launches per guided step carrying 4.18 of the 4.775 TFLOP."""
+    profiles/r1_bench_1gpu.json (round 1: 136 halo-kernel launches per guided step carrying 4.18 of the 4.775 TFLOP; since round 3 the
+    8x8 convs run on a halo kernel too: 168 launches, 4.23 TFLOP)."""
     import json
     from tests import plan_dump
     rows = plan_dump.step_plan()
     wconv = [r for r in rows if r[6] == "wconv"]    # Winograd halo kernel: the >= 128x128-pixel levels
-    hconv = [r for r in rows if r[6] == "hconv2"]   # direct halo kernel: 64x64 .. 16x16
+    hconv = [r for r in rows if r[6] == "hconv2"]   # direct halo kernel: the 64x64 level
+    kconv = [r for r in rows if r[6] == "kconv"]    # weight-streaming halo kernel: 32x32 .. 8x8 (round 3)
     assert len(wconv) == 52 and all(r[1] == "conv3x3" and r[3] >= 16384 and r[8] == 1 for r in wconv)
-    assert len(hconv) == 84 and all(r[1] == "conv3x3" and 256 <= r[3] < 16384 for r in hconv)
-    gflop = sum(r[10] for r in wconv + hconv)
-    assert gflop == pytest.approx(4179.5, abs=0.5)   # 4.18 of the 4.775 TFLOP of a step run on the two halo kernels
+    assert len(hconv) == 28 and all(r[1] == "conv3x3" and r[3] == 4096 for r in hconv)
+    assert len(kconv) == 88 and all(r[1] == "conv3x3" and 64 <= r[3] <= 1024 for r in kconv)
+    gflop = sum(r[10] for r in wconv + hconv + kconv)
+    assert gflop == pytest.approx(4225.4, abs=0.5)   # 4.23 of the 4.775 TFLOP of a step run on the three halo kernels
     assert sum(r[10] for r in wconv) == pytest.approx(3247.0, abs=0.5)
-    assert sum(1 for r in hconv if r[8] > 1) == 82  # 64^2 and smaller maps: split-K over channel chunks
+    assert sum(r[10] for r in kconv) == pytest.approx(418.0, abs=0.5)
+    assert sum(1 for r in hconv if r[8] > 1) == 26 and sum(1 for r in kconv if r[8] > 1) == 81  # split-K over channel chunks
+    assert max(r[8] for r in kconv) == 8  # K is split inside the workgroup first: at most 8 slices (hconv2 / igemm needed up to 32)
     # 16-row tiles while they fill the chip (256x256: 512 / 1024 workgroups), 8-row tiles on the 128x128 level (256 / 384)
     assert {(r[3], r[9]) for r in wconv} == {(65536, 512), (65536, 1024), (16384, 256), (16384, 384)}
     import bench
     algo_w = sum(4 * r[3] * (r[5][2] + r[4]) + 4 * 12 * r[5][2] * r[4] for r in wconv) / len(wconv)
     algo_h = sum(4 * r[3] * (r[5][2] + r[4]) + 4 * 9 * r[5][2] * r[4] for r in hconv) / len(hconv)
+    algo_k = sum(4 * r[3] * (r[5][2] + r[4]) + 4 * 9 * r[5][2] * r[4] for r in kconv) / len(kconv)
     assert algo_w == pytest.approx(bench.WCONV_ALGO_BYTES_PER_LAUNCH, rel=1e-3)
     assert algo_h == pytest.approx(bench.HCONV_ALGO_BYTES_PER_LAUNCH, rel=1e-3)
+    assert algo_k == pytest.approx(bench.KCONV_ALGO_BYTES_PER_LAUNCH, rel=1e-3)
     with open(os.path.join(ROOT, "profiles", "r1_bench_1gpu.json")) as f:
         roof = json.loads(f.read().strip().splitlines()[-1])["roofline"]
-    assert roof["launches_per_step"] == pytest.approx(136.0)  # round 1: every one of them on hconv2_kernel
-    assert roof["flop_per_launch"] * roof["launches_per_step"] == pytest.approx(gflop * 1e9, rel=1e-3)
+    assert roof["launches_per_step"] == pytest.approx(136.0)  # round 1: 136 launches (16x16 .. 256x256), all on hconv2_kernel
+    r1 = sum(r[10] for r in wconv + hconv + kconv if r[3] >= 256)
+    assert roof["flop_per_launch"] * roof["launches_per_step"] == pytest.approx(r1 * 1e9, rel=1e-3)
     # every ViT linear (16 cutouts = 800 token rows) goes to the weight GEMM kernel; the 8x8-pixel convs and M = 1 embeddings do not
     vit = [r for r in rows if r[0] == "vit" and r[1] == "linear" and r[3] == 800]
     assert len(vit) == 96 and all(r[6] == "hgemm" for r in vit)
-    assert all(r[6] == "igemm" for r in rows if r[1] == "conv3x3" and r[3] == 64 and r[7] != 0)
+    assert all(r[6] == "kconv" for r in rows if r[1] == "conv3x3" and r[3] == 64 and r[7] != 0)  # the 8x8 convs left igemm in round 3
