@@ -362,6 +362,7 @@ def main():
                     "bound": "hbm (packed weights)", "launches_per_step": k_n / ps, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
                     "achieved_tflops": round(k_flop / (k_ms * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(k_flop / (k_ms * 1e-3) / 2.5e15, 4),
                     "algorithmic_bytes_per_launch": KCONV_ALGO_BYTES_PER_LAUNCH if args.config == 2 else None,
+                    "traffic": pmc_traffic("kconv_kernel") if args.config == 2 else None,
                     "achieved_gbs": None if kb is None else round(kb / (k_ms / ps * 1e-3) / 1e9, 1),
                     "frac_of_hbm_peak": None if kb is None else round(kb / (k_ms / ps * 1e-3) / 8e12, 4),
                     "kernel_time_share": round(k_ms * 1e-3 / dtp, 4)}
