@@ -16,6 +16,12 @@
 //     epilogue: bias / residual, or the fp32 slab of a split-K slice (same workspace protocol, same reduce kernel / consumers).
 // Per chunk a wavefront issues 4.5 x 12 MFMAs (1728 cycles) for 9 KB of weights: 21 B/clk per CU of weight fragments, half of which
 // is L2 traffic when two pixel tiles share a weight block: the MFMA pipe keeps up with the HBM stream at 256 pixels and idles below.
+// The activations of chunk j + 2 are fetched during chunk j and converted / written to LDS during chunk j + 1 (two staging register
+// sets): they come from L2 / MALL behind the weight stream and need a whole chunk of lead.
+// Measured (round 3, profiles/r3_kconv_microbench.txt, r3_ab_kconv.txt, r3_bench_1gpu.json): 88 launches per step at 24.6 us = 1.48 TB/s of
+// algorithmic bytes (MFMA pipe 23 % busy); per layer incl. the split-K reduce 16x16 1024->1024 28.3 -> 23.5 us, 8x8 20.1 -> 15.4 (was
+// igemm), 32x32 512->512 30.2 -> 24.9; -0.35 ms per guided step.  On the 64x64 level (MFMA-bound) it loses to hconv2: a patch is
+// staged per 32 output channels here instead of per 128.
 // Supports what hconv2 supports at TH = 8: W multiple of 16 or W = 8 (half-filled tile), nearest-2x upsampled input view, fused
 // GroupNorm+SiLU on the staged input (gn pairs), split-K.  Packed weights: the layout of cgd_pack_conv3x3_frag (hconv.hip).
 #include "common.h"
@@ -298,14 +304,15 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
 
 }  // namespace
 
+long cgd_kconv_tiles_m(const GemmParams& p) { return (long)(p.M / (p.H * p.W)) * (p.H / KTH) * cdiv(p.W, 16); }
+
 // same problems as hconv2 at TH = 8 (cgd_hconv_supported); the caller (cgd_plan_gemm) restricts it to small maps
 bool cgd_kconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
   if (!cgd_hconv_supported(ctx, p)) return false;
-  if ((long)cdiv(p.W, 16) * (p.H / KTH) * (p.M / (p.H * p.W)) * (p.N >> 5) > 65535L * 8) return false;
+  if (p.M % (p.H * p.W)) return false;                                   // whole images only
+  if (cgd_kconv_tiles_m(p) * (p.N >> 5) > (1L << 30)) return false;     // one workgroup per (pixel tile, 32-channel block) in grid.x
   return true;
 }
-
-long cgd_kconv_tiles_m(const GemmParams& p) { return (long)(p.M / (p.H * p.W)) * (p.H / KTH) * cdiv(p.W, 16); }
 
 int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   KConvParams p;
