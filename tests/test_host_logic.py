@@ -469,6 +469,16 @@ def test_guidance_call_sequence_with_a_recording_library(monkeypatch):
     guid2.current_timestep, guid2.coords_tape = 49, [[(0, 0, 32)] * 6]
     guid2.native(x, x.clone(), x.clone(), coef=None)
     assert [c[1][-2] for c in calls if c[0] == "cgd_cutouts_bwd"] == [0, 1]
+    # sharded run: the saturation term is a mean over the GLOBAL batch (cgd.py:214-218) while the kernel divides by the
+    # rank's own batch, so a rank holding B of shard[1] samples passes sat_scale * B / shard[1]; unsharded: the scale as given
+    for shard, want in ((None, 3.0), (([0, 1], 8), 3.0 * 2 / 8), (([5], 8), None)):
+        del calls[:]
+        guid3 = dg.ClipGuidance(ctx, unet, [vit], diffusion, [th.randn(1, 16)], [1.0], 6, sat_scale=3.0)
+        guid3.current_timestep, guid3.coords_tape, guid3.shard = 49, [[(0, 0, 32)] * 6], shard
+        xs = x if want is not None else x[:1]
+        guid3.native(xs, xs.clone(), xs.clone(), coef=None)
+        combine = [c[1] for c in calls if c[0] == "cgd_guidance_combine"][0]
+        assert combine[-2] == pytest.approx(want if want is not None else 3.0 * 1 / 8)
 
 
 def test_native_step_orders_noise_draw_before_guidance(monkeypatch):
