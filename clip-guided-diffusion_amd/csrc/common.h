@@ -71,6 +71,8 @@ struct cgd_ctx {
                        // parity-tested (tile code 512), but no faster than igemm 64x64 + split-K on the step (22.07 vs 22.07-22.11 ms,
                        // same-box A/B round 2), so off by default
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int thin_direct = 1;  // 1: the 3/6-channel INPUT-side convs (stem forward, head dgrad) run on the direct fp32 kernel of conv_thin.hip (one
+                        // write pass over the wide tensor); 0: the round-1 MFMA route (im2col + GEMM) (A/B knob CGD_THIN)
   int kconv_mode = 1, kconv_max_m = 1024, kconv_min_chunks = 4;  // weight-streaming variant of the halo conv (kconv.hip, tile code 516): for
                                           // convs of at most kconv_max_m pixels; split-K slices of at least kconv_min_chunks chunks (A/B knob
                                           // CGD_KCONV="<mode>[,<max pixels>[,<min chunks>]]")

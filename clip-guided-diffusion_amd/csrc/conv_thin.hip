@@ -176,6 +176,68 @@ __global__ __launch_bounds__(256) void thin_gather_kernel(const float* __restric
   for (int co = 0; co < COUT; ++co) y[(((long)b * COUT + co) * H + yy) * W + xx] = acc[co];
 }
 
+// ---- direct fp32 kernel for the thin INPUT side (round 3, default for conv_in) -------------------------------------------------
+// The MFMA route above spends 63-114 us per launch at 256x256 (plus the im2col and weight-padding helpers): a K = 32 / 64 GEMM whose
+// time is the generic kernel's epilogue and the scratch round trip, for 0.5-0.9 GFLOP.  The layer is bound by ONE write pass over the
+// wide tensor (67 MB at 256x256x256): the kernel below makes exactly that pass, with exact fp32 FMAs.  (The thin OUTPUT side, 256 ->
+// 3 / 6 channels, stays on the MFMA route: with one output pixel per thread every weight feeds a single FMA, so the weights would have
+// to come from scalar registers — more than a wavefront has for a 32-channel chunk — or from LDS at 2.3x the FMA time.)
+//
+// thin_in_direct: CIN (3 / 6) NCHW -> Cout NHWC (row stride ldy).  A workgroup owns a 4-row x 64-column pixel tile; the (4+2) x (64+2)
+// x CIN input patch sits in LDS; a lane owns 4 output channels (their 9*CIN x 4 weights in REGISTERS for the whole tile) and walks
+// the pixels of its wavefront's row: 9*CIN broadcast LDS reads + 36*CIN FMAs per pixel, one 16-byte store per lane = the pixel's
+// Cout channels in one coalesced 4*Cout-byte burst.
+template <int CIN>
+__global__ __launch_bounds__(256) void thin_in_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int ldy, int H, int W,
+                                                             int Cout) {
+  constexpr int KK = 9 * CIN, KH = 27, TW = 64, PWP = TW + 2 + 2;  // weights are staged 27 taps-x-channels at a time; patch row pitch
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [KH][Cout] transposed weight slab, then the patch [CIN][6][PWP]
+  float* wsm = sm;
+  float* patch = sm + KH * Cout;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * 4, x0 = blockIdx.x * TW;
+  const int Q = Cout >> 2;                      // lanes per pixel (<= 64)
+  const int ppi = Q <= 32 ? 64 / Q : 1;         // pixels per wavefront iteration
+  const int q = lane % Q, pl = lane / Q;
+  const float* xb = x + (long)b * CIN * H * W;
+  for (int i = tid; i < CIN * 6 * (TW + 2); i += 256) {
+    const int ci = i / (6 * (TW + 2)), rem = i - ci * 6 * (TW + 2), py = rem / (TW + 2), px = rem - py * (TW + 2);
+    const int sy = y0 + py - 1, sx = x0 + px - 1;
+    patch[(ci * 6 + py) * PWP + px] = ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) ? xb[((long)ci * H + sy) * W + sx] : 0.f;
+  }
+  ct_f32x4 wr[KK];
+#pragma unroll
+  for (int h = 0; h < KK; h += KH) {  // CIN = 6: two slabs through the same 27 x Cout floats of LDS
+    if (h) __syncthreads();
+    for (int i = tid; i < KH * Cout; i += 256) {
+      const int co = i / KH, k = i - co * KH;
+      wsm[k * Cout + co] = w[(long)co * KK + h + k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KH; ++k) wr[h + k] = *(const ct_f32x4*)&wsm[k * Cout + 4 * q];
+  }
+  const int yy = y0 + wave;
+  if (pl >= ppi || yy >= H) return;
+  const ct_f32x4 bv = bias ? *(const ct_f32x4*)(bias + 4 * q) : ct_f32x4{0.f, 0.f, 0.f, 0.f};
+  float* yrow = y + ((long)b * H + yy) * W * ldy + 4 * q;
+  const int xend = min(TW, W - x0);
+  for (int p = pl; p < xend; p += ppi) {
+    ct_f32x4 acc = bv;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const float v = patch[(ci * 6 + wave + ky) * PWP + p + kx];
+          acc += v * wr[(ky * 3 + kx) * CIN + ci];
+        }
+    *(ct_f32x4*)(yrow + (long)(x0 + p) * ldy) = acc;
+  }
+}
+
 }  // namespace
 
 int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int Bn, int H, int W, int Cin,
@@ -186,6 +248,18 @@ int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float
   const long npix = (long)Bn * H * W;
   if (Cin != 3 && Cin != 6) CGD_FAIL(ctx, "conv_in: Cin must be 3 or 6");
   CGD_TRY(cgd_flush_pending(ctx, s));  // the im2col scratch below lives in the split-K workspace
+  if (ctx->thin_direct && Cout / 4 <= 64 && (ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) {
+    const size_t sh2 = ((size_t)27 * Cout + (size_t)Cin * 6 * 68) * sizeof(float);
+    if (sh2 <= 64 * 1024) {
+      dim3 grid(cdiv(W, 64), cdiv(H, 4), Bn);
+      if (Cin == 3)
+        hipLaunchKernelGGL((thin_in_direct_kernel<3>), grid, dim3(256), sh2, s, x, w, bias, y, ldy, H, W, Cout);
+      else
+        hipLaunchKernelGGL((thin_in_direct_kernel<6>), grid, dim3(256), sh2, s, x, w, bias, y, ldy, H, W, Cout);
+      CGD_HIP(ctx, hipGetLastError());
+      return 0;
+    }
+  }
   {
     // MFMA route: scratch (im2col + padded weights) lives in the split-K workspace, so the GEMM must not split
     const int KP = Cin == 3 ? 32 : 64;

@@ -200,6 +200,26 @@ def check_conv(precision):
     return out
 
 
+def check_thin_in(precision=1):
+    """The 3 / 6-channel INPUT-side convs (UNet stem forward, head backward-to-input; conv_thin.hip): the direct fp32 kernel
+    (default) or, with CGD_THIN=0 in the environment of the context, the im2col + MFMA GEMM route — lanes-per-pixel counts 16, 24
+    (two pixels per wavefront pass, 16 idle lanes), 48 (one pixel, 16 idle lanes) and 64, widths that are not multiples of the
+    64-pixel tile, batch, with and without bias."""
+    from cgd_amd import ops
+    ctx = _ctx(precision)
+    out = []
+    for (Bn, H, W, Ci, Co, use_bias) in [(2, 16, 24, 3, 64, 1), (1, 40, 72, 3, 192, 1), (1, 64, 128, 6, 256, 0), (2, 8, 8, 6, 96, 1),
+                                         (1, 24, 200, 3, 256, 1), (1, 6, 66, 6, 128, 0)]:
+        x = th.randn(Bn, Ci, H, W, generator=g(9))
+        w = th.randn(Co, Ci, 3, 3, generator=g(10)) / math.sqrt(9 * Ci)
+        b = 0.3 * th.randn(Co, generator=g(11)) if use_bias else None
+        wf, _ = ops.pack_conv3x3(w)
+        got = ops.conv_in(ctx, x.to(DEV), wf.to(DEV), None if b is None else b.to(DEV), Co)
+        ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1).float()
+        out.append(rec(f"conv_in[p{precision}] B{Bn} {H}x{W} {Ci}->{Co}", got.permute(0, 3, 1, 2), ref))
+    return out
+
+
 def check_kconv(precision=1):
     """Weight-streaming halo conv kernel for the small maps (csrc/kconv.hip, tile code 516: K split among the wavefronts of a workgroup,
     cross-wavefront reduction through LDS) against a float64 convolution: 8-pixel-wide maps (half-filled tiles), 16x16 / 32x32 / non-

@@ -55,6 +55,15 @@ def test_unet_small_maps_on_the_previous_kernels(monkeypatch):
     _assert_all(pc.check_unet("cfg64", 1))
 
 
+@pytest.mark.parametrize("route", ["direct", "mfma"])
+def test_thin_input_side_convs(route, monkeypatch):
+    """conv_thin.hip: the direct fp32 kernel (default since round 3) and the previous im2col + MFMA GEMM route (CGD_THIN=0)."""
+    if route == "mfma":
+        monkeypatch.setenv("CGD_THIN", "0")
+    _assert_all(pc.check_thin_in(1))
+    _assert_all(pc.check_thin_in(0))
+
+
 def test_conv_winograd_variant():
     _assert_all(pc.check_wconv())
 
