@@ -71,6 +71,8 @@ struct cgd_ctx {
                        // parity-tested (tile code 512), but no faster than igemm 64x64 + split-K on the step (22.07 vs 22.07-22.11 ms,
                        // same-box A/B round 2), so off by default
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int gemv_mode = 1;    // 1: GEMMs with M <= 4 rows (the UNet's time / class embedding linears, 424 MB of FiLM projection weights per step) run
+                        // on the weight-streaming GEMV kernel of gemm.hip (tile code 517); 0: the MFMA GEMM + split-K reduce (A/B knob CGD_GEMV)
   int thin_direct = 1;  // 1: the 3/6-channel INPUT-side convs (stem forward, head dgrad) run on the direct fp32 kernel of conv_thin.hip (one
                         // write pass over the wide tensor); 0: the round-1 MFMA route (im2col + GEMM) (A/B knob CGD_THIN)
   int kconv_mode = 1, kconv_max_m = 1024, kconv_min_chunks = 4;  // weight-streaming variant of the halo conv (kconv.hip, tile code 516): for
@@ -180,7 +182,7 @@ struct GemmParams {
   int no_split = 0;  // 1: never split K automatically (the caller keeps data of its own in the workspace)
   float* ws = nullptr;
   int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel;
-                       // 515 Winograd halo conv kernel (wconv.hip); 516 weight-streaming halo conv kernel (kconv.hip)
+                       // 515 Winograd halo conv kernel (wconv.hip); 516 weight-streaming halo conv kernel (kconv.hip); 517 GEMV kernel (M <= 4)
   int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
   const void* Bwk = nullptr;  // conv only: Winograd F(2,3)-transformed weights in fragment order (cgd_pack_conv3x3_wino) for wconv.hip
@@ -190,6 +192,10 @@ struct GemmParams {
   float* act_out = nullptr;
   const float* act_in = nullptr;
   int ld_act = 0, act = 0;  // act: 1 SiLU, 2 QuickGELU
+  int skip_group = 0;  // hgemm2 in one slice only (cgd_gemm_fuses_act): rows come in groups of `skip_group`; the FIRST row of every group is
+                       // computed but not written and the others are written compactly (output row = row - group - 1).  The ViT's
+                       // patch-embedding dgrad: 16 x 50 token rows in, 16 x 49 patch rows out, as ONE weight GEMM instead of 16 batched
+                       // 49-row GEMMs on the generic kernel (92 -> 25 us)
   const float* gn_ab = nullptr;  // conv on the halo kernel only: apply SiLU(x * a + b) to the input while staging it; {a, b} pairs
                                  // [B][Cin][2] of the GroupNorm(+FiLM) that precedes the conv (kernels.h cgd_gn_ab)
   int defer = 0;       // 1: if the launch splits K, leave the slices in the workspace (ctx->pending): the caller guarantees that the

@@ -325,6 +325,69 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     }
 }
 
+// ---- weight-streaming GEMV for M <= 4 rows (round 3): C[m][n] = alpha * sum_k A[m][k] B[n][k] (+ bias[n]) (+ R[m][n]) ------------------
+// The UNet's time / class embedding path is three M = B linears per step, the last one onto ALL FiLM projections at once: N = 103,424
+// outputs x K = 1024 = 424 MB of fp32 weights for 0.2 GFLOP — a pure HBM stream.  On the MFMA GEMM it took 122 us (3.5 TB/s) plus a
+// split-K reduce; here a wavefront owns rows of B: 1 KiB coalesced loads (16 B per lane), four rows in flight (16 loads per lane),
+// exact fp32 FMAs against the A rows held in LDS, a 6-step butterfly per row.  No split-K, no workspace.
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                   float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ R,
+                                                   int ldr, int N, int K, float alpha) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [MR][K]
+  for (int i = threadIdx.x; i < MR * K; i += 256) xs[i] = A[(long)(i / K) * lda + (i % K)];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  constexpr int RB = 4;  // rows of B in flight per wavefront
+  for (long n0 = wave * RB; n0 < N; n0 += nwaves * RB) {
+    float acc[RB][MR];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
+    for (int k0 = 4 * lane; k0 < K; k0 += 256) {
+      float4 w[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const long n = n0 + r < N ? n0 + r : N - 1;  // clamped: the loads stay unconditional
+        w[r] = *(const float4*)(B + n * ldb + k0);
+      }
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const float4 xv = *(const float4*)&xs[m * K + k0];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r][m] += w[r].x * xv.x + w[r].y * xv.y + w[r].z * xv.z + w[r].w * xv.w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        float v = acc[r][m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[r][m] = v;
+      }
+    if (lane < RB * MR) {
+      const int r = lane / MR, m = lane % MR;
+      const long n = n0 + r;
+      if (n < N) {
+        float v = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+          for (int mm = 0; mm < MR; ++mm)
+            if (rr == r && mm == m) v = acc[rr][mm];
+        v *= alpha;
+        if (bias) v += bias[n];
+        if (R) v += R[(long)m * ldr + n];
+        C[(long)m * ldc + n] = v;
+      }
+    }
+  }
+}
+
 // C = alpha * sum_k ws[k] (+ bias) (+ R).  The slices of one output element are fetched EIGHT AT A TIME before they are summed
 // (in ascending k, so the result does not depend on the batching): with a plain `for k` loop the loads of a thread form a
 // dependent chain of L2 round trips (~0.5 us each) and the kernel, which moves only a few MB, took 5.8 us per launch on
@@ -413,12 +476,22 @@ static void tile_dims(int tile, int* bm, int* bn) {
 }
 
 // Kernel selection and split-K policy: pure host logic (no HIP calls), shared by the launcher and by cgd_op_plan (CPU tests).
-// kernel: 0 igemm_kernel (tile code in *tile_out), 1 hconv2_kernel, 2 hgemm_kernel; p.K / p.splitk are finalised in place.
+// kernel: 0 igemm_kernel (tile code in *tile_out), 1 halo conv kernels (512 / 515 / 516), 2 hgemm_kernel, 3 gemv_kernel (517); p.K / p.splitk
+// are finalised in place.
 int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) CGD_FAIL(ctx, "cgd_launch_gemm: K, lda, ldb must be multiples of 4");
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) CGD_FAIL(ctx, "cgd_launch_gemm: A/B must be 16-byte aligned");
   if (p.conv && (p.Cin % BK)) CGD_FAIL(ctx, "cgd_launch_gemm: conv Cin must be a multiple of 32");
   if (p.conv) p.K = 9 * p.Cin;
+  // weight-streaming GEMV (tile code 517, kernel 3): M <= 4 rows, one batch, 16-byte aligned K-contiguous operands
+  if ((p.force_tile == 517 || (!p.force_tile && ctx->gemv_mode)) && !p.conv && p.M <= 4 && p.nbatch == 1 && !(p.K & 3) && !(p.ldb & 3) &&
+      (size_t)p.M * p.K * sizeof(float) <= 48 * 1024 && !p.act_out && !p.act_in) {
+    p.splitk = 1;
+    *tile_out = 517;
+    *kernel_out = 3;
+    return 0;
+  }
+  if (p.force_tile == 517) CGD_FAIL(ctx, "cgd_launch_gemm: the GEMV kernel takes M <= 4, one batch, K and ldb multiples of 4");
   const int nkt = cdiv(p.K, BK);
   if (p.splitk <= 0) p.splitk = 1;
   int tile = p.force_tile;
@@ -575,12 +648,24 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   CGD_TRY(cgd_plan_gemm(ctx, p, &tile, &kernel));
   const bool use_h = kernel == 1, use_g = kernel == 2;
   if (p.gn_ab && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: only the halo conv kernel applies a GroupNorm on the fly (cgd_conv_uses_hconv)");
+  if (p.skip_group && !(use_g && p.splitk == 1)) CGD_FAIL(ctx, "cgd_launch_gemm: skip_group needs the weight GEMM kernel in one slice (cgd_gemm_fuses_act)");
   if ((p.act_out || p.act_in) && !(use_g && p.splitk == 1 && ctx->hgemm_var != 0))
     CGD_FAIL(ctx, "cgd_launch_gemm: only hgemm2 in one slice fuses an activation into its epilogue (cgd_gemm_fuses_act)");
   if (p.splitk > 1) p.ws = ctx->ws;
   ProfRec pr;
   CGD_TRY(cgd_prof_begin(ctx, &pr, use_h ? (tile == 515 ? CGD_PROF_WCONV : (tile == 516 ? CGD_PROF_KCONV : CGD_PROF_HCONV)) : CGD_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.nbatch, s));
-  if (use_h) {
+  if (kernel == 3) {
+    const int blocks = (int)std::min<long>(std::max<long>(cdiv(p.N, 16), 1), 4L * ctx->num_cu);
+    const size_t sh = (size_t)p.M * p.K * sizeof(float);
+#define GV_LAUNCH(MR_) hipLaunchKernelGGL((gemv_kernel<MR_>), dim3(blocks), dim3(256), sh, s, p.A, p.lda, p.B, p.ldb, p.C, p.ldc, p.bias, p.R, p.ldr, p.N, p.K, p.alpha)
+    switch (p.M) {
+      case 1: GV_LAUNCH(1); break;
+      case 2: GV_LAUNCH(2); break;
+      case 3: GV_LAUNCH(3); break;
+      default: GV_LAUNCH(4); break;
+    }
+#undef GV_LAUNCH
+  } else if (use_h) {
     if (tile == 515)
       CGD_TRY(cgd_launch_wconv(ctx, p, s));
     else if (tile == 516)
@@ -633,6 +718,8 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   long wg;
   if (kernel == 1) {
     wg = tile == 516 ? cgd_kconv_tiles_m(p) * (p.N >> 5) : (tile == 515 ? cgd_wconv_tiles_m(&ctx, p) : cgd_hconv_tiles_m(&ctx, p)) * cdiv(p.N, 128);
+  } else if (kernel == 3) {
+    wg = std::min<long>(std::max<long>(cdiv(p.N, 16), 1), 4L * ctx.num_cu);
   } else if (kernel == 2) {
     wg = cgd_hgemm_tiles(&ctx, p);
   } else {

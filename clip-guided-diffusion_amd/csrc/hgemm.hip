@@ -32,6 +32,7 @@ struct HGemmParams {
   float* act_out;       // hgemm2 epilogue: C2 = act(C) (GemmParams::act_out)
   const float* act_in;  // hgemm2 epilogue: C = (...) * act'(U)
   int ld_act, act;
+  int skip_group;  // hgemm2, one slice: drop the first row of every group of this many rows, write the rest compactly (GemmParams)
   int nmajor;  // tile order within the XCD-contiguous runs: 0 = M-tile major (an XCD owns row panels and streams all weights),
                // 1 = N-tile major (an XCD owns weight column panels, read from HBM once and kept in its 4 MB L2; the small
                // activation matrix is what every XCD re-reads): chosen when the weights are the larger operand (N >= M)
@@ -470,8 +471,13 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const long row = m0 + i * 32 + l31;
+    long row = m0 + i * 32 + l31;
     if (row >= p.M) continue;
+    if (p.skip_group) {  // (no residual / activation operand with this option: the launcher checks)
+      const long grp = row / p.skip_group;
+      if (row == grp * p.skip_group) continue;
+      row -= grp + 1;
+    }
     f32x4 rv[4];
     if (Rg) {
 #pragma unroll
@@ -597,11 +603,14 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.K = g.K; p.splitk = g.splitk; p.alpha = g.alpha;
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && g.N >= g.M)) ? 1 : 0;
   p.act_out = g.act_out; p.act_in = g.act_in; p.ld_act = g.ld_act; p.act = g.act;
+  p.skip_group = g.skip_group;
   const int tm = cgd_hgemm_tile_m(ctx, g);
   dim3 grid(cdiv(g.M, tm) * cdiv(g.N, GN), 1, g.splitk > 1 ? g.splitk : 1);
   const bool x3 = ctx->precision == CGD_PREC_BF16X3;
   // hgemm2 addresses A with 32-bit element offsets
   const bool v2 = ctx->hgemm_var != 0 && (long)g.M * g.lda < (1L << 31);
+  if (g.skip_group && (!v2 || g.splitk > 1 || g.R || g.act_out || g.act_in))
+    CGD_FAIL(ctx, "hgemm: skip_group needs hgemm2 in one slice without residual / activation operands");
 #define HG_ARGS grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p
   if (!v2) {
     if (x3) hipLaunchKernelGGL((hgemm_kernel<1>), HG_ARGS); else hipLaunchKernelGGL((hgemm_kernel<2>), HG_ARGS);

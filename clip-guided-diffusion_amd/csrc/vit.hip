@@ -218,10 +218,20 @@ int ViT::dgrad(const float* demb, float* dimg, hipStream_t s) {
     CGD_TRY(ensure(dcols, (size_t)N * g * g * PP));
     dc = dcols.p;
   }
-  GemmParams p;
-  p.A = dtok.p + W; p.lda = W; p.B = convwT; p.ldb = W; p.C = dc; p.ldc = PP; p.M = g * g; p.N = PP; p.K = W;
-  p.nbatch = N; p.bdiv = 1; p.sA1 = (long)L * W; p.sC1 = (long)g * g * PP;
-  CGD_TRY(cgd_launch_gemm(ctx, p, s));
+  // one weight GEMM over all N * L token rows whose epilogue drops the class-token row of every image (GemmParams::skip_group) where
+  // the weight GEMM kernel takes the shape in one slice; otherwise N batched (L - 1)-row GEMMs on the generic kernel (patch 14: 588
+  // columns are not a multiple of 32)
+  GemmParams one = lin(dtok.p, W, convwT, W, dc, PP, nullptr, nullptr, 0, rows, PP);
+  one.no_split = 1;
+  if (cgd_gemm_fuses_act(ctx, one)) {
+    one.skip_group = L;
+    CGD_TRY(cgd_launch_gemm(ctx, one, s));
+  } else {
+    GemmParams p;
+    p.A = dtok.p + W; p.lda = W; p.B = convwT; p.ldb = W; p.C = dc; p.ldc = PP; p.M = g * g; p.N = PP; p.K = W;
+    p.nbatch = N; p.bdiv = 1; p.sA1 = (long)L * W; p.sC1 = (long)g * g * PP;
+    CGD_TRY(cgd_launch_gemm(ctx, p, s));
+  }
   if (layout == 0) CGD_TRY(cgd_launch_unpatchify(ctx, dcols.p, dimg, N, cfg.resolution, cfg.patch, s));
   return 0;
 }

@@ -98,6 +98,8 @@ def check_gemm(precision):
     out = []
     cases = [(300, 200, 128, 0, 1), (1, 1024, 256, 0, 1), (64, 1024, 4608, 0, 1), (800, 2304, 768, 0, 1), (130, 70, 52, 64, 1),
              (256, 256, 512, 128, 1), (256, 192, 1024, 64, 4), (4096, 256, 288, 0, 1)]
+    # weight-streaming GEMV kernel (tile code 517; automatic for M <= 4): 1-4 rows, K not a multiple of the 256-wide pass, ragged N
+    cases += [(1, 1024, 256, 517, 1), (2, 2048, 1024, 517, 1), (3, 1000, 260, 517, 1), (4, 37, 1024, 517, 1), (2, 513, 768, 0, 1)]
     if precision != 0:  # weight GEMM kernel (hgemm.hip, tile code 513): ragged M, partial N tile, split-K, single chunk
         cases += [(800, 768, 768, 513, 1), (200, 96, 256, 513, 2), (128, 160, 64, 513, 1), (1000, 2304, 768, 513, 1),
                   (70, 32, 3072, 513, 5), (784, 768, 3072, 513, 0)]
