@@ -73,8 +73,9 @@ struct cgd_ctx {
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
   int gemv_mode = 1;    // 1: GEMMs with M <= 4 rows (the UNet's time / class embedding linears, 424 MB of FiLM projection weights per step) run
                         // on the weight-streaming GEMV kernel of gemm.hip (tile code 517); 0: the MFMA GEMM + split-K reduce (A/B knob CGD_GEMV)
-  int thin_direct = 1;  // 1: the 3/6-channel INPUT-side convs (stem forward, head dgrad) run on the direct fp32 kernel of conv_thin.hip (one
-                        // write pass over the wide tensor); 0: the round-1 MFMA route (im2col + GEMM) (A/B knob CGD_THIN)
+  int thin_direct = 1;  // 1: the 3-channel INPUT-side conv (UNet stem forward) runs on the direct fp32 kernel of conv_thin.hip (one write pass
+                        // over the wide tensor); 2: the 6-channel one (head dgrad) too; 0: the round-1 MFMA route (im2col + GEMM) for both
+                        // (A/B knob CGD_THIN)
   int kconv_mode = 1, kconv_max_m = 1024, kconv_min_chunks = 4;  // weight-streaming variant of the halo conv (kconv.hip, tile code 516): for
                                           // convs of at most kconv_max_m pixels; split-K slices of at least kconv_min_chunks chunks (A/B knob
                                           // CGD_KCONV="<mode>[,<max pixels>[,<min chunks>]]")

@@ -248,7 +248,9 @@ int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float
   const long npix = (long)Bn * H * W;
   if (Cin != 3 && Cin != 6) CGD_FAIL(ctx, "conv_in: Cin must be 3 or 6");
   CGD_TRY(cgd_flush_pending(ctx, s));  // the im2col scratch below lives in the split-K workspace
-  if (ctx->thin_direct && Cout / 4 <= 64 && (ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) {
+  // measured at 256x256 (profiles/r3_thin_and_cutout_kernels.txt): 3 -> 256 channels 27.8 us direct vs 35.8 us (im2col + padding + GEMM); 6 -> 256
+  // 47.3 us direct vs 40.9 us: the direct kernel is the default for Cin = 3 only (CGD_THIN=2 forces it for both, 0 disables it)
+  if (ctx->thin_direct && (Cin == 3 || ctx->thin_direct >= 2) && Cout / 4 <= 64 && (ldy & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) {
     const size_t sh2 = ((size_t)27 * Cout + (size_t)Cin * 6 * 68) * sizeof(float);
     if (sh2 <= 64 * 1024) {
       dim3 grid(cdiv(W, 64), cdiv(H, 4), Bn);

@@ -10,6 +10,8 @@
 // All tensors here are NCHW fp32 (B,3,H,W) / (B,6,H,W): the sampler's public layout.  HBM-trivial sizes.
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
+
 #include "guidance.h"
 
 namespace {
@@ -17,82 +19,95 @@ namespace {
 __constant__ float kClipMean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
 __constant__ float kClipStd[3] = {0.26862954f, 0.26130258f, 0.27577711f};
 
+// Exact unsigned division by a runtime-uniform divisor without the ~30-instruction v_div sequence (the two cutout kernels spent most of
+// their 26 / 55 us on 64-bit index decomposition and on the bin arithmetic of adaptive_avg_pool2d): q = umulhi(n, ceil(2^32 / d)) is
+// floor(n / d) whenever n * d < 2^32 — every use below stays under 2^28 (pixel indices < 2^18, bin numerators < 2^17, divisors <= 2^10).
+struct FastDiv {
+  unsigned m, d;
+  __host__ __device__ explicit FastDiv(unsigned dd = 1) : m(dd > 1 ? 0xFFFFFFFFu / dd + 1u : 0u), d(dd) {}
+  __device__ __forceinline__ unsigned div(unsigned n) const { return d > 1 ? __umulhi(n, m) : n; }
+  __device__ __forceinline__ unsigned mod(unsigned n) const { return n - div(n) * d; }
+};
+
+// grid.y = plane (cut, b, c); grid.x covers the cs * cs outputs of the plane
 __global__ __launch_bounds__(256) void cutouts_fwd_kernel(const float* __restrict__ x, const int* __restrict__ coords,
                                                           float* __restrict__ out, int B, int H, int W, int cutn, int cs, int layout,
-                                                          int P) {
-  const long total = (long)cutn * B * 3 * cs * cs;
+                                                          int P, FastDiv dcs, FastDiv dP) {
+  const unsigned plane = blockIdx.y, c = plane % 3u, nb = plane / 3u, b = nb % (unsigned)B, cut = nb / (unsigned)B;  // scalar: per block
+  const unsigned pix = blockIdx.x * 256u + threadIdx.x;
+  if (pix >= (unsigned)(cs * cs)) return;
+  const unsigned i = dcs.div(pix), j = pix - i * cs;
   const int g = layout ? cs / P : 0;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % cs);
-    long t = idx / cs;
-    const int i = (int)(t % cs);
-    t /= cs;
-    const int c = (int)(t % 3);
-    t /= 3;
-    const int b = (int)(t % B), cut = (int)(t / B);
-    const int oy = coords[cut * 4 + 0], ox = coords[cut * 4 + 1], h = coords[cut * 4 + 2], w = coords[cut * 4 + 3];
-    const int ys = (i * h) / cs, ye = ((i + 1) * h + cs - 1) / cs;
-    const int xs = (j * w) / cs, xe = ((j + 1) * w + cs - 1) / cs;
-    const float* xp = x + ((long)b * 3 + c) * H * W;
-    float s = 0.f;
-    for (int yy = ys; yy < ye; ++yy)
-      for (int xx = xs; xx < xe; ++xx) s += xp[(long)(oy + yy) * W + ox + xx];
-    // mean of (x+1)/2 over the bin, then CLIP normalisation
-    const float m = (s / (float)((ye - ys) * (xe - xs)) + 1.f) * 0.5f;
-    const float v = (m - kClipMean[c]) / kClipStd[c];
-    long o = idx;
-    if (layout) {
-      const long n = (long)cut * B + b;
-      o = (n * g * g + (i / P) * g + (j / P)) * (3L * P * P) + (long)c * P * P + (i % P) * P + (j % P);
-    }
-    out[o] = v;
+  const int oy = coords[cut * 4 + 0], ox = coords[cut * 4 + 1], h = coords[cut * 4 + 2], w = coords[cut * 4 + 3];
+  const int ys = (int)dcs.div(i * h), ye = (int)dcs.div((i + 1) * h + cs - 1);
+  const int xs = (int)dcs.div(j * w), xe = (int)dcs.div((j + 1) * w + cs - 1);
+  const float* xp = x + ((long)b * 3 + c) * H * W;
+  float s = 0.f;
+  for (int yy = ys; yy < ye; ++yy)
+    for (int xx = xs; xx < xe; ++xx) s += xp[(long)(oy + yy) * W + ox + xx];
+  // mean of (x+1)/2 over the bin, then CLIP normalisation
+  const float m = (s / (float)((ye - ys) * (xe - xs)) + 1.f) * 0.5f;
+  const float v = (m - kClipMean[c]) / kClipStd[c];
+  long o = (long)plane * cs * cs + pix;
+  if (layout) {
+    const unsigned ip = dP.div(i), jp = dP.div(j);
+    o = ((long)nb * g * g + ip * g + jp) * (3L * P * P) + (long)c * P * P + (i - ip * P) * P + (j - jp * P);
   }
+  out[o] = v;
 }
 
-constexpr int CB_SUB = 8;  // lanes per pixel in cutouts_bwd_kernel
+constexpr int CB_SUB = 8;     // lanes per pixel in cutouts_bwd_kernel
+constexpr int CB_MAXCUT = 256;  // cutouts whose division constants fit the kernel's LDS table
+// grid.y = plane (b, c); grid.x covers H * W pixels x CB_SUB lanes, each lane walking every CB_SUB-th cutout; fixed 3-step butterfly
 __global__ __launch_bounds__(256) void cutouts_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ coords,
                                                           float* __restrict__ G, int B, int H, int W, int cutn, int cs, int layout,
-                                                          int P, int accumulate) {
-  // CB_SUB lanes per pixel, each walking every CB_SUB-th cutout (the per-cutout chain — box test, bin arithmetic, 1-4 dependent
-  // loads — is pure latency: sequentially over 16 cutouts it took 55 us at 256x256), summed with a fixed 3-step butterfly
-  const long total = (long)B * 3 * H * W;
+                                                          int P, int accumulate, FastDiv dcs, FastDiv dP, FastDiv dW) {
+  __shared__ unsigned mh[CB_MAXCUT], mw[CB_MAXCUT];
+  for (int k = threadIdx.x; k < cutn; k += 256) {
+    mh[k] = FastDiv((unsigned)coords[k * 4 + 2]).m;
+    mw[k] = FastDiv((unsigned)coords[k * 4 + 3]).m;
+  }
+  __syncthreads();
+  const unsigned plane = blockIdx.y, c = plane % 3u, b = plane / 3u;
   const int g = layout ? cs / P : 0;
   const int sub = threadIdx.x & (CB_SUB - 1);
-  const long nthr = (long)gridDim.x * blockDim.x / CB_SUB;
-  const long tend = (total + nthr - 1) / nthr * nthr;  // whole groups of lanes stay in the loop together (shuffles below)
-  for (long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) / CB_SUB; idx < tend; idx += nthr) {
-    const bool live = idx < total;
-    const long ii = live ? idx : total - 1;
-    const int x = (int)(ii % W);
-    long t = ii / W;
-    const int y = (int)(t % H);
-    t /= H;
-    const int c = (int)(t % 3), b = (int)(t / 3);
-    float acc = 0.f;
-    for (int cut = sub; cut < cutn; cut += CB_SUB) {
-      const int oy = coords[cut * 4 + 0], ox = coords[cut * 4 + 1], h = coords[cut * 4 + 2], w = coords[cut * 4 + 3];
-      const int yy = y - oy, xx = x - ox;
-      if ((unsigned)yy >= (unsigned)h || (unsigned)xx >= (unsigned)w) continue;
-      const int i0 = (yy * cs) / h, i1 = min(cs - 1, ((yy + 1) * cs - 1) / h);
-      const int j0 = (xx * cs) / w, j1 = min(cs - 1, ((xx + 1) * cs - 1) / w);
-      const long n = (long)cut * B + b;
-      for (int i = i0; i <= i1; ++i) {
-        const int bh = ((i + 1) * h + cs - 1) / cs - (i * h) / cs;
-        for (int j = j0; j <= j1; ++j) {
-          const int bw = ((j + 1) * w + cs - 1) / cs - (j * w) / cs;
-          long o;
-          if (layout)
-            o = (n * g * g + (i / P) * g + (j / P)) * (3L * P * P) + (long)c * P * P + (i % P) * P + (j % P);
-          else
-            o = ((n * 3 + c) * cs + i) * cs + j;
-          acc += dout[o] / (float)(bh * bw);
+  const unsigned pix = (blockIdx.x * 256u + threadIdx.x) / CB_SUB;
+  const bool live = pix < (unsigned)(H * W);
+  const unsigned pp = live ? pix : 0u;
+  const int y = (int)dW.div(pp), x = (int)(pp - (unsigned)y * W);
+  float acc = 0.f;
+  for (int cut = sub; cut < cutn; cut += CB_SUB) {
+    const int oy = coords[cut * 4 + 0], ox = coords[cut * 4 + 1], h = coords[cut * 4 + 2], w = coords[cut * 4 + 3];
+    const int yy = y - oy, xx = x - ox;
+    if ((unsigned)yy >= (unsigned)h || (unsigned)xx >= (unsigned)w) continue;
+    const unsigned mhh = mh[cut], mww = mw[cut];
+    auto divh = [&](unsigned n) { return h > 1 ? __umulhi(n, mhh) : n; };
+    auto divw = [&](unsigned n) { return w > 1 ? __umulhi(n, mww) : n; };
+    const int i0 = (int)divh(yy * cs), i1 = min(cs - 1, (int)divh((yy + 1) * cs - 1));
+    const int j0 = (int)divw(xx * cs), j1 = min(cs - 1, (int)divw((xx + 1) * cs - 1));
+    const long n = (long)cut * B + b;
+    for (int i = i0; i <= i1; ++i) {
+      const int bh = (int)dcs.div((i + 1) * h + cs - 1) - (int)dcs.div(i * h);
+      const unsigned ip = dP.div(i);
+      for (int j = j0; j <= j1; ++j) {
+        const int bw = (int)dcs.div((j + 1) * w + cs - 1) - (int)dcs.div(j * w);
+        long o;
+        if (layout) {
+          const unsigned jp = dP.div(j);
+          o = (n * g * g + ip * g + jp) * (3L * P * P) + (long)c * P * P + (i - ip * P) * P + (j - jp * P);
+        } else {
+          o = ((n * 3 + c) * cs + i) * cs + j;
         }
+        acc += dout[o] / (float)(bh * bw);
       }
     }
+  }
 #pragma unroll
-    for (int o = 1; o < CB_SUB; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    acc *= 0.5f / kClipStd[c];
-    if (live && sub == 0) G[idx] = accumulate ? G[idx] + acc : acc;
+  for (int o = 1; o < CB_SUB; o <<= 1) acc += __shfl_xor(acc, o, 64);
+  acc *= 0.5f / kClipStd[c];
+  if (live && sub == 0) {
+    const long idx = (long)plane * H * W + pix;
+    G[idx] = accumulate ? G[idx] + acc : acc;
   }
 }
 
@@ -327,8 +342,12 @@ inline int grid_for(long n, int cap = 1024) { return (int)std::min<long>(cdiv(n,
 int cgd_launch_cutouts_fwd(cgd_ctx* ctx, const float* x_in, const int* coords, float* out, int B, int H, int W, int cutn, int cs,
                            int layout, int P, hipStream_t s) {
   if (layout && (P <= 0 || cs % P)) CGD_FAIL(ctx, "cutouts: cut size must be a multiple of the patch size");
-  hipLaunchKernelGGL(cutouts_fwd_kernel, dim3(grid_for((long)cutn * B * 3 * cs * cs, 4096)), dim3(256), 0, s, x_in, coords, out, B, H,
-                     W, cutn, cs, layout, P);
+  // FastDiv is exact while numerator * divisor < 2^32: bin numerators (cs + 1) * max(H, W) by cs, pixel index cs^2 by cs
+  const long mx = std::max(H, W);
+  if (cs <= 0 || (long)(cs + 1) * mx * cs >= (1L << 32) || (long)cs * cs * cs >= (1L << 32) || (long)cutn * B * 3 > 65535)
+    CGD_FAIL(ctx, "cutouts: size out of range");
+  hipLaunchKernelGGL(cutouts_fwd_kernel, dim3(cdiv((long)cs * cs, 256), cutn * B * 3), dim3(256), 0, s, x_in, coords, out, B, H, W, cutn, cs,
+                     layout, P, FastDiv((unsigned)cs), FastDiv((unsigned)(layout ? P : 1)));
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -336,8 +355,13 @@ int cgd_launch_cutouts_fwd(cgd_ctx* ctx, const float* x_in, const int* coords, f
 int cgd_launch_cutouts_bwd(cgd_ctx* ctx, const float* dout, const int* coords, float* G, int B, int H, int W, int cutn, int cs,
                            int layout, int P, int accumulate, hipStream_t s) {
   if (layout && (P <= 0 || cs % P)) CGD_FAIL(ctx, "cutouts: cut size must be a multiple of the patch size");
-  hipLaunchKernelGGL(cutouts_bwd_kernel, dim3(grid_for((long)B * 3 * H * W * CB_SUB, 8192)), dim3(256), 0, s, dout, coords, G, B, H, W, cutn,
-                     cs, layout, P, accumulate);
+  // FastDiv is exact while numerator * divisor < 2^32: (crop extent * cs) by the extent, (cs + 1) * extent by cs, pixel index by W
+  const long mx = std::max(H, W);
+  if (cs <= 0 || mx * mx * cs >= (1L << 32) || (long)(cs + 1) * mx * cs >= (1L << 32) || (long)H * W * W >= (1L << 32) || cutn > CB_MAXCUT ||
+      (long)B * 3 > 65535)
+    CGD_FAIL(ctx, "cutouts: size out of range");
+  hipLaunchKernelGGL(cutouts_bwd_kernel, dim3(cdiv((long)H * W * CB_SUB, 256), B * 3), dim3(256), 0, s, dout, coords, G, B, H, W, cutn,
+                     cs, layout, P, accumulate, FastDiv((unsigned)cs), FastDiv((unsigned)(layout ? P : 1)), FastDiv((unsigned)W));
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }

@@ -55,11 +55,12 @@ def test_unet_small_maps_on_the_previous_kernels(monkeypatch):
     _assert_all(pc.check_unet("cfg64", 1))
 
 
-@pytest.mark.parametrize("route", ["direct", "mfma"])
+@pytest.mark.parametrize("route", ["default", "direct", "mfma"])
 def test_thin_input_side_convs(route, monkeypatch):
-    """conv_thin.hip: the direct fp32 kernel (default since round 3) and the previous im2col + MFMA GEMM route (CGD_THIN=0)."""
-    if route == "mfma":
-        monkeypatch.setenv("CGD_THIN", "0")
+    """conv_thin.hip: default routing (direct fp32 kernel for 3 input channels, im2col + MFMA GEMM for 6), the direct kernel for both
+    (CGD_THIN=2) and the MFMA route for both (CGD_THIN=0)."""
+    if route != "default":
+        monkeypatch.setenv("CGD_THIN", "2" if route == "direct" else "0")
     _assert_all(pc.check_thin_in(1))
     _assert_all(pc.check_thin_in(0))
 
