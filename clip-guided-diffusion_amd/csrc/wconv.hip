@@ -58,6 +58,20 @@ __host__ __device__ constexpr int w_proc_task(int q, int piece) {
   return s == 10 ? 0 : s == 14 ? 1 : s == 21 ? 2 : -1;
 }
 
+// per-wavefront timeline for benchmarks/ubench/wconv_stamps.hip (which includes this file with CGD_WCONV_STAMPS defined); the library
+// build never defines it: W_STAMP expands to nothing there
+#ifdef CGD_WCONV_STAMPS
+__device__ unsigned long long* g_wstamps;  // [workgroup][wavefront][32]: 0 entry, 1 chunk 0 staged, 2 + c chunk c done, 30 stores issued, 31 HW id
+#define W_STAMP(I)                                                                                   \
+  do {                                                                                               \
+    if (lane == 0) g_wstamps[((long)blockIdx.x * 4 + wave) * 32 + (I)] = wall_clock64();            \
+  } while (0)
+#else
+#define W_STAMP(I) \
+  do {             \
+  } while (0)
+#endif
+
 struct WConvParams {
   int lda, ldc, ldr;
   int M, N, H, W, Cin, ups;
@@ -91,6 +105,7 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * WPLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
+  W_STAMP(0);
 
   const int ntn = (p.N + 127) >> 7;
   int bid = blockIdx.x;
@@ -237,6 +252,7 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
     }
   }
   __syncthreads();
+  W_STAMP(1);
   for (int c = 0; c < nchunk; ++c) {
     const bool more = c + 1 < nchunk;
     const int cn = more ? c + 1 : c;  // the last chunk re-stages itself into the idle buffer: no branch in the scheduled region
@@ -279,6 +295,7 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // patch c consumed by every wavefront, patch c + 1 written
+    W_STAMP(2 + (c < 27 ? c : 27));
   }
 #undef W_TASK_LOAD
 #undef W_GN_LOAD
@@ -318,6 +335,12 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
       *(wf32x4*)&Cg[(m_even + 1) * p.ldc + col] = oo;
     }
   }
+  W_STAMP(30);
+#ifdef CGD_WCONV_STAMPS
+  if (lane == 0)
+    g_wstamps[((long)blockIdx.x * 4 + wave) * 32 + 31] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID | HW_ID
+#endif
 }
 
 // w: torch conv weight [Co][Ci][3][3].  dgrad = 0: g[kx] = w[n][k][ky][kx]; dgrad = 1: g[kx] = w[k][n][2-ky][2-kx].
