@@ -3,9 +3,11 @@
 // wall_clock64() (the 100 MHz constant clock) at entry, after chunk 0 is staged, after every chunk and after the epilogue's stores are
 // issued, plus XCC_ID / HW_ID, so that the workgroups a CU runs back to back can be lined up.  One extra 8-byte store per chunk.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include wconv_stamps.hip -o wconv_stamps
-// Usage: wconv_stamps H Cin N [gn 0|1] [nb 4|2] [reps] [csv]
+// Usage: wconv_stamps H Cin N [gn 0|1] [nb 4|2] [reps] [csv|-] [unused] [residual 0|1]
 #define CGD_WCONV_STAMPS 1
 #include "../../clip-guided-diffusion_amd/csrc/wconv.hip"
+
+#include <string.h>
 
 #include <algorithm>
 #include <map>
@@ -30,8 +32,9 @@ static double vmin(const std::vector<double>& v) { return v.empty() ? 0.0 : *std
 static double vmax(const std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); }
 
 template <bool GN, int NB>
-static void launch(dim3 grid, const float* A, const uint4* B, float* C, const float* bias, const float* gn, const WConvParams& p) {
-  hipLaunchKernelGGL((wconv_kernel<GN, NB>), grid, dim3(256), 0, 0, A, B, C, bias, (const float*)nullptr, gn, p);
+static void launch(dim3 grid, const float* A, const uint4* B, float* C, const float* bias, const float* R, const float* gn, const WConvParams& p, int lep) {
+  (void)lep;
+  hipLaunchKernelGGL((wconv_kernel<GN, NB>), grid, dim3(256), 0, 0, A, B, C, bias, R, gn, p);
 }
 
 int main(int argc, char** argv) {
@@ -41,7 +44,8 @@ int main(int argc, char** argv) {
   }
   const int H = atoi(argv[1]), Cin = atoi(argv[2]), N = atoi(argv[3]);
   const int gn = argc > 4 ? atoi(argv[4]) : 0, nb = argc > 5 ? atoi(argv[5]) : 4, reps = argc > 6 ? atoi(argv[6]) : 10;
-  const char* csv = argc > 7 ? argv[7] : nullptr;
+  const char* csv = argc > 7 && strcmp(argv[7], "-") ? argv[7] : nullptr;
+  const int lep = argc > 8 ? atoi(argv[8]) : 0, res = argc > 9 ? atoi(argv[9]) : 0;
   const int W = H, TR = 4 * nb;
   if ((H % TR) || (W & 15) || (Cin & 31) || (N & 127) || (nb != 4 && nb != 2)) {
     fprintf(stderr, "unsupported shape\n");
@@ -59,13 +63,17 @@ int main(int argc, char** argv) {
     hab[2 * c] = 0.5f + 0.5f * fabsf(nd(rng));
     hab[2 * c + 1] = 0.5f * nd(rng);
   }
-  float *dA, *dW, *dB, *dC, *dbias, *dab;
+  float *dA, *dW, *dB, *dC, *dbias, *dab, *dR = nullptr;
   CK(hipMalloc(&dA, hA.size() * 4));
   CK(hipMalloc(&dW, hW.size() * 4));
   CK(hipMalloc(&dB, (size_t)N * Cin * 12 * 4));
   CK(hipMalloc(&dC, (size_t)M * N * 4));
   CK(hipMalloc(&dbias, hb.size() * 4));
   CK(hipMalloc(&dab, hab.size() * 4));
+  if (res) {
+    CK(hipMalloc(&dR, (size_t)M * N * 4));
+    CK(hipMemset(dR, 0, (size_t)M * N * 4));
+  }
   CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dbias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
@@ -74,7 +82,7 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 
   WConvParams p;
-  p.lda = Cin; p.ldc = N; p.ldr = 0;
+  p.lda = Cin; p.ldc = N; p.ldr = res ? N : 0;
   p.M = (int)M; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ups = 0; p.alpha = 1.f;
   p.nmajor = 12L * N >= M ? 1 : 0;
   const int tiles_m = (H / TR) * (W >> 4), nwg = tiles_m * (N >> 7), nchunk = Cin >> 5;
@@ -84,9 +92,9 @@ int main(int argc, char** argv) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), &dst, sizeof(dst)));
   auto go = [&]() {
     if (gn) {
-      if (nb == 4) launch<true, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dab, p); else launch<true, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dab, p);
+      if (nb == 4) launch<true, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep); else launch<true, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep);
     } else {
-      if (nb == 4) launch<false, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, nullptr, p); else launch<false, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, nullptr, p);
+      if (nb == 4) launch<false, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, nullptr, p, lep); else launch<false, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, nullptr, p, lep);
     }
   };
   hipEvent_t e0, e1;
@@ -142,8 +150,8 @@ int main(int argc, char** argv) {
     starts.push_back(x.start);
     ends.push_back(x.end);
   }
-  printf("wconv_kernel<%s, %d>  %dx%d  %d -> %d : %d workgroups, %d chunks; %.1f us per launch (events over %d launches); clock %d kHz\n",
-         gn ? "true" : "false", nb, H, W, Cin, N, nwg, nchunk, ms * 1e3 / reps, reps, khz);
+  printf("wconv_kernel<%s, %d>%s  %dx%d  %d -> %d : %d workgroups, %d chunks; %.1f us per launch (events over %d launches); clock %d kHz\n",
+         gn ? "true" : "false", nb, res ? " + residual" : "", H, W, Cin, N, nwg, nchunk, ms * 1e3 / reps, reps, khz);
   printf("last launch, us from the first wavefront's entry: last entry %.1f, first exit %.1f, last exit %.1f\n", vmax(starts), vmin(ends), vmax(ends));
   printf("per workgroup   min / median / max [us]\n");
   printf("  entry -> chunk 0 staged   %7.2f %7.2f %7.2f\n", vmin(pro), med(pro), vmax(pro));

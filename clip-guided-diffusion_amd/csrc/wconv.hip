@@ -24,6 +24,8 @@
 //     transforms, splits and writes 8 x 8 B; 5 such tasks per thread and chunk (18 rows x 8 pairs x 8 channel quads = 1152
 //     tasks; the last 128 slots repeat rows 16-17: same values to the same addresses), spread over the 24 steps.
 //   * weights: [N/32][Cin/32][ky 3][position 4][kstep 2][plane 2][lane 64][8 bf16], 8-deep register ring.
+//   * epilogue: the output tile goes through LDS once (the patch buffers are free by then) so that every store instruction writes whole
+//     128-byte lines, and the residual is read the same way.
 //   * NB = 2: the same kernel on 8 x 16-pixel tiles (2 column blocks, 128 accumulators, 10 patch rows = 81,920 B of LDS, 3 staging
 //     tasks, 6 MFMAs per step) for maps whose 16-row tiles would not give every CU a workgroup (the 128 x 128 level: 1.22x the
 //     direct kernel instead of 0.9x, profiles/r2_wconv_microbench.txt).
@@ -312,27 +314,62 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   //      channel (r & 3) + 8 (r >> 2) + 4 hh: accumulator quad g holds channels 8g + 4hh .. + 3 of the lane's pair.
   const int cb0 = nb0 * 32;
   if (cb0 >= p.N) return;
+  {
+    // Stores.  In the C/D layout a lane holds 4 channels of a pixel: a wave-wide 16-byte store would touch 64 different
+    // 128-byte lines (profiles/r3_wconv_timeline.txt: 7.6 us per tile on the CU's store path, the MFMA pipes idle).  The patch
+    // buffers are free now (the chunk loop ended with a barrier): each wavefront parks its 32 channels as [pixel][32 ch] fp32 in its
+    // own LDS slab (16-byte unit q of pixel P at (q ^ (P >> 1)) & 7: both directions bank-conflict-free), reads it back with 8
+    // consecutive lanes on one pixel, and adds bias / residual and stores 8 whole lines per instruction: 7.9 -> 5.2 us per tile,
+    // 14.6 -> 8.5 with a residual (profiles/r3_ab_wino_epilogue.txt; bit-identical to the per-lane epilogue it replaced).
+    float* slab = (float*)lds + wave * (TR * 16 * 32);
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const long m_even = (long)img * HW + (long)(y0 + 4 * b + lr) * p.W + x0 + 2 * lp;
+    for (int b = 0; b < NB; ++b) {
+      const int pe = (4 * b + lr) * 16 + 2 * lp;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col = cb0 + 8 * g + 4 * hh;
-      wf32x4 m[4];
+      for (int g = 0; g < 4; ++g) {
+        wf32x4 m[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) m[x] = wf32x4{acc[x][b][4 * g], acc[x][b][4 * g + 1], acc[x][b][4 * g + 2], acc[x][b][4 * g + 3]};
-      wf32x4 oe = (m[0] + m[1] + m[2]) * p.alpha, oo = (m[1] - m[2] - m[3]) * p.alpha;
-      if (biasg) {
-        const wf32x4 bv = wf32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
-        oe += bv;
-        oo += bv;
+        for (int x = 0; x < 4; ++x) m[x] = wf32x4{acc[x][b][4 * g], acc[x][b][4 * g + 1], acc[x][b][4 * g + 2], acc[x][b][4 * g + 3]};
+        const int u = ((2 * g + hh) ^ lp) * 4;
+        *(wf32x4*)&slab[pe * 32 + u] = (m[0] + m[1] + m[2]) * p.alpha;
+        *(wf32x4*)&slab[(pe + 1) * 32 + u] = (m[1] - m[2] - m[3]) * p.alpha;
       }
+    }
+    // the slab is private to the wavefront and its LDS operations execute in order: only the compiler must not move the reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // pixel P = 8 i + psub of instruction i: tile row i >> 1, column 8 (i & 1) + psub; its unit is swizzled by (P >> 1) & 7 = 4 (i & 1) + (psub >> 1)
+    const int psub = lane >> 3, quad = lane & 7, col = cb0 + 4 * quad;
+    const float* sl0 = slab + psub * 32 + ((quad ^ (psub >> 1)) & 7) * 4;        // even i
+    const float* sl1 = slab + psub * 32 + ((quad ^ (psub >> 1) ^ 4) & 7) * 4;    // odd i
+    const long m00 = (long)img * HW + (long)y0 * p.W + x0 + psub;
+    float* cp = Cg + m00 * p.ldc + col;
+    const float* rp = Rg ? Rg + m00 * p.ldr + col : nullptr;
+    const long crow = (long)p.W * p.ldc, rrow = (long)p.W * p.ldr;
+    const bool hb = biasg != nullptr;
+    const wf32x4 bv = hb ? wf32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]} : z4;
+#pragma unroll
+    for (int i0 = 0; i0 < 2 * TR; i0 += 8) {  // 8 instructions = 4 tile rows in flight
+      wf32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const wf32x4*)&((u & 1) ? sl1 : sl0)[(i0 + u) * 256];
       if (Rg) {
-        oe += *(const wf32x4*)&Rg[m_even * p.ldr + col];
-        oo += *(const wf32x4*)&Rg[(m_even + 1) * p.ldr + col];
+        wf32x4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = *(const wf32x4*)&rp[((i0 + u) >> 1) * rrow + 8 * (u & 1) * p.ldr];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (hb) v[u] += bv;
+          v[u] += r[u];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (hb) v[u] += bv;
       }
-      *(wf32x4*)&Cg[m_even * p.ldc + col] = oe;
-      *(wf32x4*)&Cg[(m_even + 1) * p.ldc + col] = oo;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) *(wf32x4*)&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc] = v[u];
     }
   }
   W_STAMP(30);
