@@ -32,6 +32,7 @@ struct HGemmParams {
   float* act_out;       // hgemm2 epilogue: C2 = act(C) (GemmParams::act_out)
   const float* act_in;  // hgemm2 epilogue: C = (...) * act'(U)
   int ld_act, act;
+  int lep;         // hgemm2, bf16x3: 1 = output block through LDS, whole-line stores / operand reads (ctx->hgemm_epi)
   int skip_group;  // hgemm2, one slice: drop the first row of every group of this many rows, write the rest compactly (GemmParams)
   int nmajor;  // tile order within the XCD-contiguous runs: 0 = M-tile major (an XCD owns row panels and streams all weights),
                // 1 = N-tile major (an XCD owns weight column panels, read from HBM once and kept in its 4 MB L2; the small
@@ -455,6 +456,96 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
 
   // ---- epilogue: D = W x A^T in the 32x32 C/D layout: column (lane & 31) = row m of C, accumulator quad g = columns 8g + 4hh ..
   const int cb0 = n0 + wn * 32;
+  if (MODE == 1 && p.lep) {
+    // Stores straight from that layout are 16-byte pieces of 64 different rows per instruction, bound by the CU's store path (the finding
+    // of profiles/r3_wconv_timeline.txt for the same layout in wconv_kernel).  The staging buffers are free after the last chunk: each
+    // wavefront parks its TM x 32 block in its own slab (16-byte unit q of row r at q ^ (r & 7): conflict-free both ways), reads it
+    // back with 8 consecutive lanes on one row, and everything row-wise (bias, residual, activation operands, both outputs, split-K
+    // slab) moves whole 128-byte lines.  Same operations per element in the same order as the per-lane epilogue below, which the
+    // single-plane modes (half the LDS) and CGD_HGEMM_EPI=0 keep.
+    __syncthreads();  // every wavefront has fetched its last A fragments
+    if (cb0 >= p.N) return;
+    float* slab = (float*)lds + wn * (TM * 32);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int rl = i * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)&slab[rl * 32 + (((2 * g + hh) ^ rl) & 7) * 4] = f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int rsub = lane >> 3, quad = lane & 7, col = cb0 + 4 * quad;
+    const float* sl = slab + rsub * 32 + ((quad ^ rsub) & 7) * 4;  // row 8 it + rsub at sl[it * 256]
+    if (p.splitk > 1) {
+      float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+      for (int it = 0; it < TM / 8; ++it) {
+        const long row = m0 + 8 * it + rsub;
+        const f32x4 v = *(const f32x4*)&sl[it * 256];
+        if (row < p.M) *(f32x4*)&ws[row * p.N + col] = v;
+      }
+      return;
+    }
+    const bool hb = biasg != nullptr;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 bv = hb ? f32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]} : z4;
+    const float ka = p.act == 2 ? 1.702f : 1.f;  // QuickGELU x * sigmoid(1.702 x) / SiLU
+#pragma unroll
+    for (int i0 = 0; i0 < TM / 8; i0 += 8) {
+      f32x4 v[8], rv[8], uv[8];
+      long row[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = *(const f32x4*)&sl[(i0 + u) * 256];
+        long r = m0 + 8 * (i0 + u) + rsub;
+        ok[u] = r < p.M;
+        if (!ok[u]) r = p.M - 1;
+        if (p.skip_group) {  // (no residual / activation operand with this option: the launcher checks)
+          const long grp = r / p.skip_group;
+          if (r == grp * p.skip_group) ok[u] = false;
+          r -= grp + 1;
+          if (r < 0) r = 0;
+        }
+        row[u] = r;
+      }
+      if (Rg) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rv[u] = *(const f32x4*)&Rg[row[u] * p.ldr + col];
+      }
+      if (p.act_in) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) uv[u] = *(const f32x4*)&p.act_in[row[u] * p.ld_act + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        f32x4 o = v[u] * p.alpha;
+        if (hb) o += bv;
+        if (Rg) o += rv[u];
+        if (p.act_in) {  // backward through the activation: multiply by act'(u), same arithmetic as elem.hip dact_f
+          f32x4 d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sg = 1.f / (1.f + __expf(-ka * uv[u][e]));
+            d[e] = sg * (1.f + ka * uv[u][e] * (1.f - sg));
+          }
+          o *= d;
+        }
+        if (ok[u]) {
+          *(f32x4*)&Cg[row[u] * p.ldc + col] = o;
+          if (p.act_out) {  // second output: the activated tensor, same arithmetic as elem.hip act_f
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = o[e] / (1.f + __expf(-ka * o[e]));
+            *(f32x4*)&p.act_out[row[u] * p.ld_act + col] = a;
+          }
+        }
+      }
+    }
+    return;
+  }
   if (cb0 >= p.N) return;
   if (p.splitk > 1) {
     float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
@@ -604,6 +695,7 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && g.N >= g.M)) ? 1 : 0;
   p.act_out = g.act_out; p.act_in = g.act_in; p.ld_act = g.ld_act; p.act = g.act;
   p.skip_group = g.skip_group;
+  p.lep = ctx->hgemm_epi;
   const int tm = cgd_hgemm_tile_m(ctx, g);
   dim3 grid(cdiv(g.M, tm) * cdiv(g.N, GN), 1, g.splitk > 1 ? g.splitk : 1);
   const bool x3 = ctx->precision == CGD_PREC_BF16X3;

@@ -116,6 +116,41 @@ def check_gemm(precision):
     return out
 
 
+def check_hgemm_epilogues():
+    """hgemm2_kernel (bf16x3) has two epilogues: the output block through LDS with whole-line stores / operand reads (default) and
+    per-lane 16-byte accesses straight from the accumulator layout (CGD_HGEMM_EPI=0; also what the single-plane modes use).  Same
+    operations per element in the same order: results must be BIT-identical, with and without split-K, ragged M, partial N tile,
+    bias / residual; each is also graded against float64."""
+    from cgd_amd import ops
+    prev = os.environ.get("CGD_HGEMM_EPI")
+    ctxs = []
+    try:
+        for v in ("1", "0"):
+            os.environ["CGD_HGEMM_EPI"] = v
+            ctxs.append(_ctx(1))
+    finally:
+        if prev is None:
+            del os.environ["CGD_HGEMM_EPI"]
+        else:
+            os.environ["CGD_HGEMM_EPI"] = prev
+    out = []
+    for (M, N, K, sk, full) in [(800, 768, 768, 1, 1), (800, 3072, 768, 3, 1), (200, 96, 256, 2, 1), (128, 160, 64, 1, 1), (1000, 2304, 768, 1, 0),
+                                (70, 32, 3072, 5, 1), (784, 768, 3072, 0, 1), (4096, 1024, 256, 1, 1), (50, 768, 768, 4, 0)]:
+        A = th.randn(M, K, generator=g(1))
+        B = th.randn(N, K, generator=g(2))
+        bias = 0.3 * th.randn(N, generator=g(3)) if full else None
+        R = 0.3 * th.randn(M, N, generator=g(4)) if full else None
+        alpha = 1.0 / math.sqrt(K)
+        ref = alpha * (A.double() @ B.double().T)
+        if full:
+            ref = ref + bias.double() + R.double()
+        got = [ops.gemm(c, A.to(DEV), B.to(DEV), None if bias is None else bias.to(DEV), None if R is None else R.to(DEV), alpha=alpha,
+                        force_tile=513, splitk=sk) for c in ctxs]
+        assert th.equal(got[0], got[1]), f"hgemm2 {M}x{N}x{K} sk{sk}: the two epilogues differ"
+        out.append(rec(f"hgemm2 epilogues {M}x{N}x{K} sk{sk} bias/res {full}", got[0], ref.float()))
+    return out
+
+
 def check_conv(precision):
     from cgd_amd import ops
     ctx = _ctx(precision)

@@ -28,6 +28,17 @@ def test_gemm(precision):
     _assert_all(pc.check_gemm(precision))
 
 
+def test_hgemm2_epilogues_are_bit_identical():
+    _assert_all(pc.check_hgemm_epilogues())
+
+
+def test_clip_vit_b32_on_the_per_lane_gemm_epilogue(monkeypatch):
+    """CGD_HGEMM_EPI=0 keeps hgemm2's per-lane epilogue selectable (fused QuickGELU outputs / derivative operands, the patch-embedding
+    dgrad's dropped class rows go through it): grade that path too, so no instantiation in the library is unrun."""
+    monkeypatch.setenv("CGD_HGEMM_EPI", "0")
+    _assert_all(pc.check_vit("ViT-B/32", 1))
+
+
 def test_gemm_bf16_single_product_is_bf16_accurate():
     recs = pc.check_gemm(2)  # reduced-precision speed mode: not parity mode, only sanity-bounded
     assert all(r["err_rel"] < 1e-2 for r in recs)
