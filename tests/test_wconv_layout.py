@@ -26,6 +26,17 @@ def test_layouts_emulated_end_to_end_match_a_direct_convolution_and_are_bank_con
         assert err < 1e-9 and worst == 1, (nb, err, worst)
 
 
+def test_lds_transposed_epilogues_round_trip_and_are_bank_conflict_free():
+    """wconv_kernel and hgemm2_kernel park their output block in an XOR-swizzled LDS slab and read it back line-wise (whole-line global
+    stores): the read-back finds exactly the element each lane wrote, and neither the ds_write_b128 nor the ds_read_b128 lane groups put
+    two different addresses on one bank / 16-byte slot."""
+    from benchmarks import emulate_epilogue
+    for nb in (4, 2):
+        assert emulate_epilogue.wconv(nb) == (1, 1)
+    for tm in (64, 128):
+        assert emulate_epilogue.hgemm2(tm) == (1, 1)
+
+
 def test_staging_schedule_never_reloads_a_live_register_slot():
     """Task k of the next chunk is loaded into slot k & 1 and transformed in three pieces later in the same chunk: every task is loaded
     and transformed exactly once, in order, with >= 5 steps of load latency covered, and a slot is only reloaded after the last piece
