@@ -25,6 +25,41 @@ namespace {
 constexpr int GM = 128, GN = 128, GK = 64, GPH = GK + 8;  // tile, chunk width, LDS row pitch (bf16 elements)
 constexpr int GPLANE = GM * GPH;
 
+// per-wavefront timeline for benchmarks/ubench/hgemm_stamps.hip (which includes this file with CGD_HGEMM_STAMPS defined); the library build
+// never defines it: H_STAMP expands to nothing there
+#ifdef CGD_HGEMM_STAMPS
+__device__ unsigned long long* g_hstamps;  // [workgroup (x + gridDim.x * z)][wavefront][32]: 0 entry, 1 first chunk staged, 2 + c chunk c done (level 2), 29 loop done, 30 stores issued, 31 HW id
+#define H_STAMP(I)                                                                                                          \
+  do {                                                                                                                      \
+    if ((threadIdx.x & 63) == 0)                                                                                            \
+      g_hstamps[(((long)blockIdx.z * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32 + (I)] = wall_clock64();        \
+  } while (0)
+#if CGD_HGEMM_STAMPS >= 2  // a store per chunk slows the 0.75 us chunks by ~30 %: level 1 stamps only around the loop
+#define H_STAMP_CHUNK(I) H_STAMP(I)
+#else
+#define H_STAMP_CHUNK(I) \
+  do {                   \
+  } while (0)
+#endif
+#define H_STAMP_END()                                                                                                       \
+  do {                                                                                                                      \
+    H_STAMP(30);                                                                                                            \
+    if ((threadIdx.x & 63) == 0)                                                                                            \
+      g_hstamps[(((long)blockIdx.z * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32 + 31] =                         \
+          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); \
+  } while (0)
+#else
+#define H_STAMP(I) \
+  do {             \
+  } while (0)
+#define H_STAMP_CHUNK(I) \
+  do {                   \
+  } while (0)
+#define H_STAMP_END() \
+  do {                \
+  } while (0)
+#endif
+
 struct HGemmParams {
   int lda, ldc, ldr;
   int M, N, K, splitk;
@@ -288,6 +323,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
+  H_STAMP(0);
 
   const int ntn = (p.N + GN - 1) / GN;
   int bid = blockIdx.x;
@@ -413,6 +449,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
     H2_B_LOAD(bq[((S) + 3 + DIST) % RING], kq + 3 + DIST);                                        \
     H2_MFMA(af[1], bq[(S) + 3]);                                                                  \
     H2_INTERLEAVE();                                                                              \
+    H_STAMP_CHUNK(2 + ((C) - c0 < 26 ? (C) - c0 : 26));                                           \
   }
 
     bf16x8 af[2][NI][NPL];  // [pipeline slot][row block][plane]
@@ -430,6 +467,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
       // alternating register sets (one chunk ahead left every chunk waiting ~0.7 us for its patch, gemm_r2b)
       H2_PATCH_LOAD(pr2, c0 + 2);
       __syncthreads();
+      H_STAMP(1);
       H2_A_LOAD(af[0], buf0, 0);
       for (; c + 1 < c1; c += 2) {
         H2_CHUNK(0, buf0, buf1, c, pr);
@@ -438,6 +476,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
       if (c < c1) H2_CHUNK(0, buf0, buf1, c, pr);
     } else {
       __syncthreads();
+      H_STAMP(1);
       H2_A_LOAD(af[0], buf0, 0);
       for (; c + 1 < c1; c += 2) {
         H2_CHUNK(0, buf0, buf1, c, pr);
@@ -454,6 +493,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
 #undef H2_CHUNK
   }
 
+  H_STAMP(29);
   // ---- epilogue: D = W x A^T in the 32x32 C/D layout: column (lane & 31) = row m of C, accumulator quad g = columns 8g + 4hh ..
   const int cb0 = n0 + wn * 32;
   if (MODE == 1 && p.lep) {
@@ -486,19 +526,21 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
         const f32x4 v = *(const f32x4*)&sl[it * 256];
         if (row < p.M) *(f32x4*)&ws[row * p.N + col] = v;
       }
+      H_STAMP_END();
       return;
     }
     const bool hb = biasg != nullptr;
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 bv = hb ? f32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]} : z4;
     const float ka = p.act == 2 ? 1.702f : 1.f;  // QuickGELU x * sigmoid(1.702 x) / SiLU
+    constexpr int EB = TM == 64 ? 8 : 4;         // rows in flight per lane (the 128-row instantiation must stay within 256 registers)
 #pragma unroll
-    for (int i0 = 0; i0 < TM / 8; i0 += 8) {
-      f32x4 v[8], rv[8], uv[8];
-      long row[8];
-      bool ok[8];
+    for (int i0 = 0; i0 < TM / 8; i0 += EB) {
+      f32x4 v[EB], rv[EB], uv[EB];
+      long row[EB];
+      bool ok[EB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < EB; ++u) {
         v[u] = *(const f32x4*)&sl[(i0 + u) * 256];
         long r = m0 + 8 * (i0 + u) + rsub;
         ok[u] = r < p.M;
@@ -513,14 +555,14 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
       }
       if (Rg) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rv[u] = *(const f32x4*)&Rg[row[u] * p.ldr + col];
+        for (int u = 0; u < EB; ++u) rv[u] = *(const f32x4*)&Rg[row[u] * p.ldr + col];
       }
       if (p.act_in) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) uv[u] = *(const f32x4*)&p.act_in[row[u] * p.ld_act + col];
+        for (int u = 0; u < EB; ++u) uv[u] = *(const f32x4*)&p.act_in[row[u] * p.ld_act + col];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < EB; ++u) {
         f32x4 o = v[u] * p.alpha;
         if (hb) o += bv;
         if (Rg) o += rv[u];
@@ -544,6 +586,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
         }
       }
     }
+    H_STAMP_END();
     return;
   }
   if (cb0 >= p.N) return;
