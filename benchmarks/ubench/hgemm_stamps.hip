@@ -147,6 +147,27 @@ int main(int argc, char** argv) {
     unsigned long long sum = 0;
     for (size_t i = 0; i < n; ++i) sum = sum * 1000003ull + h[i];
     printf("output checksum %016llx\n", sum);
+    if ((double)M * N * K <= 4e8) {  // small enough for a float64 reference on the host: alpha * A W^T + bias (+ 0 residual), slabs summed
+      std::vector<float> hc(n);
+      memcpy(hc.data(), h.data(), n * 4);
+      double worst = 0.0, peak = 0.0;
+      for (int m = 0; m < M; ++m)
+        for (int c = 0; c < N; ++c) {
+          double a = 0.0;
+          for (int k = 0; k < K; ++k) a += (double)hA[(size_t)m * K + k] * hW[(size_t)c * K + k];
+          double got = 0.0;
+          if (sk > 1) {
+            for (int z = 0; z < sk; ++z) got += hc[((size_t)z * M + m) * N + c];
+            a *= 1.0;  // the slabs hold the raw partial products (alpha, bias applied by the reduction)
+          } else {
+            got = hc[(size_t)m * N + c];
+            a = a * p.alpha + hb[c];
+          }
+          worst = std::max(worst, fabs(got - a));
+          peak = std::max(peak, fabs(a));
+        }
+      printf("float64 reference: max |err| %.3e at peak %.3e (%s)\n", worst, peak, worst <= 1e-4 * std::max(1.0, peak) ? "ok" : "MISMATCH");
+    }
   }
   printf("hgemm2_kernel<1, %d>  M %d N %d K %d  split-K %d%s: %d workgroups (%d x %d tiles), %d chunks per slice; %.2f us per launch (events, %d launches)\n", tm, M,
          N, K, sk, res ? " + residual" : "", nwg, ntm, ntn, per, ms * 1e3 / reps, reps);

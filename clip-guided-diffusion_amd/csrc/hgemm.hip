@@ -367,9 +367,10 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
   if (c0 < c1) {
-    constexpr bool DEEP = TM == 64;      // activations two chunks ahead (second staging register set)
-    constexpr int AHEAD = DEEP ? 3 : 2;  // chunk fetched by the load at the end of chunk C
-    f32x4 pr[NPS], pr2[DEEP ? NPS : 1];
+    constexpr bool DEEP = TM == 64;          // activations several chunks ahead: NSET staging register sets used in turn
+    constexpr int NSET = DEEP ? 4 : 1;       // set (C - c0) % NSET holds chunk C + 1 while chunk C runs and is refilled with chunk C + 1 + NSET
+    constexpr int AHEAD = NSET + 1;          // chunk fetched by the load at the end of chunk C
+    f32x4 pr[NPS], prx[DEEP ? 3 : 1][DEEP ? NPS : 1];
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #define H2_PATCH_LOAD(PR, CH)                                                                     \
   {                                                                                               \
@@ -463,17 +464,25 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
     H2_PATCH_LOAD(pr, c0 + 1);
     int c = c0;
     if constexpr (DEEP) {
-      // A chunk of the 64-row tile lasts ~0.3 us, less than an L2 round trip: the activations are fetched TWO chunks ahead into
-      // alternating register sets (one chunk ahead left every chunk waiting ~0.7 us for its patch, gemm_r2b)
-      H2_PATCH_LOAD(pr2, c0 + 2);
+      // A chunk of the 64-row tile has 0.32 us of MFMA work and the L2 starts every launch cold: the fp32 activations see the Infinity
+      // Cache / HBM latency (1.5-1.9 us).  The loop runs at (that latency) / (chunks of prefetch): one chunk ahead 1.4 us per chunk
+      // (gemm_r2b), two ahead 0.74-0.94 (profiles/r3_hgemm_timeline.txt: one workgroup alone on the chip is as slow as 234), so
+      // the patch is fetched FOUR chunks ahead into four register sets used in turn.
+      H2_PATCH_LOAD(prx[0], c0 + 2);
+      H2_PATCH_LOAD(prx[1], c0 + 3);
+      H2_PATCH_LOAD(prx[2], c0 + 4);
       __syncthreads();
       H_STAMP(1);
       H2_A_LOAD(af[0], buf0, 0);
-      for (; c + 1 < c1; c += 2) {
+      for (; c + 3 < c1; c += 4) {
         H2_CHUNK(0, buf0, buf1, c, pr);
-        H2_CHUNK(4, buf1, buf0, c + 1, pr2);
+        H2_CHUNK(4, buf1, buf0, c + 1, prx[0]);
+        H2_CHUNK(0, buf0, buf1, c + 2, prx[1]);
+        H2_CHUNK(4, buf1, buf0, c + 3, prx[2]);
       }
       if (c < c1) H2_CHUNK(0, buf0, buf1, c, pr);
+      if (c + 1 < c1) H2_CHUNK(4, buf1, buf0, c + 1, prx[0]);
+      if (c + 2 < c1) H2_CHUNK(0, buf0, buf1, c + 2, prx[1]);
     } else {
       __syncthreads();
       H_STAMP(1);
