@@ -311,6 +311,12 @@ epilogue:
 //   * the loop body covers a whole period of ring base, LDS buffer and staging set (two 64-deep chunks = 8 k-steps = one turn of the ring in
 //     the shipped configuration), so every ring slot, LDS buffer and register set is a compile-time constant; a shorter tail follows;
 //   * A staging, conversion, barrier placement and the epilogue are those of hgemm_kernel.
+// Ablation switches for benchmarks/ubench/hgemm_stamps.hip ONLY (results become wrong; the library build never defines the macro): which element
+// of the chunk loop is the exposed latency?  bit 0: no weight-fragment loads inside the loop (the ring keeps its prologue contents), bit 1: no
+// activation patch loads / conversion / LDS writes inside the loop, bit 2: no barrier inside the loop, bit 3: no A-fragment LDS reads inside the loop
+#ifndef CGD_HGEMM_EXP
+#define CGD_HGEMM_EXP 0
+#endif
 constexpr int h2_gcd(int a, int b) { return b ? h2_gcd(b, a % b) : a; }
 constexpr int h2_lcm(int a, int b) { return a / h2_gcd(a, b) * b; }
 // RING = weight-fragment ring depth in k-steps (a multiple of 4: slots of a chunk are ring[(4 j) % RING ..]), NSET = staging register sets of
@@ -431,27 +437,31 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   }
   // one 64-deep chunk: ring slots S .. S+3 (S = 0 or 4), LDS buffers CUR -> NXT, staging registers PR (they hold chunk C+1 on
   // entry and are refilled with chunk C+AHEAD once converted)
+#define X_B(...) do { if constexpr (!(CGD_HGEMM_EXP & 1)) { __VA_ARGS__; } } while (0)
+#define X_P(...) do { if constexpr (!(CGD_HGEMM_EXP & 2)) { __VA_ARGS__; } } while (0)
+#define X_S(...) do { if constexpr (!(CGD_HGEMM_EXP & 4)) { __VA_ARGS__; } } while (0)
+#define X_A(...) do { if constexpr (!(CGD_HGEMM_EXP & 8)) { __VA_ARGS__; } } while (0)
 #define H2_CHUNK(S, CUR, NXT, C, PR)                                                              \
   {                                                                                               \
     const int kq = (C) * 4;                                                                       \
-    H2_A_LOAD(af[1], CUR, 1);                                                                     \
-    H2_B_LOAD(bq[((S) + 0 + DIST) % RING], kq + 0 + DIST);                                        \
+    X_A(H2_A_LOAD(af[1], CUR, 1));                                                                     \
+    X_B(H2_B_LOAD(bq[((S) + 0 + DIST) % RING], kq + 0 + DIST));                                        \
     H2_MFMA(af[0], bq[(S) + 0]);                                                                  \
     H2_INTERLEAVE();                                                                              \
-    H2_A_LOAD(af[0], CUR, 2);                                                                     \
-    H2_B_LOAD(bq[((S) + 1 + DIST) % RING], kq + 1 + DIST);                                        \
+    X_A(H2_A_LOAD(af[0], CUR, 2));                                                                     \
+    X_B(H2_B_LOAD(bq[((S) + 1 + DIST) % RING], kq + 1 + DIST));                                        \
     H2_MFMA(af[1], bq[(S) + 1]);                                                                  \
-    H2_PATCH_STORE(PR, NXT, 0, NPS / 2);                                                          \
+    X_P(H2_PATCH_STORE(PR, NXT, 0, NPS / 2));                                                          \
     H2_INTERLEAVE();                                                                              \
-    H2_A_LOAD(af[1], CUR, 3);                                                                     \
-    H2_B_LOAD(bq[((S) + 2 + DIST) % RING], kq + 2 + DIST);                                        \
+    X_A(H2_A_LOAD(af[1], CUR, 3));                                                                     \
+    X_B(H2_B_LOAD(bq[((S) + 2 + DIST) % RING], kq + 2 + DIST));                                        \
     H2_MFMA(af[0], bq[(S) + 2]);                                                                  \
-    H2_PATCH_STORE(PR, NXT, NPS / 2, NPS);                                                        \
+    X_P(H2_PATCH_STORE(PR, NXT, NPS / 2, NPS));                                                        \
     H2_INTERLEAVE();                                                                              \
-    H2_PATCH_LOAD(PR, (C) + AHEAD);                                                               \
-    __syncthreads(); /* NXT fully written; every wavefront has fetched its last fragments of CUR */ \
-    H2_A_LOAD(af[0], NXT, 0);                                                                     \
-    H2_B_LOAD(bq[((S) + 3 + DIST) % RING], kq + 3 + DIST);                                        \
+    X_P(H2_PATCH_LOAD(PR, (C) + AHEAD));                                                               \
+    X_S(__syncthreads()); /* NXT fully written; every wavefront has fetched its last fragments of CUR */ \
+    X_A(H2_A_LOAD(af[0], NXT, 0));                                                                     \
+    X_B(H2_B_LOAD(bq[((S) + 3 + DIST) % RING], kq + 3 + DIST));                                        \
     H2_MFMA(af[1], bq[(S) + 3]);                                                                  \
     H2_INTERLEAVE();                                                                              \
     H_STAMP_CHUNK(2 + ((C) - c0 < 26 ? (C) - c0 : 26));                                           \
@@ -491,6 +501,10 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
 #undef H2_MFMA
 #undef H2_INTERLEAVE
 #undef H2_CHUNK
+#undef X_B
+#undef X_P
+#undef X_S
+#undef X_A
   }
 
   H_STAMP(29);
