@@ -21,7 +21,8 @@ done
 # Ablation (wrong results, timing only): the chunk loop with one element removed at a time — bit 0 weight-fragment loads, 1 activation patch path,
 # 2 barrier, 3 A-fragment LDS reads; 15 = MFMAs + schedule only.  Shows which latency of the chain is exposed (per-k-step stamps are not usable).
 for e in 1 2 4 8 3 15; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DCGD_HGEMM_EXP=$e hgemm_stamps.hip -o hgemm_exp$e 2>/dev/null
+  # build these HERE before the gpurun call (binaries travel with the snapshot; compiling on the GPU box costs ~25 s of box time each)
+  [ -x hgemm_exp$e ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -DCGD_HGEMM_EXP=$e hgemm_stamps.hip -o hgemm_exp$e 2>/dev/null
   for args in "64 128 768 1" "800 2304 768 1"; do
     timeout 20 ./hgemm_exp$e $args 64 20 0 0 | grep -E "^hgemm2|chunk loop /" | tr '\n' ' ' | sed "s/  */ /g; s/^/ablation $e: /"
     echo
