@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # round-3 GPU batch: kconv parity + micro-benchmark + step A/B, early-schedule tests, config-4 full-shape failure detail
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out
 timeout 300 python -m pytest tests/test_gpu_parity.py -q -x -k "weight_streaming or previous_kernels or unet_small or unet_64 or test_conv" 2>&1 | tail -15 > $O/r3b1_kconv_parity.txt

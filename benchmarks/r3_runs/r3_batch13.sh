@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Timeline of wconv_kernel's workgroups (benchmarks/ubench/wconv_stamps.hip) on the UNet's large-map layer shapes
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/benchmarks/ubench"
 [ -x wconv_stamps ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include wconv_stamps.hip -o wconv_stamps
 O=$ROOT/gpurun_out

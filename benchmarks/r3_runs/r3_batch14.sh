@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # wconv_kernel's coalesced epilogue (CGD_WINO_EPI=1): timeline per layer shape, parity + bit-identity test, whole-step A/B
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/benchmarks/ubench"
 [ -x wconv_stamps ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include wconv_stamps.hip -o wconv_stamps
 for args in "256 256 256 0 4" "256 256 256 1 4" "256 256 512 0 4" "128 256 256 0 2"; do

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # hgemm2_kernel's coalesced epilogue (CGD_HGEMM_EPI=1, default) against the per-lane one: bit-identity + parity tests, whole-step A/B
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 timeout 200 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "gemm or clip_vit_b32 or unet_64 or unet_128 or attention" 2>&1 | tail -4
 run() {

@@ -2,7 +2,7 @@
 # Timeline of hgemm2_kernel's workgroups (benchmarks/ubench/hgemm_stamps.hip) on the ViT-B/32 GEMM shapes of the guidance step (M = 800 token rows):
 # level 1 = stamps around the chunk loop only (undisturbed loop time), level 2 = a stamp after every chunk
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/benchmarks/ubench"
 [ -x hgemm_stamps ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include hgemm_stamps.hip -o hgemm_stamps
 # qkv (N 2304), out_proj (768), fc1 (3072, K 768), fc2 (768, K 3072) with / without split-K; one 128-row case

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # PMC stall diagnosis of hgemm2_kernel<1, 64> on the ViT qkv shape (M 800, N 2304, K 768), via the timeline micro-benchmark's binary
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_r3hgemm
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

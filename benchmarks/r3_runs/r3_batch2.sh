@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out
 SKIP_MFMA=1 PASS_TIMEOUT=200 bash benchmarks/run_profile.sh r3a 4 > $O/r3b2_profile.log 2>&1

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 run() {
   env "$@" timeout 100 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-profile 2>/dev/null |
@@ -8,8 +8,8 @@ run() {
 }
 for _ in 1 2; do
   run CGD_NOP=1
-  run CGD_DEFER=2
-  run CGD_DEFER=0
-  run CGD_HGEMM=1,64,2
-  run CGD_HGEMM=1,64,8
+  run CGD_FUSE_GN=1,16384
+  run CGD_FUSE_GN=1,4096
+  run CGD_FUSE_GN=1,1073741824,65536
+  run CGD_FUSE_GN=0
 done

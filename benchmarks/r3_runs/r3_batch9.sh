@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_step.py -q -x -k "cutouts or thin_input or headline_shape_single or p_sample_trajectory or cosine_nonsquare or config5_nonsquare or reference_recipe or use_augs_guided or dual_clip" 2>&1 | tail -4 | cut -c1-600
