@@ -2,9 +2,9 @@
 // of a launch goes.  Includes the kernel source with CGD_HGEMM_STAMPS defined: lane 0 of every wavefront stores wall_clock64() (100 MHz) at
 // entry, after the first chunk is staged, after every chunk and after the epilogue's stores are issued, plus XCC_ID / HW_ID.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include hgemm_stamps.hip -o hgemm_stamps
-// Usage: hgemm_stamps M N K splitk [tm 64|128] [reps] [residual 0|1] [pipeline 0..7]
+// Usage: hgemm_stamps M N K splitk [tm 64|128] [reps] [residual 0|1] [pipeline 0..8]
 //   pipeline (64-row tiles only) = index into {ring depth in k-steps, activation staging sets}: 0 {8,2} (shipped), 1 {8,3}, 2 {8,4}, 3 {12,2},
-//   4 {12,3}, 5 {12,4}, 6 {16,2}, 7 {16,3} — the sweep of the software pipeline's depth against the cold-L2 operand latency
+//   4 {12,3}, 5 {12,4}, 6 {16,2}, 7 {16,3}, 8 {16,4} — the sweep of the software pipeline's depth against the cold-L2 operand latency
 #ifndef CGD_HGEMM_STAMPS
 #define CGD_HGEMM_STAMPS 1  // 2 (-DCGD_HGEMM_STAMPS=2): a stamp after every chunk as well
 #endif
@@ -92,6 +92,7 @@ int main(int argc, char** argv) {
         case 5: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 12, 4>), HS_ARGS); break;
         case 6: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 2>), HS_ARGS); break;
         case 7: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 3>), HS_ARGS); break;
+        case 8: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 4>), HS_ARGS); break;
         default: hipLaunchKernelGGL((hgemm2_kernel<1, 64>), HS_ARGS); break;
       }
     } else
