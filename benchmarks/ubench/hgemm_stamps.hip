@@ -2,7 +2,9 @@
 // of a launch goes.  Includes the kernel source with CGD_HGEMM_STAMPS defined: lane 0 of every wavefront stores wall_clock64() (100 MHz) at
 // entry, after the first chunk is staged, after every chunk and after the epilogue's stores are issued, plus XCC_ID / HW_ID.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include hgemm_stamps.hip -o hgemm_stamps
-// Usage: hgemm_stamps M N K splitk [tm 64|128] [reps] [residual 0|1]
+// Usage: hgemm_stamps M N K splitk [tm 64|128] [reps] [residual 0|1] [pipeline 0..8]
+//   pipeline (64-row tiles only) = index into {ring depth in k-steps, activation staging sets}: 0 {8,2} (shipped), 1 {8,3}, 2 {8,4}, 3 {12,2},
+//   4 {12,3}, 5 {12,4}, 6 {16,2}, 7 {16,3}, 8 {16,4} — the sweep of the software pipeline's depth against the cold-L2 operand latency
 #ifndef CGD_HGEMM_STAMPS
 #define CGD_HGEMM_STAMPS 1  // 2 (-DCGD_HGEMM_STAMPS=2): a stamp after every chunk as well
 #endif
@@ -39,6 +41,7 @@ int main(int argc, char** argv) {
   }
   const int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]), sk = std::max(1, atoi(argv[4]));
   const int tm = argc > 5 ? atoi(argv[5]) : 64, reps = argc > 6 ? atoi(argv[6]) : 10, res = argc > 7 ? atoi(argv[7]) : 0;
+  const int cfg = argc > 8 ? atoi(argv[8]) : 0;
   if ((N & 31) || (K % GK) || (tm != 64 && tm != 128)) {
     fprintf(stderr, "unsupported shape\n");
     return 2;
@@ -79,9 +82,20 @@ int main(int argc, char** argv) {
   CK(hipMemset(dst, 0, (size_t)nwg * 4 * 32 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_hstamps), &dst, sizeof(dst)));
   auto go = [&]() {
-    if (tm == 64)
-      hipLaunchKernelGGL((hgemm2_kernel<1, 64>), grid, dim3(256), 0, 0, dA, (const uint4*)dB, dC, dbias, dR, dws, p);
-    else
+#define HS_ARGS grid, dim3(256), 0, 0, dA, (const uint4*)dB, dC, dbias, dR, dws, p
+    if (tm == 64) {
+      switch (cfg) {
+        case 1: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 8, 3>), HS_ARGS); break;
+        case 2: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 8, 4>), HS_ARGS); break;
+        case 3: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 12, 2>), HS_ARGS); break;
+        case 4: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 12, 3>), HS_ARGS); break;
+        case 5: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 12, 4>), HS_ARGS); break;
+        case 6: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 2>), HS_ARGS); break;
+        case 7: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 3>), HS_ARGS); break;
+        case 8: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 4>), HS_ARGS); break;
+        default: hipLaunchKernelGGL((hgemm2_kernel<1, 64>), HS_ARGS); break;
+      }
+    } else
       hipLaunchKernelGGL((hgemm2_kernel<1, 128>), grid, dim3(256), 0, 0, dA, (const uint4*)dB, dC, dbias, dR, dws, p);
   };
   hipEvent_t e0, e1;
@@ -169,7 +183,7 @@ int main(int argc, char** argv) {
       printf("float64 reference: max |err| %.3e at peak %.3e (%s)\n", worst, peak, worst <= 1e-4 * std::max(1.0, peak) ? "ok" : "MISMATCH");
     }
   }
-  printf("hgemm2_kernel<1, %d>  M %d N %d K %d  split-K %d%s: %d workgroups (%d x %d tiles), %d chunks per slice; %.2f us per launch (events, %d launches)\n", tm, M,
+  printf("hgemm2_kernel<1, %d> pipeline %d  M %d N %d K %d  split-K %d%s: %d workgroups (%d x %d tiles), %d chunks per slice; %.2f us per launch (events, %d launches)\n", tm, cfg, M,
          N, K, sk, res ? " + residual" : "", nwg, ntm, ntn, per, ms * 1e3 / reps, reps);
   printf("  CUs used %zu; workgroups per CU:", percu.size());
   for (auto& h : hist) printf("  %d x %d", h.second, h.first);

@@ -308,10 +308,21 @@ epilogue:
 //   * TM = 64 for small M (fewer than one 128-row tile per CU): M = 800 gives 13 x N/128 workgroups instead of 7 x N/128, so
 //     the N >= 2304 linears fill the chip without split-K and the others split less; two to three workgroups fit a CU
 //     (LDS 36.9 KB, ~170 VGPRs), whose load stalls overlap;
-//   * the loop body covers TWO 64-deep chunks (8 k-steps = one turn of the ring), so every ring slot and LDS buffer is a
-//     compile-time constant; an odd chunk count ends with a single-chunk tail outside the loop;
+//   * the loop body covers a whole period of ring base, LDS buffer and staging set (two 64-deep chunks = 8 k-steps = one turn of the ring in
+//     the shipped configuration), so every ring slot, LDS buffer and register set is a compile-time constant; a shorter tail follows;
 //   * A staging, conversion, barrier placement and the epilogue are those of hgemm_kernel.
-template <int MODE, int TM>
+// Ablation switches for benchmarks/ubench/hgemm_stamps.hip ONLY (results become wrong; the library build never defines the macro): which element
+// of the chunk loop is the exposed latency?  bit 0: no weight-fragment loads inside the loop (the ring keeps its prologue contents), bit 1: no
+// activation patch loads / conversion / LDS writes inside the loop, bit 2: no barrier inside the loop, bit 3: no A-fragment LDS reads inside the loop
+#ifndef CGD_HGEMM_EXP
+#define CGD_HGEMM_EXP 0
+#endif
+constexpr int h2_gcd(int a, int b) { return b ? h2_gcd(b, a % b) : a; }
+constexpr int h2_lcm(int a, int b) { return a / h2_gcd(a, b) * b; }
+// RING = weight-fragment ring depth in k-steps (a multiple of 4: slots of a chunk are ring[(4 j) % RING ..]), NSET = staging register sets of
+// the activation patch (the patch is fetched NSET chunks ahead).  Defaults = the shipped configuration; benchmarks/ubench/hgemm_stamps.hip
+// instantiates others to sweep the pipeline depth against the cold-L2 operand latency.
+template <int MODE, int TM, int RING = 8, int NSET = (TM == 64 ? 2 : 1)>
 __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                      const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                      const HGemmParams p) {
@@ -319,7 +330,8 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   constexpr int NI = TM / 32;      // 32-row blocks per wavefront
   constexpr int NPS = TM / 16;     // staging slots per thread: rows r0 + 16 j
   constexpr int PLANE = TM * GPH;
-  constexpr int RING = 8, DIST = RING - 1;
+  constexpr int DIST = RING - 1;
+  static_assert(RING % 4 == 0 && RING >= 8 && NSET >= 1, "hgemm2: ring depth in whole chunks, at least two");
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -367,9 +379,8 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
   if (c0 < c1) {
-    constexpr bool DEEP = TM == 64;      // activations two chunks ahead (second staging register set)
-    constexpr int AHEAD = DEEP ? 3 : 2;  // chunk fetched by the load at the end of chunk C
-    f32x4 pr[NPS], pr2[DEEP ? NPS : 1];
+    constexpr int AHEAD = NSET + 1;  // set (C - c0) % NSET holds chunk C + 1 while chunk C runs and is refilled with chunk C + AHEAD
+    f32x4 prs[NSET][NPS];
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #define H2_PATCH_LOAD(PR, CH)                                                                     \
   {                                                                                               \
@@ -426,27 +437,31 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   }
   // one 64-deep chunk: ring slots S .. S+3 (S = 0 or 4), LDS buffers CUR -> NXT, staging registers PR (they hold chunk C+1 on
   // entry and are refilled with chunk C+AHEAD once converted)
+#define X_B(...) do { if constexpr (!(CGD_HGEMM_EXP & 1)) { __VA_ARGS__; } } while (0)
+#define X_P(...) do { if constexpr (!(CGD_HGEMM_EXP & 2)) { __VA_ARGS__; } } while (0)
+#define X_S(...) do { if constexpr (!(CGD_HGEMM_EXP & 4)) { __VA_ARGS__; } } while (0)
+#define X_A(...) do { if constexpr (!(CGD_HGEMM_EXP & 8)) { __VA_ARGS__; } } while (0)
 #define H2_CHUNK(S, CUR, NXT, C, PR)                                                              \
   {                                                                                               \
     const int kq = (C) * 4;                                                                       \
-    H2_A_LOAD(af[1], CUR, 1);                                                                     \
-    H2_B_LOAD(bq[((S) + 0 + DIST) % RING], kq + 0 + DIST);                                        \
+    X_A(H2_A_LOAD(af[1], CUR, 1));                                                                     \
+    X_B(H2_B_LOAD(bq[((S) + 0 + DIST) % RING], kq + 0 + DIST));                                        \
     H2_MFMA(af[0], bq[(S) + 0]);                                                                  \
     H2_INTERLEAVE();                                                                              \
-    H2_A_LOAD(af[0], CUR, 2);                                                                     \
-    H2_B_LOAD(bq[((S) + 1 + DIST) % RING], kq + 1 + DIST);                                        \
+    X_A(H2_A_LOAD(af[0], CUR, 2));                                                                     \
+    X_B(H2_B_LOAD(bq[((S) + 1 + DIST) % RING], kq + 1 + DIST));                                        \
     H2_MFMA(af[1], bq[(S) + 1]);                                                                  \
-    H2_PATCH_STORE(PR, NXT, 0, NPS / 2);                                                          \
+    X_P(H2_PATCH_STORE(PR, NXT, 0, NPS / 2));                                                          \
     H2_INTERLEAVE();                                                                              \
-    H2_A_LOAD(af[1], CUR, 3);                                                                     \
-    H2_B_LOAD(bq[((S) + 2 + DIST) % RING], kq + 2 + DIST);                                        \
+    X_A(H2_A_LOAD(af[1], CUR, 3));                                                                     \
+    X_B(H2_B_LOAD(bq[((S) + 2 + DIST) % RING], kq + 2 + DIST));                                        \
     H2_MFMA(af[0], bq[(S) + 2]);                                                                  \
-    H2_PATCH_STORE(PR, NXT, NPS / 2, NPS);                                                        \
+    X_P(H2_PATCH_STORE(PR, NXT, NPS / 2, NPS));                                                        \
     H2_INTERLEAVE();                                                                              \
-    H2_PATCH_LOAD(PR, (C) + AHEAD);                                                               \
-    __syncthreads(); /* NXT fully written; every wavefront has fetched its last fragments of CUR */ \
-    H2_A_LOAD(af[0], NXT, 0);                                                                     \
-    H2_B_LOAD(bq[((S) + 3 + DIST) % RING], kq + 3 + DIST);                                        \
+    X_P(H2_PATCH_LOAD(PR, (C) + AHEAD));                                                               \
+    X_S(__syncthreads()); /* NXT fully written; every wavefront has fetched its last fragments of CUR */ \
+    X_A(H2_A_LOAD(af[0], NXT, 0));                                                                     \
+    X_B(H2_B_LOAD(bq[((S) + 3 + DIST) % RING], kq + 3 + DIST));                                        \
     H2_MFMA(af[1], bq[(S) + 3]);                                                                  \
     H2_INTERLEAVE();                                                                              \
     H_STAMP_CHUNK(2 + ((C) - c0 < 26 ? (C) - c0 : 26));                                           \
@@ -456,34 +471,29 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
     uint4 bq[RING][NPL];    // [ring slot][plane]
     __bf16* const buf0 = lds;
     __bf16* const buf1 = lds + NPL * PLANE;
-    H2_PATCH_LOAD(pr, c0);
+    H2_PATCH_LOAD(prs[0], c0);
 #pragma unroll
     for (int q = 0; q < DIST; ++q) H2_B_LOAD(bq[q], c0 * 4 + q);
-    H2_PATCH_STORE(pr, buf0, 0, NPS);
-    H2_PATCH_LOAD(pr, c0 + 1);
+    H2_PATCH_STORE(prs[0], buf0, 0, NPS);
+    // A chunk of the 64-row tile has 0.32 us of MFMA work and the L2 starts every launch cold: both operand streams see the Infinity Cache /
+    // HBM latency (1.5-1.9 us), and the loop runs at (that latency) / (depth of the prefetch): activations one chunk ahead 1.4 us per chunk
+    // (gemm_r2b), two ahead 0.74-0.94, four ahead 0.65-0.83 (profiles/r3_hgemm_timeline.txt).
+#pragma unroll
+    for (int k = 0; k < NSET; ++k) H2_PATCH_LOAD(prs[k], c0 + 1 + k);
     int c = c0;
-    if constexpr (DEEP) {
-      // A chunk of the 64-row tile lasts ~0.3 us, less than an L2 round trip: the activations are fetched TWO chunks ahead into
-      // alternating register sets (one chunk ahead left every chunk waiting ~0.7 us for its patch, gemm_r2b)
-      H2_PATCH_LOAD(pr2, c0 + 2);
-      __syncthreads();
-      H_STAMP(1);
-      H2_A_LOAD(af[0], buf0, 0);
-      for (; c + 1 < c1; c += 2) {
-        H2_CHUNK(0, buf0, buf1, c, pr);
-        H2_CHUNK(4, buf1, buf0, c + 1, pr2);
-      }
-      if (c < c1) H2_CHUNK(0, buf0, buf1, c, pr);
-    } else {
-      __syncthreads();
-      H_STAMP(1);
-      H2_A_LOAD(af[0], buf0, 0);
-      for (; c + 1 < c1; c += 2) {
-        H2_CHUNK(0, buf0, buf1, c, pr);
-        H2_CHUNK(4, buf1, buf0, c + 1, pr);
-      }
-      if (c < c1) H2_CHUNK(0, buf0, buf1, c, pr);
+    __syncthreads();
+    H_STAMP(1);
+    H2_A_LOAD(af[0], buf0, 0);
+    // the loop body covers U chunks = one common period of the LDS buffer (2), the staging set (NSET) and the ring base (RING / 4), so that
+    // every ring slot, buffer and register set is a compile-time constant; a shorter tail follows
+    constexpr int U = h2_lcm(h2_lcm(2, NSET), RING / 4);
+    for (; c + U - 1 < c1; c += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) H2_CHUNK((4 * u) % RING, ((u & 1) ? buf1 : buf0), ((u & 1) ? buf0 : buf1), c + u, prs[u % NSET]);
     }
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+      if (c + u < c1) H2_CHUNK((4 * u) % RING, ((u & 1) ? buf1 : buf0), ((u & 1) ? buf0 : buf1), c + u, prs[u % NSET]);
 #undef H2_PATCH_LOAD
 #undef H2_PATCH_STORE
 #undef H2_A_LOAD
@@ -491,6 +501,10 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
 #undef H2_MFMA
 #undef H2_INTERLEAVE
 #undef H2_CHUNK
+#undef X_B
+#undef X_P
+#undef X_S
+#undef X_A
   }
 
   H_STAMP(29);
