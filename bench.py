@@ -258,8 +258,14 @@ def main():
     local = int(os.environ.get("CGD_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     th.cuda.set_device(local)
     dev = f"cuda:{local}"
-    if world > 1:
+    # CGD_FORCE_COLLECTIVES=1 (test knob): a ONE-rank job still initialises the process group and runs every collective of the N > 1
+    # flow (weight broadcast, barriers, all_gather, all_reduce MAX) — RCCL on a 1-GPU box (tests/test_gpu_step.py)
+    dist_on = world > 1 or os.environ.get("CGD_FORCE_COLLECTIVES") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl":
             dist.init_process_group("nccl", device_id=th.device(dev))  # "nccl" is RCCL on ROCm
         else:
@@ -287,14 +293,20 @@ def main():
                 yield out
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         th.cuda.synchronize()
+
+    def launch_counts():
+        c = (C.c_uint64 * 2)()
+        ctx.lib.cgd_launch_counts(c)
+        return int(c[0]), int(c[1])
 
     steps = trajectory()
     for _ in range(args.warmup):
         next(steps)
     sync()
+    n0 = launch_counts()
     t0, c0 = time.perf_counter(), time.process_time()
     for _ in range(args.steps):
         out = next(steps)
@@ -302,6 +314,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_s = time.process_time() - c0  # CPU seconds (user + sys, all threads of this rank) spent driving the K steps
+    n1 = launch_counts()  # kernel launches of the library over the K timed steps (torch's own few elementwise / RNG launches not included)
     finite = bool(th.isfinite(out["sample"]).all().item())
     peak = float(out["sample"].abs().max().item())
     # host cost of ONE step in isolation (untimed, after the timed region): the queue is empty and the 4-slot upload ring is free, so the
@@ -325,6 +338,7 @@ def main():
         tp = time.perf_counter()
         for _ in range(args.profile_steps):
             next(steps)
+        assert ctx.lib.cgd_profile_kinds() == 5
         buf = (C.c_double * 15)()
         ctx.check(ctx.lib.cgd_profile_read(ctx.h, buf))
         dtp = time.perf_counter() - tp
@@ -337,6 +351,7 @@ def main():
             ach = flop / (ms * 1e-3) / 1e12
             return {"kernel": name, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                     "traffic": pmc_traffic(pmc_name) if args.config == 2 else None,
+                    "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass of this command; a constant in this line)",
                     "algorithmic_bytes_per_launch": algo_bytes if args.config == 2 else None,
                     "launches_per_step": n / ps, "avg_launch_us": round(ms * 1e3 / n, 2), "flop_per_launch": flop / n,
                     "kernel_time_share": round(ms * 1e-3 / dtp, 4), "mfma_products_per_flop": products,
@@ -385,7 +400,7 @@ def main():
     tdev = dev if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
     tmax = th.tensor([dt], device=tdev, dtype=th.float64)
     per_rank, host = [dt], [(cpu_s, t_enq, iso_wall, iso_cpu)]
-    if world > 1:
+    if dist_on:
         gathered = [th.zeros_like(tmax) for _ in range(world)]
         dist.all_gather(gathered, tmax)
         per_rank = [float(t.item()) for t in gathered]
@@ -412,7 +427,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["what"], "global_batch": world,
                        "parallelism": f"{world} independent samples (1/GPU), weights broadcast once over RCCL, no per-step collective",
-                       "world_size_checked": dist.get_world_size() if world > 1 else 1,
+                       "world_size_checked": dist.get_world_size() if dist_on else 1,
+                       "collectives": (f"{dist.get_backend()}: weight broadcast per network, barrier, all_gather, all_reduce(MAX)"
+                                       if dist_on else "none (single process)"),
                        "ms_per_step_per_rank": [round(t / args.steps * 1e3, 3) for t in per_rank],
                        # multi-GPU host readiness: CPU time each rank's driver process burns per step (user + sys,
                        # all threads) and the wall time it needs to ENQUEUE a step; the host keeps N ranks fed while
@@ -426,6 +443,8 @@ def main():
                        "host_cores": usable_cores(1 << 20),
                        "trajectory": f"chained: every step consumes the previous step's sample; chains of {start + 1} steps from "
                                      f"x_t = q_sample(x0*, t={start}) down to t = 0 (init-image prologue, skip_timesteps {N - 1 - start})",
+                       "launches_per_step": round((n1[0] - n0[0]) / args.steps, 1),
+                       "splitk_reduce_per_step": round((n1[1] - n0[1]) / args.steps, 1),
                        "timed_seconds": round(tmax, 3), "last_sample_peak": round(peak, 3),
                        "tflop_per_step": cfg["tflop"], "achieved_tflops_whole_step": round(cfg["tflop"] * args.steps / tmax, 2)},
         }
@@ -439,7 +458,7 @@ def main():
             except Exception as e:  # never lose the GPU number to a host-side problem
                 res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

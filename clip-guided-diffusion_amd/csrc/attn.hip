@@ -622,12 +622,12 @@ bool attn_mid_ok(const AttnShape& sh, int ldq, int ldo) { return sh.d == 64 && s
 }  // namespace
 
 int cgd_launch_softmax_rows(cgd_ctx* ctx, float* S, long rows, int T, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, S, rows, T, ld);
+  CGD_LAUNCH(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, S, rows, T, ld);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 int cgd_launch_softmax_bwd_rows(cgd_ctx* ctx, const float* P, float* dP, long rows, int T, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, P, dP, rows, T, ld);
+  CGD_LAUNCH(softmax_bwd_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, P, dP, rows, T, ld);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -641,10 +641,10 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   const HeadOff ho = head_off(sh);
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3)) {
     if (x3) {
-      hipLaunchKernelGGL((attn_s64_fwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
+      CGD_LAUNCH((attn_s64_fwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
                        1.f / sqrtf((float)d));
     } else {
-      hipLaunchKernelGGL((attn_s64_fwd_kernel<false>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
+      CGD_LAUNCH((attn_s64_fwd_kernel<false>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
                        1.f / sqrtf((float)d));
     }
     CGD_HIP(ctx, hipGetLastError());
@@ -652,10 +652,10 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   }
   if (attn_mid_ok(sh, ldq, ldo)) {
     if (x3) {
-      hipLaunchKernelGGL((attn_mid_fwd_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
+      CGD_LAUNCH((attn_mid_fwd_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, 1.f / sqrtf((float)d));
     } else {
-      hipLaunchKernelGGL((attn_mid_fwd_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
+      CGD_LAUNCH((attn_mid_fwd_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, 1.f / sqrtf((float)d));
     }
     CGD_HIP(ctx, hipGetLastError());
@@ -700,10 +700,10 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3)) {
     if (x3) {
-      hipLaunchKernelGGL((attn_s64_bwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
+      CGD_LAUNCH((attn_s64_bwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, alpha);
     } else {
-      hipLaunchKernelGGL((attn_s64_bwd_kernel<false>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
+      CGD_LAUNCH((attn_s64_bwd_kernel<false>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, alpha);
     }
     CGD_HIP(ctx, hipGetLastError());
@@ -711,17 +711,17 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   }
   if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3)) {
     if (x3) {
-      hipLaunchKernelGGL((attn_mid_bwd_dq_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
+      CGD_LAUNCH((attn_mid_bwd_dq_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
                        dqkv, lddq, T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
     } else {
-      hipLaunchKernelGGL((attn_mid_bwd_dq_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
+      CGD_LAUNCH((attn_mid_bwd_dq_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
                        dqkv, lddq, T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
     }
     if (x3) {
-      hipLaunchKernelGGL((attn_mid_bwd_dkv_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq,
+      CGD_LAUNCH((attn_mid_bwd_dkv_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq,
                        T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
     } else {
-      hipLaunchKernelGGL((attn_mid_bwd_dkv_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq,
+      CGD_LAUNCH((attn_mid_bwd_dkv_kernel<false>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.P, bufs.dP, dqkv, lddq,
                        T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
     }
     CGD_HIP(ctx, hipGetLastError());

@@ -48,6 +48,8 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_GEMV")) ctx->gemv_mode = atoi(e);
   if (const char* e = getenv("CGD_KCONV")) sscanf(e, "%d,%d,%d", &ctx->kconv_mode, &ctx->kconv_max_m, &ctx->kconv_min_chunks);
   if (const char* e = getenv("CGD_HCONV_SPLIT")) sscanf(e, "%d,%d", &ctx->hconv_slots, &ctx->hconv_min_chunks);
+  if (ctx->kconv_min_chunks < 1) ctx->kconv_min_chunks = 1;  // divisors of the split-K policy
+  if (ctx->hconv_min_chunks < 1) ctx->hconv_min_chunks = 1;
   if (const char* e = getenv("CGD_HCONV_SMALL")) sscanf(e, "%d,%d,%d", &ctx->hconv_small_m, &ctx->hconv_small_slots, &ctx->hconv_small_min_chunks);
   ctx->ws_bytes = (size_t)256 << 20;
   if (hipMalloc((void**)&ctx->ws, ctx->ws_bytes) != hipSuccess) {
@@ -124,6 +126,17 @@ int cgd_profile_read(cgd_ctx* ctx, double* out) {
     out[3 * k + 2] = ctx->prof_n[k];
     ctx->prof_ms[k] = ctx->prof_flops[k] = ctx->prof_n[k] = 0.0;
   }
+  return 0;
+}
+
+// number of profiled launch kinds = a third of the doubles cgd_profile_read writes (a caller sizes its buffer from this)
+int cgd_profile_kinds(void) { return CGD_PROF_KINDS; }
+
+// process-wide counters since load: out[0] = kernel launches of the library, out[1] = split-K reduce launches among them
+int cgd_launch_counts(unsigned long long* out2) {
+  if (!out2) return -3;
+  out2[0] = g_cgd_launches.load(std::memory_order_relaxed);
+  out2[1] = g_cgd_reduces.load(std::memory_order_relaxed);
   return 0;
 }
 }  // extern "C"

@@ -4,8 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 #include <vector>
+
+// process-wide launch counters (measurement: bench.py reports launches and split-K reduce launches per step): every kernel launch of
+// the library goes through CGD_LAUNCH
+inline std::atomic<unsigned long long> g_cgd_launches{0}, g_cgd_reduces{0};
+#define CGD_LAUNCH(...)                                          \
+  do {                                                           \
+    g_cgd_launches.fetch_add(1, std::memory_order_relaxed);      \
+    hipLaunchKernelGGL(__VA_ARGS__);                             \
+  } while (0)
 
 // ---- precision modes of the MFMA contractions ------------------------------------------------
 // 0: fp32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products, 157 TF peak

@@ -255,9 +255,9 @@ int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float
     if (sh2 <= 64 * 1024) {
       dim3 grid(cdiv(W, 64), cdiv(H, 4), Bn);
       if (Cin == 3)
-        hipLaunchKernelGGL((thin_in_direct_kernel<3>), grid, dim3(256), sh2, s, x, w, bias, y, ldy, H, W, Cout);
+        CGD_LAUNCH((thin_in_direct_kernel<3>), grid, dim3(256), sh2, s, x, w, bias, y, ldy, H, W, Cout);
       else
-        hipLaunchKernelGGL((thin_in_direct_kernel<6>), grid, dim3(256), sh2, s, x, w, bias, y, ldy, H, W, Cout);
+        CGD_LAUNCH((thin_in_direct_kernel<6>), grid, dim3(256), sh2, s, x, w, bias, y, ldy, H, W, Cout);
       CGD_HIP(ctx, hipGetLastError());
       return 0;
     }
@@ -271,10 +271,10 @@ int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float
       float* wp = ctx->ws + a_floats;
       const int g1 = (int)std::min<long>(cdiv(npix * (KP / 4), 256), 8192);
       if (Cin == 3)
-        hipLaunchKernelGGL((thin_im2col_kernel<3, 32>), dim3(g1), dim3(256), 0, s, x, a, Bn, H, W);
+        CGD_LAUNCH((thin_im2col_kernel<3, 32>), dim3(g1), dim3(256), 0, s, x, a, Bn, H, W);
       else
-        hipLaunchKernelGGL((thin_im2col_kernel<6, 64>), dim3(g1), dim3(256), 0, s, x, a, Bn, H, W);
-      hipLaunchKernelGGL(thin_padw_kernel, dim3(cdiv((long)Cout * KP, 256)), dim3(256), 0, s, w, wp, Cout, 9 * Cin, KP);
+        CGD_LAUNCH((thin_im2col_kernel<6, 64>), dim3(g1), dim3(256), 0, s, x, a, Bn, H, W);
+      CGD_LAUNCH(thin_padw_kernel, dim3(cdiv((long)Cout * KP, 256)), dim3(256), 0, s, w, wp, Cout, 9 * Cin, KP);
       GemmParams g;
       g.A = a; g.lda = KP;
       g.B = wp; g.ldb = KP;
@@ -290,9 +290,9 @@ int cgd_launch_conv_in(cgd_ctx* ctx, const float* x, const float* w, const float
   const size_t sh = (size_t)9 * Cin * Cout * sizeof(float);
   dim3 grid(cdiv(npix, ppb));
   if (Cin == 3)
-    hipLaunchKernelGGL((conv_in_kernel<3>), grid, dim3(256), sh, s, x, w, bias, y, ldy, Bn, H, W, Cout, ppb);
+    CGD_LAUNCH((conv_in_kernel<3>), grid, dim3(256), sh, s, x, w, bias, y, ldy, Bn, H, W, Cout, ppb);
   else if (Cin == 6)
-    hipLaunchKernelGGL((conv_in_kernel<6>), grid, dim3(256), sh, s, x, w, bias, y, ldy, Bn, H, W, Cout, ppb);
+    CGD_LAUNCH((conv_in_kernel<6>), grid, dim3(256), sh, s, x, w, bias, y, ldy, Bn, H, W, Cout, ppb);
   else
     CGD_FAIL(ctx, "conv_in: Cin must be 3 or 6");
   CGD_HIP(ctx, hipGetLastError());
@@ -311,7 +311,7 @@ int cgd_launch_conv_thin_out(cgd_ctx* ctx, const float* x, int ldx, const float*
     if ((t_floats + w_floats) * sizeof(float) <= ctx->ws_bytes) {
       float* T = ctx->ws;
       float* wt = ctx->ws + t_floats;
-      hipLaunchKernelGGL(thin_tapw_kernel, dim3(cdiv((long)NP * Cin, 256)), dim3(256), 0, s, w, wt, Cout, Cin, NP);
+      CGD_LAUNCH(thin_tapw_kernel, dim3(cdiv((long)NP * Cin, 256)), dim3(256), 0, s, w, wt, Cout, Cin, NP);
       GemmParams g;
       g.A = x; g.lda = ldx;
       g.B = wt; g.ldb = Cin;
@@ -320,9 +320,9 @@ int cgd_launch_conv_thin_out(cgd_ctx* ctx, const float* x, int ldx, const float*
       g.no_split = 1;
       CGD_TRY(cgd_launch_gemm(ctx, g, s));
       if (Cout == 3)
-        hipLaunchKernelGGL((thin_gather_kernel<3, 32>), dim3(cdiv(npix, 256)), dim3(256), 0, s, T, bias, y, Bn, H, W);
+        CGD_LAUNCH((thin_gather_kernel<3, 32>), dim3(cdiv(npix, 256)), dim3(256), 0, s, T, bias, y, Bn, H, W);
       else
-        hipLaunchKernelGGL((thin_gather_kernel<6, 64>), dim3(cdiv(npix, 256)), dim3(256), 0, s, T, bias, y, Bn, H, W);
+        CGD_LAUNCH((thin_gather_kernel<6, 64>), dim3(cdiv(npix, 256)), dim3(256), 0, s, T, bias, y, Bn, H, W);
       CGD_HIP(ctx, hipGetLastError());
       return 0;
     }
@@ -331,9 +331,9 @@ int cgd_launch_conv_thin_out(cgd_ctx* ctx, const float* x, int ldx, const float*
   if (sh > 160 * 1024) CGD_FAIL(ctx, "conv_thin_out: weights do not fit LDS");
   dim3 grid(cdiv(npix, ppb));
   if (Cout == 3)
-    hipLaunchKernelGGL((conv_thin_out_kernel<3>), grid, dim3(256), sh, s, x, ldx, w, bias, y, Bn, H, W, Cin, ppb);
+    CGD_LAUNCH((conv_thin_out_kernel<3>), grid, dim3(256), sh, s, x, ldx, w, bias, y, Bn, H, W, Cin, ppb);
   else if (Cout == 6)
-    hipLaunchKernelGGL((conv_thin_out_kernel<6>), grid, dim3(256), sh, s, x, ldx, w, bias, y, Bn, H, W, Cin, ppb);
+    CGD_LAUNCH((conv_thin_out_kernel<6>), grid, dim3(256), sh, s, x, ldx, w, bias, y, Bn, H, W, Cin, ppb);
   else
     CGD_FAIL(ctx, "conv_thin_out: Cout must be 3 or 6");
   CGD_HIP(ctx, hipGetLastError());

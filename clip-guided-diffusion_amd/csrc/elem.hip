@@ -178,7 +178,7 @@ int cgd_launch_pool2x2(cgd_ctx* ctx, const float* in, int ldi, float* out, int l
                        int Wo, int C, float scale, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (ldi & 3) || (ldo & 3)) CGD_FAIL(ctx, "pool2x2: C and strides must be multiples of 4");
-  hipLaunchKernelGGL(pool2x2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, ldi, out, ldo, add, ldadd, B,
+  CGD_LAUNCH(pool2x2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, ldi, out, ldo, add, ldadd, B,
                      Ho, Wo, C, scale);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -188,7 +188,7 @@ int cgd_launch_upsample2x(cgd_ctx* ctx, const float* in, int ldi, float* out, in
                           int Wo, int C, float scale, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (ldi & 3) || (ldo & 3)) CGD_FAIL(ctx, "upsample2x: C and strides must be multiples of 4");
-  hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, ldi, out, ldo, add, ldadd,
+  CGD_LAUNCH(upsample2x_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, ldi, out, ldo, add, ldadd,
                      B, Ho, Wo, C, scale);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -198,7 +198,7 @@ int cgd_launch_copy2d(cgd_ctx* ctx, const float* a, int lda, const float* b, int
                       hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (lda & 3) || (ldo & 3) || (b && (ldb & 3))) CGD_FAIL(ctx, "copy2d: C and strides must be multiples of 4");
-  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C);
+  CGD_LAUNCH(copy2d_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -207,20 +207,20 @@ int cgd_launch_concat2(cgd_ctx* ctx, const float* a, int lda, int Ca, const floa
                        hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((Ca & 3) || (Cb & 3) || (lda & 3) || (ldb & 3) || (ldo & 3)) CGD_FAIL(ctx, "concat2: channels and strides must be multiples of 4");
-  hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * ((Ca + Cb) / 4))), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, out, ldo, rows);
+  CGD_LAUNCH(concat2_kernel, dim3(grid_for(rows * ((Ca + Cb) / 4))), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, out, ldo, rows);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 
 int cgd_launch_act_fwd(cgd_ctx* ctx, const float* x, float* y, long n, int act, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
-  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, act);
+  CGD_LAUNCH(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, act);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 int cgd_launch_act_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx, long n, int act, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, dy, dx, n, act);
+  CGD_LAUNCH(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, dy, dx, n, act);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -228,43 +228,43 @@ int cgd_launch_act_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx,
 int cgd_launch_transpose(cgd_ctx* ctx, const float* in, int ldi, long si, float* out, int ldo, long so, int R, int Cc, int nb,
                          hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
-  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(ldo, 32), nb), dim3(32, 8), 0, s, in, ldi, si, out, ldo, so, R, Cc);
+  CGD_LAUNCH(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(ldo, 32), nb), dim3(32, 8), 0, s, in, ldi, si, out, ldo, so, R, Cc);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 
 int cgd_launch_timestep_embedding(cgd_ctx* ctx, const float* t, const float* freqs, float* out, int B, int dim, hipStream_t s) {
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(B), dim3(128), 0, s, t, freqs, out, dim);
+  CGD_LAUNCH(timestep_embedding_kernel, dim3(B), dim3(128), 0, s, t, freqs, out, dim);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 
 int cgd_launch_embedding_add(cgd_ctx* ctx, const float* table, const int64_t* idx, float* out, int B, int dim, hipStream_t s) {
-  hipLaunchKernelGGL(embedding_add_kernel, dim3(B), dim3(256), 0, s, table, idx, out, dim);
+  CGD_LAUNCH(embedding_add_kernel, dim3(B), dim3(256), 0, s, table, idx, out, dim);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 
 int cgd_launch_vit_tokens(cgd_ctx* ctx, const float* patch, const float* cls, const float* pos, float* tok, int N, int L, int W,
                           hipStream_t s) {
-  hipLaunchKernelGGL(vit_tokens_kernel, dim3(grid_for((long)N * L * W)), dim3(256), 0, s, patch, cls, pos, tok, N, L, W);
+  CGD_LAUNCH(vit_tokens_kernel, dim3(grid_for((long)N * L * W)), dim3(256), 0, s, patch, cls, pos, tok, N, L, W);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 
 int cgd_launch_patchify(cgd_ctx* ctx, const float* img, float* cols, int N, int res, int P, hipStream_t s) {
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)N * 3 * res * res)), dim3(256), 0, s, (float*)img, cols, N, res, P, 0);
+  CGD_LAUNCH(patchify_kernel, dim3(grid_for((long)N * 3 * res * res)), dim3(256), 0, s, (float*)img, cols, N, res, P, 0);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 int cgd_launch_unpatchify(cgd_ctx* ctx, const float* cols, float* img, int N, int res, int P, hipStream_t s) {
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)N * 3 * res * res)), dim3(256), 0, s, img, (float*)cols, N, res, P, 1);
+  CGD_LAUNCH(patchify_kernel, dim3(grid_for((long)N * 3 * res * res)), dim3(256), 0, s, img, (float*)cols, N, res, P, 1);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 
 int cgd_launch_fill(cgd_ctx* ctx, float* p, long n, float v, hipStream_t s) {
-  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, n, v);
+  CGD_LAUNCH(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, n, v);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }

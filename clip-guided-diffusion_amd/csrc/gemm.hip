@@ -444,7 +444,7 @@ template <int MODE, int BM, int BN, int WM, int WN, int PF>
 void launch_cfg(const GemmParams& p, hipStream_t s) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, p.splitk > 1 ? p.splitk : p.nbatch);
-  hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, PF>), grid, dim3(NT), 0, s, p.A, p.B, p.C, p.bias, p.R, p.ws, p);
+  CGD_LAUNCH((igemm_kernel<MODE, BM, BN, WM, WN, PF>), grid, dim3(NT), 0, s, p.A, p.B, p.C, p.bias, p.R, p.ws, p);
 }
 
 // tile codes: 64 = 64x64, 128 = 128x128, 256 = 256x128 (8 waves), 257 = 128x256 (wave tile 64x128);
@@ -512,7 +512,8 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   if (tile == 512 && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: halo conv kernel does not support this problem");
   // weight-streaming variant for the small maps (kconv.hip): tile code 516; also takes the 8-pixel-wide maps from igemm
   const bool kc_forced = tile == 516;
-  if (kc_forced || (!tile && ctx->kconv_mode && p.M <= ctx->kconv_max_m && p.M % (p.H > 0 && p.W > 0 ? p.H * p.W : 1) == 0)) {
+  // (cgd_set_hconv(mode 0) takes the small maps off the halo kernels too: tools that A/B through the setter measure igemm)
+  if (kc_forced || (!tile && ctx->kconv_mode && ctx->hconv_mode && p.M <= ctx->kconv_max_m && p.M % (p.H > 0 && p.W > 0 ? p.H * p.W : 1) == 0)) {
     if (cgd_kconv_supported(ctx, p)) {
       const long tiles = cgd_kconv_tiles_m(p) * (p.N >> 5);
       const int nchunk = p.Cin / 32;
@@ -625,11 +626,20 @@ int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s) {
   const PendingReduce& q = ctx->pending;
   const long total = (long)q.M * q.src.N;
   const int blocks = (int)std::min<long>(cdiv(cdiv(total, 4), 256), 4096);
-  (void)s;  // the reduction is ordered behind its slices: it always runs on the stream that produced them
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, q.stream, q.src.ws, q.src.n, q.M, q.src.N, q.C, q.ldc, q.src.bias,
+  g_cgd_reduces.fetch_add(1, std::memory_order_relaxed);
+  CGD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, q.stream, q.src.ws, q.src.n, q.M, q.src.N, q.C, q.ldc, q.src.bias,
                      q.src.R, q.src.ldr, q.src.alpha);
   ctx->pending.valid = false;
   CGD_HIP(ctx, hipGetLastError());
+  // The reduction always runs on the stream that produced the slices.  A caller on ANOTHER stream (it is about to read C or to overwrite the
+  // workspace) is ordered behind it with an event (the one-stream-per-context habit of the callers is no longer load-bearing)
+  if (s != q.stream) {
+    hipEvent_t ev = nullptr;
+    CGD_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    CGD_HIP(ctx, hipEventRecord(ev, q.stream));
+    CGD_HIP(ctx, hipStreamWaitEvent(s, ev, 0));
+    CGD_HIP(ctx, hipEventDestroy(ev));  // released once the recorded work has completed
+  }
   return 0;
 }
 
@@ -657,7 +667,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (kernel == 3) {
     const int blocks = (int)std::min<long>(std::max<long>(cdiv(p.N, 16), 1), 4L * ctx->num_cu);
     const size_t sh = (size_t)p.M * p.K * sizeof(float);
-#define GV_LAUNCH(MR_) hipLaunchKernelGGL((gemv_kernel<MR_>), dim3(blocks), dim3(256), sh, s, p.A, p.lda, p.B, p.ldb, p.C, p.ldc, p.bias, p.R, p.ldr, p.N, p.K, p.alpha)
+#define GV_LAUNCH(MR_) CGD_LAUNCH((gemv_kernel<MR_>), dim3(blocks), dim3(256), sh, s, p.A, p.lda, p.B, p.ldb, p.C, p.ldc, p.bias, p.R, p.ldr, p.N, p.K, p.alpha)
     switch (p.M) {
       case 1: GV_LAUNCH(1); break;
       case 2: GV_LAUNCH(2); break;

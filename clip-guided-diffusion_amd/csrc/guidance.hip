@@ -344,10 +344,16 @@ int cgd_launch_cutouts_fwd(cgd_ctx* ctx, const float* x_in, const int* coords, f
   if (layout && (P <= 0 || cs % P)) CGD_FAIL(ctx, "cutouts: cut size must be a multiple of the patch size");
   // FastDiv is exact while numerator * divisor < 2^32: bin numerators (cs + 1) * max(H, W) by cs, pixel index cs^2 by cs
   const long mx = std::max(H, W);
-  if (cs <= 0 || (long)(cs + 1) * mx * cs >= (1L << 32) || (long)cs * cs * cs >= (1L << 32) || (long)cutn * B * 3 > 65535)
+  if (cs <= 0 || (long)(cs + 1) * mx * cs >= (1L << 32) || (long)cs * cs * cs >= (1L << 32) || (long)B * 3 > 65535)
     CGD_FAIL(ctx, "cutouts: size out of range");
-  hipLaunchKernelGGL(cutouts_fwd_kernel, dim3(cdiv((long)cs * cs, 256), cutn * B * 3), dim3(256), 0, s, x_in, coords, out, B, H, W, cutn, cs,
-                     layout, P, FastDiv((unsigned)cs), FastDiv((unsigned)(layout ? P : 1)));
+  // grid.y holds (cut, b, c) planes and is limited to 65535: any number of cutouts runs as launches over runs of cuts (both
+  // output layouts index by cut * B + b, so a run starts 3 cs^2 floats per (cut, b) further into `out`)
+  const int per = (int)std::min<long>(cutn, 65535 / ((long)B * 3));
+  for (int k0 = 0; k0 < cutn; k0 += per) {
+    const int nk = std::min(per, cutn - k0);
+    CGD_LAUNCH(cutouts_fwd_kernel, dim3(cdiv((long)cs * cs, 256), nk * B * 3), dim3(256), 0, s, x_in, coords + 4 * k0,
+               out + (long)k0 * B * 3 * cs * cs, B, H, W, nk, cs, layout, P, FastDiv((unsigned)cs), FastDiv((unsigned)(layout ? P : 1)));
+  }
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -357,11 +363,16 @@ int cgd_launch_cutouts_bwd(cgd_ctx* ctx, const float* dout, const int* coords, f
   if (layout && (P <= 0 || cs % P)) CGD_FAIL(ctx, "cutouts: cut size must be a multiple of the patch size");
   // FastDiv is exact while numerator * divisor < 2^32: (crop extent * cs) by the extent, (cs + 1) * extent by cs, pixel index by W
   const long mx = std::max(H, W);
-  if (cs <= 0 || mx * mx * cs >= (1L << 32) || (long)(cs + 1) * mx * cs >= (1L << 32) || (long)H * W * W >= (1L << 32) || cutn > CB_MAXCUT ||
-      (long)B * 3 > 65535)
+  if (cs <= 0 || mx * mx * cs >= (1L << 32) || (long)(cs + 1) * mx * cs >= (1L << 32) || (long)H * W * W >= (1L << 32) || (long)B * 3 > 65535)
     CGD_FAIL(ctx, "cutouts: size out of range");
-  hipLaunchKernelGGL(cutouts_bwd_kernel, dim3(cdiv((long)H * W * CB_SUB, 256), B * 3), dim3(256), 0, s, dout, coords, G, B, H, W, cutn,
-                     cs, layout, P, accumulate, FastDiv((unsigned)cs), FastDiv((unsigned)(layout ? P : 1)), FastDiv((unsigned)W));
+  // the kernel keeps the per-cut division constants in a CB_MAXCUT-entry LDS table: more cutouts than that (the reference's num_cutouts has
+  // no limit) run as further launches over the next CB_MAXCUT cuts that accumulate into G
+  for (int k0 = 0; k0 < cutn; k0 += CB_MAXCUT) {
+    const int nk = std::min(CB_MAXCUT, cutn - k0);
+    CGD_LAUNCH(cutouts_bwd_kernel, dim3(cdiv((long)H * W * CB_SUB, 256), B * 3), dim3(256), 0, s, dout + (long)k0 * B * 3 * cs * cs,
+               coords + 4 * k0, G, B, H, W, nk, cs, layout, P, (accumulate || k0 > 0) ? 1 : 0, FastDiv((unsigned)cs),
+               FastDiv((unsigned)(layout ? P : 1)), FastDiv((unsigned)W));
+  }
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -369,7 +380,7 @@ int cgd_launch_cutouts_bwd(cgd_ctx* ctx, const float* dout, const int* coords, f
 int cgd_launch_spherical_loss(cgd_ctx* ctx, const float* emb, const float* targets_n, const float* weights, float* demb,
                               float* loss_part, int cutn, int B, int P, int D, float scale, hipStream_t s) {
   if (D > 2048) CGD_FAIL(ctx, "spherical loss: embedding dim > 2048");
-  hipLaunchKernelGGL(spherical_loss_kernel, dim3(cutn * B), dim3(64), 0, s, emb, targets_n, weights, demb, loss_part, B, P, D,
+  CGD_LAUNCH(spherical_loss_kernel, dim3(cutn * B), dim3(64), 0, s, emb, targets_n, weights, demb, loss_part, B, P, D,
                      scale / (float)cutn);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -377,7 +388,7 @@ int cgd_launch_spherical_loss(cgd_ctx* ctx, const float* emb, const float* targe
 
 int cgd_launch_pmv_blend(cgd_ctx* ctx, const float* x, const float* out6, float* x0, float* mean, float* logvar, float* xin, int B,
                          int H, int W, const StepCoef& k, hipStream_t s) {
-  hipLaunchKernelGGL(pmv_blend_kernel, dim3(grid_for((long)B * 3 * H * W)), dim3(256), 0, s, x, out6, x0, mean, logvar, xin, B,
+  CGD_LAUNCH(pmv_blend_kernel, dim3(grid_for((long)B * 3 * H * W)), dim3(256), 0, s, x, out6, x0, mean, logvar, xin, B,
                      3 * H * W, k);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -388,7 +399,7 @@ int cgd_guidance_part_blocks(int B, int H, int W) { return grid_for((long)B * 3 
 int cgd_launch_guidance_combine(cgd_ctx* ctx, const float* gclip, const float* xin, const float* x0, float* gdir, float* seed6,
                                 float* part, int B, int H, int W, const StepCoef& k, float tv_scale, float range_scale,
                                 float sat_scale, hipStream_t s) {
-  hipLaunchKernelGGL(guidance_combine_kernel, dim3(grid_for((long)B * 3 * H * W)), dim3(256), 0, s, gclip, xin, x0, gdir, seed6, part,
+  CGD_LAUNCH(guidance_combine_kernel, dim3(grid_for((long)B * 3 * H * W)), dim3(256), 0, s, gclip, xin, x0, gdir, seed6, part,
                      B, H, W, k, tv_scale, range_scale, sat_scale);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -397,7 +408,7 @@ int cgd_launch_guidance_combine(cgd_ctx* ctx, const float* gclip, const float* x
 int cgd_launch_grad_finish(cgd_ctx* ctx, const float* gdir, const float* gunet, float* g, float* part, int B, int H, int W,
                            hipStream_t s) {
   const long total = (long)B * 3 * H * W;
-  hipLaunchKernelGGL(grad_finish_kernel, dim3(grid_for(total)), dim3(256), 0, s, gdir, gunet, g, part, total);
+  CGD_LAUNCH(grad_finish_kernel, dim3(grid_for(total)), dim3(256), 0, s, gdir, gunet, g, part, total);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -406,7 +417,7 @@ int cgd_launch_scalars(cgd_ctx* ctx, const float* clip_part, int n_clip, const f
                        int use_magnitude, float* scalars, hipStream_t s) {
   const long total = (long)B * 3 * H * W;
   const int nb = grid_for(total);
-  hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, s, clip_part, n_clip, l_part, nb, g_part, nb, total, use_magnitude,
+  CGD_LAUNCH(scalars_kernel, dim3(1), dim3(256), 0, s, clip_part, n_clip, l_part, nb, g_part, nb, total, use_magnitude,
                      scalars);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -416,7 +427,7 @@ int cgd_launch_sample_update(cgd_ctx* ctx, const float* x, const float* x0, cons
                              const float* noise, const float* scalars, float* sample, float* x0_out, int B, int H, int W,
                              const StepCoef& k, int mode, hipStream_t s) {
   const long total = (long)B * 3 * H * W;
-  hipLaunchKernelGGL(sample_update_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, x0, mean, logvar, g, noise, scalars, sample,
+  CGD_LAUNCH(sample_update_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, x0, mean, logvar, g, noise, scalars, sample,
                      x0_out, total, k, mode);
   CGD_HIP(ctx, hipGetLastError());
   return 0;

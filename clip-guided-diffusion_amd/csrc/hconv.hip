@@ -374,7 +374,7 @@ size_t cgd_hconv_packed_floats(int Co, int Ci) { return (size_t)Co * Ci * 9; }  
 int cgd_pack_conv3x3_frag(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, hipStream_t s) {
   if ((Co & 31) || (Ci & 31)) CGD_FAIL(ctx, "pack_conv3x3_frag: channels must be multiples of 32");
   const long total = (long)Co * Ci * 9;
-  hipLaunchKernelGGL(pack_frag_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
+  CGD_LAUNCH(pack_frag_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -418,9 +418,9 @@ int cgd_launch_hconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
 #define HC2_LAUNCH(M_, TH_, NJ_)                                                                                                   \
   {                                                                                                                                \
     if (p.gn)                                                                                                                      \
-      hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_, true>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p);  \
+      CGD_LAUNCH((hconv2_kernel<M_, TH_, NJ_, true>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p);  \
     else                                                                                                                           \
-      hipLaunchKernelGGL((hconv2_kernel<M_, TH_, NJ_, false>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p); \
+      CGD_LAUNCH((hconv2_kernel<M_, TH_, NJ_, false>), grid, dim3(TH_ * 32), 0, s, p.A, p.Bp, p.C, p.bias, p.R, p.ws, p.gn, p); \
   }
 #define HC2_LAUNCH_T(M_, NJ_)  \
   {                            \

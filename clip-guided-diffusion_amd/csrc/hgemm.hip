@@ -703,7 +703,7 @@ static const void* cgd_frag_cache_get(cgd_ctx* ctx, const float* w, int N, int K
   e.w = w; e.N = N; e.K = K; e.ldw = ldw; e.packed = nullptr;
   if (hipMalloc(&e.packed, (size_t)N * K * sizeof(float)) != hipSuccess) return nullptr;
   const long total = (long)N * K;
-  hipLaunchKernelGGL(pack_frag_linear_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, ldw, (__bf16*)e.packed, N, K);
+  CGD_LAUNCH(pack_frag_linear_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, ldw, (__bf16*)e.packed, N, K);
   ctx->frag_cache.push_back(e);
   return e.packed;
 }
@@ -741,7 +741,7 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
       ctx->frag_tmp_bytes = need;
     }
     const long total = (long)g.N * g.K;
-    hipLaunchKernelGGL(pack_frag_linear_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, g.B, g.ldb,
+    CGD_LAUNCH(pack_frag_linear_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, g.B, g.ldb,
                        (__bf16*)ctx->frag_tmp, g.N, g.K);
     packed = ctx->frag_tmp;
   }
@@ -762,11 +762,11 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
     CGD_FAIL(ctx, "hgemm: skip_group needs hgemm2 in one slice without residual / activation operands");
 #define HG_ARGS grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p
   if (!v2) {
-    if (x3) hipLaunchKernelGGL((hgemm_kernel<1>), HG_ARGS); else hipLaunchKernelGGL((hgemm_kernel<2>), HG_ARGS);
+    if (x3) CGD_LAUNCH((hgemm_kernel<1>), HG_ARGS); else CGD_LAUNCH((hgemm_kernel<2>), HG_ARGS);
   } else if (tm == 64) {
-    if (x3) hipLaunchKernelGGL((hgemm2_kernel<1, 64>), HG_ARGS); else hipLaunchKernelGGL((hgemm2_kernel<2, 64>), HG_ARGS);
+    if (x3) CGD_LAUNCH((hgemm2_kernel<1, 64>), HG_ARGS); else CGD_LAUNCH((hgemm2_kernel<2, 64>), HG_ARGS);
   } else {
-    if (x3) hipLaunchKernelGGL((hgemm2_kernel<1, 128>), HG_ARGS); else hipLaunchKernelGGL((hgemm2_kernel<2, 128>), HG_ARGS);
+    if (x3) CGD_LAUNCH((hgemm2_kernel<1, 128>), HG_ARGS); else CGD_LAUNCH((hgemm2_kernel<2, 128>), HG_ARGS);
   }
 #undef HG_ARGS
   return 0;

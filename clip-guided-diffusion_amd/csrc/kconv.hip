@@ -320,7 +320,7 @@ int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   dim3 grid((int)(cgd_kconv_tiles_m(g) * (g.N >> 5)), 1, g.splitk > 1 ? g.splitk : 1);
 #define KC_LAUNCH(M_, GN_) \
-  hipLaunchKernelGGL((kconv_kernel<M_, GN_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
+  CGD_LAUNCH((kconv_kernel<M_, GN_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
   if (ctx->precision == CGD_PREC_BF16X3) {
     if (g.gn_ab) KC_LAUNCH(1, true); else KC_LAUNCH(1, false);
   } else {

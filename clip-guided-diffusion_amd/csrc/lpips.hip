@@ -266,7 +266,7 @@ int Lpips::features(const float* x, int Bn, int Hh, int Ww, hipStream_t s) {
   B = Bn; H = Hh; W = Ww;
   const long hw = (long)H * W, tot = (long)B * 3 * hw;
   CGD_TRY(ensure(xs, (size_t)tot));
-  hipLaunchKernelGGL(lp_scaling_fwd_kernel, dim3(grid_of(tot)), dim3(256), 0, s, x, xs.p, hw, tot, kShift[0], kShift[1], kShift[2], kScale[0],
+  CGD_LAUNCH(lp_scaling_fwd_kernel, dim3(grid_of(tot)), dim3(256), 0, s, x, xs.p, hw, tot, kShift[0], kShift[1], kShift[2], kScale[0],
                      kScale[1], kScale[2]);
   int h = H, w = W;
   for (int l = 0; l < NCONV; ++l) {
@@ -275,7 +275,7 @@ int Lpips::features(const float* x, int Bn, int Hh, int Ww, hipStream_t s) {
     if (pooled_in(l)) {
       h >>= 1; w >>= 1;
       CGD_TRY(ensure(c.pin, (size_t)B * h * w * c.cin));
-      hipLaunchKernelGGL(lp_maxpool_fwd_kernel, dim3(grid_of((long)B * h * w * (c.cin / 4))), dim3(256), 0, s, in, c.pin.p, B, h, w, c.cin);
+      CGD_LAUNCH(lp_maxpool_fwd_kernel, dim3(grid_of((long)B * h * w * (c.cin / 4))), dim3(256), 0, s, in, c.pin.p, B, h, w, c.cin);
       in = c.pin.p;
     }
     const long M = (long)B * h * w;
@@ -288,7 +288,7 @@ int Lpips::features(const float* x, int Bn, int Hh, int Ww, hipStream_t s) {
       g.M = (int)M; g.N = c.cout; g.conv = 1; g.H = h; g.W = w; g.Cin = c.cin;
       CGD_TRY(cgd_launch_gemm(ctx, g, s));
     }
-    hipLaunchKernelGGL(lp_relu_kernel, dim3(grid_of(M * c.cout / 4)), dim3(256), 0, s, c.a.p, M * c.cout / 4);
+    CGD_LAUNCH(lp_relu_kernel, dim3(grid_of(M * c.cout / 4)), dim3(256), 0, s, c.a.p, M * c.cout / 4);
     if (replay_on && in_loss_grad && replay[l])
       CGD_HIP(ctx, hipMemcpyAsync(c.a.p, replay[l], (size_t)M * c.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
@@ -306,7 +306,7 @@ int Lpips::set_reference(const float* ref, int Bn, int Hh, int Ww, hipStream_t s
     if (k < 0) continue;
     const long M = (long)B * h * w;
     CGD_TRY(ensure(n0[k], (size_t)M * cv[l].cout));
-    hipLaunchKernelGGL((lp_tap_kernel<true>), dim3((int)((M + 3) / 4)), dim3(256), 0, s, cv[l].a.p, n0[k].p, nullptr, nullptr, nullptr, M,
+    CGD_LAUNCH((lp_tap_kernel<true>), dim3((int)((M + 3) / 4)), dim3(256), 0, s, cv[l].a.p, n0[k].p, nullptr, nullptr, nullptr, M,
                        cv[l].cout, 0.f);
   }
   CGD_HIP(ctx, hipGetLastError());
@@ -339,9 +339,9 @@ int Lpips::loss_grad(const float* x, float gscale, float* loss, float* g, int ac
     const long nblk = (M + 3) / 4;
     CGD_TRY(ensure(dtap[k], (size_t)M * cv[l].cout));
     CGD_TRY(ensure(part, (size_t)nblk));
-    hipLaunchKernelGGL((lp_tap_kernel<false>), dim3((int)nblk), dim3(256), 0, s, cv[l].a.p, n0[k].p, lin[k], dtap[k].p, part.p, M, cv[l].cout,
+    CGD_LAUNCH((lp_tap_kernel<false>), dim3((int)nblk), dim3(256), 0, s, cv[l].a.p, n0[k].p, lin[k], dtap[k].p, part.p, M, cv[l].cout,
                        gscale / (float)hw);
-    hipLaunchKernelGGL(lp_loss_reduce_kernel, dim3(B), dim3(256), 0, s, part.p, hw / 4, 1.f / (float)hw, loss);
+    CGD_LAUNCH(lp_loss_reduce_kernel, dim3(B), dim3(256), 0, s, part.p, hw / 4, 1.f / (float)hw, loss);
   }
   // backward through the trunk
   const float* dnext = nullptr;  // gradient w.r.t. the INPUT of conv l+1 (same resolution as its input)
@@ -355,18 +355,18 @@ int Lpips::loss_grad(const float* x, float gscale, float* loss, float* g, int ac
     } else if (pooled_in(l + 1)) {
       // a_l -> max-pool -> conv l+1: route the pooled gradient back and add the tap gradient (every pooled layer is a tap)
       CGD_TRY(ensure(c.da, (size_t)M * c.cout));
-      hipLaunchKernelGGL(lp_maxpool_bwd_kernel, dim3(grid_of((long)B * hs[l + 1] * ws_[l + 1] * (c.cout / 4))), dim3(256), 0, s, c.a.p, dnext,
+      CGD_LAUNCH(lp_maxpool_bwd_kernel, dim3(grid_of((long)B * hs[l + 1] * ws_[l + 1] * (c.cout / 4))), dim3(256), 0, s, c.a.p, dnext,
                          k >= 0 ? dtap[k].p : nullptr, c.da.p, B, hs[l + 1], ws_[l + 1], c.cout);
       da = c.da.p;
     } else {
       da = const_cast<float*>(dnext);  // plain chain: conv l+1's input gradient is this activation's gradient
     }
-    hipLaunchKernelGGL(lp_relu_bwd_kernel, dim3(grid_of(M * c.cout / 4)), dim3(256), 0, s, c.a.p, da, M * c.cout / 4);
+    CGD_LAUNCH(lp_relu_bwd_kernel, dim3(grid_of(M * c.cout / 4)), dim3(256), 0, s, c.a.p, da, M * c.cout / 4);
     if (l == 0) {
       const long hw = (long)H * W, tot = (long)B * 3 * hw;
       CGD_TRY(ensure(dxs, (size_t)tot));
       CGD_TRY(cgd_launch_conv_thin_out(ctx, da, c.cout, c.wd, nullptr, dxs.p, B, H, W, c.cout, 3, s));
-      hipLaunchKernelGGL(lp_scaling_bwd_kernel, dim3(grid_of(tot)), dim3(256), 0, s, dxs.p, g, hw, tot, 1.f, accumulate, kScale[0], kScale[1],
+      CGD_LAUNCH(lp_scaling_bwd_kernel, dim3(grid_of(tot)), dim3(256), 0, s, dxs.p, g, hw, tot, 1.f, accumulate, kScale[0], kScale[1],
                          kScale[2]);
     } else {
       DevBuf& din = pooled_in(l) ? c.dpin : cv[l - 1].da;

@@ -960,7 +960,7 @@ void launch_gn_small_fwd(const float* x, int ldx, float* y, int ldy, int B, int 
   int lg = 0;
   while ((1 << lg) < cq) ++lg;
   const bool cache = (long)HW <= 8L * (GS_NT >> lg) && !getenv("CGD_GN_NOCACHE");  // <= 8 vectors per thread: single read
-#define GN_SF(V_, C_) hipLaunchKernelGGL((gn_small_fwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, (float*)x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps, stats, coef, src)
+#define GN_SF(V_, C_) CGD_LAUNCH((gn_small_fwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, (float*)x, ldx, y, ldy, HW, C, lg, gamma, beta, film, ldfilm, eps, stats, coef, src)
   if (v4) {
     if (cache) GN_SF(4, true); else GN_SF(4, false);
   } else {
@@ -979,7 +979,7 @@ void launch_gn_small_bwd(const float* x, int ldx, const float* dz, int lddz, flo
   int lg = 0;
   while ((1 << lg) < cq) ++lg;
   const bool cache = (long)HW <= 4L * (GS_NT >> lg) && !getenv("CGD_GN_NOCACHE");  // <= 4 vectors of x and of dz per thread
-#define GN_SB(V_, C_) hipLaunchKernelGGL((gn_small_bwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, (float*)dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, HW, C, lg, stats, coef, src)
+#define GN_SB(V_, C_) CGD_LAUNCH((gn_small_bwd_kernel<ACT, V_, C_>), dim3(32, B), dim3(GS_NT), 0, s, x, ldx, dz, (float*)dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, HW, C, lg, stats, coef, src)
   if (v4) {
     if (cache) GN_SB(4, true); else GN_SB(4, false);
   } else {
@@ -1064,14 +1064,14 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, (float*)x, ldx, HW, C, chunk, part, src);
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats, gamma, beta, film,
+  CGD_LAUNCH(gn_stats_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, (float*)x, ldx, HW, C, chunk, part, src);
+  CGD_LAUNCH(gn_stats_final_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, HW, chunk, C / 32, eps, stats, gamma, beta, film,
                      ldfilm, coef);
   if (y) {
     if (act)
-      hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+      CGD_LAUNCH((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
     else
-      hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+      CGD_LAUNCH((gn_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
   }
   CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
   cgd_prof_push(ctx, &pr);
@@ -1104,16 +1104,16 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
     return 0;
   }
   if (act) {
-    hipLaunchKernelGGL((gn_bwd_partial_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
+    CGD_LAUNCH((gn_bwd_partial_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
   } else {
-    hipLaunchKernelGGL((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
+    CGD_LAUNCH((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
   }
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
+  CGD_LAUNCH(gn_bwd_coef_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
   if (act) {
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
+    CGD_LAUNCH((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
                        HW, C, chunk, coef, bcoef);
   } else {
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
+    CGD_LAUNCH((gn_bwd_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
                        HW, C, chunk, coef, bcoef);
   }
   CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
@@ -1136,13 +1136,13 @@ int cgd_launch_ln_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
     src = SplitSrc();
   }
   if (!vec) {
-    hipLaunchKernelGGL(ln_fwd_generic_kernel, grid, blk, 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps, stats);
+    CGD_LAUNCH(ln_fwd_generic_kernel, grid, blk, 0, s, x, ldx, y, ldy, rows, C, gamma, beta, eps, stats);
   } else {
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
-      case 2: hipLaunchKernelGGL((ln_fwd_kernel<2>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
-      case 3: hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
-      default: hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
+      case 1: CGD_LAUNCH((ln_fwd_kernel<1>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
+      case 2: CGD_LAUNCH((ln_fwd_kernel<2>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
+      case 3: CGD_LAUNCH((ln_fwd_kernel<3>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
+      default: CGD_LAUNCH((ln_fwd_kernel<4>), grid, blk, 0, s, x, (float*)x, ldx, y, ldy, rows, gamma, beta, eps, stats, src); break;
     }
   }
   CGD_HIP(ctx, hipGetLastError());
@@ -1163,13 +1163,13 @@ int cgd_launch_ln_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dy, in
     src = SplitSrc();
   }
   if (!vec) {
-    hipLaunchKernelGGL(ln_bwd_generic_kernel, grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, C, gamma, stats);
+    CGD_LAUNCH(ln_bwd_generic_kernel, grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, C, gamma, stats);
   } else {
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
-      case 2: hipLaunchKernelGGL((ln_bwd_kernel<2>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
-      case 3: hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
-      default: hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
+      case 1: CGD_LAUNCH((ln_bwd_kernel<1>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
+      case 2: CGD_LAUNCH((ln_bwd_kernel<2>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
+      case 3: CGD_LAUNCH((ln_bwd_kernel<3>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
+      default: CGD_LAUNCH((ln_bwd_kernel<4>), grid, blk, 0, s, x, ldx, dy, lddy, dx, lddx, add, ldadd, rows, gamma, stats, src); break;
     }
   }
   CGD_HIP(ctx, hipGetLastError());

@@ -289,9 +289,9 @@ struct ResNet : NetBase {
     }
     return v;
   }
-  void relu(float* x, long n, hipStream_t s) { hipLaunchKernelGGL(rn_relu_kernel, dim3(rn_grid(n / 4)), dim3(256), 0, s, x, n / 4); }
+  void relu(float* x, long n, hipStream_t s) { CGD_LAUNCH(rn_relu_kernel, dim3(rn_grid(n / 4)), dim3(256), 0, s, x, n / 4); }
   void relu_bwd(const float* a, float* da, long n, hipStream_t s) {
-    hipLaunchKernelGGL(rn_relu_bwd_kernel, dim3(rn_grid(n / 4)), dim3(256), 0, s, a, da, n / 4);
+    CGD_LAUNCH(rn_relu_bwd_kernel, dim3(rn_grid(n / 4)), dim3(256), 0, s, a, da, n / 4);
   }
 };
 
@@ -355,7 +355,7 @@ int ResNet::fold(ConvBN& c, hipStream_t s) {
   }
   CGD_HIP(ctx, hipMemsetAsync(c.w, 0, nw * sizeof(float), s));
   CGD_HIP(ctx, hipMemsetAsync(c.bias, 0, (size_t)c.coutP * sizeof(float), s));
-  hipLaunchKernelGGL(rn_fold_bn_kernel, dim3(rn_grid((long)c.cout * c.cin * kk)), dim3(256), 0, s, P(c.conv + ".weight"), P(c.bn + ".weight"),
+  CGD_LAUNCH(rn_fold_bn_kernel, dim3(rn_grid((long)c.cout * c.cin * kk)), dim3(256), 0, s, P(c.conv + ".weight"), P(c.bn + ".weight"),
                      P(c.bn + ".bias"), P(c.bn + ".running_mean"), P(c.bn + ".running_var"), c.w, c.bias, c.cout, c.cin, c.cinP, kk);
   if (c.k == 1) {
     if (!c.wT) CGD_TRY(alloc(&c.wT, nw));
@@ -383,7 +383,7 @@ int ResNet::finalize(hipStream_t s) {
     CGD_TRY(alloc(&s1f, (size_t)s1.coutP * 32));
     CGD_TRY(alloc(&s1b, (size_t)32 * s1.coutP));
   }
-  hipLaunchKernelGGL(rn_pack_stem_kernel, dim3((s1.coutP * 32 + 255) / 256), dim3(256), 0, s, s1.w, s1f, s1b, s1.coutP);
+  CGD_LAUNCH(rn_pack_stem_kernel, dim3((s1.coutP * 32 + 255) / 256), dim3(256), 0, s, s1.w, s1f, s1b, s1.coutP);
   for (Block& b : blocks) {
     CGD_TRY(fold(b.c1, s));
     CGD_TRY(fold(b.c2, s));
@@ -425,7 +425,7 @@ int ResNet::forward(const float* img, int Nn, float* emb, hipStream_t s) {
   CGD_TRY(ensure(a2, (size_t)M2 * wh));
   CGD_TRY(ensure(a3, (size_t)M2 * w));
   CGD_TRY(ensure(a3p, (size_t)M4 * w));
-  hipLaunchKernelGGL(rn_stem_im2col_kernel, dim3(rn_grid(M2 * 8)), dim3(256), 0, s, img, col.p, N, R, R2);
+  CGD_LAUNCH(rn_stem_im2col_kernel, dim3(rn_grid(M2 * 8)), dim3(256), 0, s, img, col.p, N, R, R2);
   CGD_TRY(gemm(col.p, 32, s1f, 32, a1.p, wh, s1.bias, nullptr, 0, M2, wh, s));
   relu(a1.p, M2 * wh, s);
   CGD_TRY(conv3(a1.p, s2, false, a2.p, N, R2, R2, s));
@@ -474,10 +474,10 @@ int ResNet::forward(const float* img, int Nn, float* emb, hipStream_t s) {
   CGD_TRY(ensure(q, (size_t)N * E));
   CGD_TRY(ensure(prob, (size_t)N * cfg.heads * T));
   CGD_TRY(ensure(o, (size_t)N * E));
-  hipLaunchKernelGGL(rn_tokens_kernel, dim3(rn_grid((long)N * E)), dim3(256), 0, s, x, pos, S.p, N, NPX, E);
+  CGD_LAUNCH(rn_tokens_kernel, dim3(rn_grid((long)N * E)), dim3(256), 0, s, x, pos, S.p, N, NPX, E);
   CGD_TRY(gemm(S.p, E, kvw, E, KV.p, 2 * E, kvb, nullptr, 0, (long)N * T, 2 * E, s));
   CGD_TRY(gemm(S.p, T * E, qw, E, q.p, E, qb, nullptr, 0, N, E, s));  // rows = the mean tokens (stride T*E)
-  hipLaunchKernelGGL(rn_pool_attn_fwd_kernel, dim3(cfg.heads, N), dim3(64), 0, s, q.p, KV.p, prob.p, o.p, T, E, cfg.heads, 0.125f);
+  CGD_LAUNCH(rn_pool_attn_fwd_kernel, dim3(cfg.heads, N), dim3(64), 0, s, q.p, KV.p, prob.p, o.p, T, E, cfg.heads, 0.125f);
   CGD_TRY(gemm(o.p, E, cw, E, emb, cfg.out_dim, cb, nullptr, 0, N, cfg.out_dim, s));
   CGD_HIP(ctx, hipGetLastError());
   have_fwd = true;
@@ -494,7 +494,7 @@ int ResNet::dgrad(const float* demb, float* dimg, hipStream_t s) {
   CGD_TRY(ensure(dS, (size_t)N * T * E));
   CGD_TRY(ensure(dSq, (size_t)N * E));
   CGD_TRY(gemm(demb, cfg.out_dim, cwT, cfg.out_dim, d_o.p, E, nullptr, nullptr, 0, N, E, s));
-  hipLaunchKernelGGL(rn_pool_attn_bwd_kernel, dim3(cfg.heads, N), dim3(64), 0, s, q.p, KV.p, prob.p, d_o.p, dq.p, dKV.p, T, E, cfg.heads, 0.125f);
+  CGD_LAUNCH(rn_pool_attn_bwd_kernel, dim3(cfg.heads, N), dim3(64), 0, s, q.p, KV.p, prob.p, d_o.p, dq.p, dKV.p, T, E, cfg.heads, 0.125f);
   CGD_TRY(gemm(dKV.p, 2 * E, kvwT, 2 * E, dS.p, E, nullptr, nullptr, 0, (long)N * T, E, s));
   // query path: dS[n][0] += dq Wq  (rows with stride T*E; the residual operand is the same strided view)
   CGD_TRY(gemm(dq.p, E, qwT, E, dS.p, T * E, nullptr, dS.p, T * E, N, E, s));
@@ -502,7 +502,7 @@ int ResNet::dgrad(const float* demb, float* dimg, hipStream_t s) {
   const int Hl = last.H / last.stride;
   const long Ml = (long)N * Hl * Hl;
   CGD_TRY(ensure(dX, (size_t)Ml * E));
-  hipLaunchKernelGGL(rn_tokens_bwd_kernel, dim3(rn_grid(Ml * E)), dim3(256), 0, s, dS.p, dX.p, N, NPX, E);
+  CGD_LAUNCH(rn_tokens_bwd_kernel, dim3(rn_grid(Ml * E)), dim3(256), 0, s, dS.p, dX.p, N, NPX, E);
   // stages, last to first
   float* dout = dX.p;
   for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
@@ -555,7 +555,7 @@ int ResNet::dgrad(const float* demb, float* dimg, hipStream_t s) {
   relu_bwd(a1.p, d_a1.p, M2 * wh, s);
   CGD_TRY(ensure(Tst, (size_t)M2 * 32));
   CGD_TRY(gemm(d_a1.p, wh, s1b, wh, Tst.p, 32, nullptr, nullptr, 0, M2, 32, s));
-  hipLaunchKernelGGL(rn_stem_gather_kernel, dim3(rn_grid((long)N * 3 * R * R)), dim3(256), 0, s, Tst.p, dimg, N, R, R2);
+  CGD_LAUNCH(rn_stem_gather_kernel, dim3(rn_grid((long)N * 3 * R * R)), dim3(256), 0, s, Tst.p, dimg, N, R, R2);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }

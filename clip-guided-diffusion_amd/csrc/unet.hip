@@ -37,7 +37,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
 
 int cgd_pack_conv3x3(cgd_ctx* ctx, const float* w, float* wf, float* wd, int Co, int Ci, hipStream_t s) {
   const long total = (long)Co * Ci * 9;
-  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wf, wd, Co, Ci);
+  CGD_LAUNCH(pack_conv3x3_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wf, wd, Co, Ci);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -127,12 +127,12 @@ struct UNet : NetBase {
 int UNet::ensure_wino(ResBlock* rb, long pixels, hipStream_t s) {
   if (!ctx->wino_mode || pixels < ctx->wino_min_m || rb->wino_ready) return 0;
   const std::string& p = rb->pre;
-  if (!rb->cw1wp) {
-    CGD_TRY(alloc(&rb->cw1wp, cgd_wconv_packed_floats(rb->cout, rb->cin)));
-    CGD_TRY(alloc(&rb->cw1wd, cgd_wconv_packed_floats(rb->cout, rb->cin)));
-    CGD_TRY(alloc(&rb->cw2wp, cgd_wconv_packed_floats(rb->cout, rb->cout)));
-    CGD_TRY(alloc(&rb->cw2wd, cgd_wconv_packed_floats(rb->cout, rb->cout)));
-  }
+  // each buffer on its own: an allocation that fails half-way is retried on the next call instead of leaving null pointers behind a
+  // non-null first one
+  if (!rb->cw1wp) CGD_TRY(alloc(&rb->cw1wp, cgd_wconv_packed_floats(rb->cout, rb->cin)));
+  if (!rb->cw1wd) CGD_TRY(alloc(&rb->cw1wd, cgd_wconv_packed_floats(rb->cout, rb->cin)));
+  if (!rb->cw2wp) CGD_TRY(alloc(&rb->cw2wp, cgd_wconv_packed_floats(rb->cout, rb->cout)));
+  if (!rb->cw2wd) CGD_TRY(alloc(&rb->cw2wd, cgd_wconv_packed_floats(rb->cout, rb->cout)));
   CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".in_layers.2.weight"), rb->cw1wp, rb->cout, rb->cin, 0, s));
   CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".in_layers.2.weight"), rb->cw1wd, rb->cout, rb->cin, 1, s));
   CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wp, rb->cout, rb->cout, 0, s));

@@ -426,7 +426,7 @@ size_t cgd_wconv_packed_floats(int Co, int Ci) { return (size_t)Co * Ci * 12; } 
 int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, hipStream_t s) {
   if ((Co & 31) || (Ci & 31)) CGD_FAIL(ctx, "pack_conv3x3_wino: channels must be multiples of 32");
   const long total = (long)Co * Ci * 12;
-  hipLaunchKernelGGL(pack_wino_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
+  CGD_LAUNCH(pack_wino_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -462,7 +462,7 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128));
   const int nb = cgd_wconv_nb(ctx, g);
 #define WC_LAUNCH(GN_, NB_) \
-  hipLaunchKernelGGL((wconv_kernel<GN_, NB_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
+  CGD_LAUNCH((wconv_kernel<GN_, NB_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
   if (g.gn_ab) {
     if (nb == 4) WC_LAUNCH(true, 4); else WC_LAUNCH(true, 2);
   } else {

@@ -60,6 +60,8 @@ _SIGS = {
     "cgd_set_hgemm": (i32, [vp, i32, i32, i32]),
     "cgd_profile": (i32, [vp, i32]),
     "cgd_profile_read": (i32, [vp, C.POINTER(C.c_double)]),
+    "cgd_profile_kinds": (i32, []),
+    "cgd_launch_counts": (i32, [C.POINTER(C.c_uint64)]),
     "cgd_unet_create": (i32, [vp, C.POINTER(UNetConfig), C.POINTER(vp)]),
     "cgd_unet_destroy": (None, [vp]),
     "cgd_unet_num_params": (i32, [vp]),

@@ -5,8 +5,17 @@ Shared across ranks: packed weights (ONE broadcast over RCCL/xGMI at start-up), 
 draws and schedule tables.  Per rank: slice `b` of x_T and of each step's noise (the reference draws one (B,3,H,W) tensor;
 rank b takes [b]).  Works with any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 """
+import os
+
 import torch as th
 import torch.distributed as dist
+
+
+def force_collectives():
+    """Test knob (tests/test_gpu_step.py::test_rccl_single_rank_collectives): with CGD_FORCE_COLLECTIVES=1 an initialised process group
+    of ONE rank still takes the N > 1 code path — the flat-vector broadcast, the object broadcast — so that RCCL executes it on a
+    1-GPU box."""
+    return os.environ.get("CGD_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def world():
@@ -21,7 +30,7 @@ def broadcast_flat(make_flat, numel, device, src=0, dtype=th.float32):
     flat = make_flat().to(device=device, dtype=dtype).contiguous() if rank == src else th.empty(numel, device=device, dtype=dtype)
     if flat.numel() != numel:
         raise ValueError(f"flat parameter vector has {flat.numel()} elements, expected {numel}")
-    if n > 1:
+    if n > 1 or force_collectives():
         dist.broadcast(flat, src=src)
     return flat
 
@@ -32,7 +41,7 @@ def on_rank0(fn):
     collective).  Single-process: a plain call.  Used for checkpoint downloads and for probing a checkpoint's architecture: N ranks
     streaming into one cache file, or N ranks each un-pickling a multi-GB archive, is the failure mode this removes."""
     rank, n = world()
-    if n == 1:
+    if n == 1 and not force_collectives():
         return fn()
     result, err = None, None
     if rank == 0:
@@ -67,7 +76,7 @@ def load_broadcast(net, make_state_dict, device, prefix=""):
     `make_state_dict()` (reads the checkpoint / draws the synthetic weights), packs the parameters the handle asks for into one
     flat fp32 vector and broadcasts it over RCCL/xGMI; the other ranks never touch the disk.  Single-process: a plain load."""
     rank, n = world()
-    if n == 1:
+    if n == 1 and not force_collectives():
         return net.load_state_dict(make_state_dict(), prefix)
     specs = net.param_specs()
     names = [prefix + name for name, _ in specs]

@@ -8,23 +8,52 @@ import torch as th
 from .shard import flat_pack, flat_unpack  # noqa: F401  (re-exported for the callers that pack synthetic weights)
 
 
-def synthetic_state_dict(net, seed=1234, device="cuda", std=0.02):
+def _fan_in(name, numel, specs):
+    """Fan-in of a >= 2-D parameter from the manifest alone (names + element counts): weight numel / sibling bias numel
+    (= output features) for every conv / linear; the bias-free CLIP tensors from the tower width (`class_embedding`)."""
+    sib = name[:-len("weight")] + "bias" if name.endswith("weight") else None
+    if sib in specs:
+        return numel // specs[sib]
+    if name.endswith("in_proj_weight"):
+        return numel // specs[name[:-len("weight")] + "bias"]
+    if name == "conv1.weight":  # ViT patch embedding [W][3][P][P], no bias
+        return numel // specs["class_embedding"]
+    raise KeyError(f"synthetic weights: no fan-in rule for {name}")
+
+
+def synthetic_state_dict(net, seed=1234, device="cuda", head_scale=0.1):
+    """The ORACLE's seeded recipes (`oracle/unet.py:synthetic_init_`, `oracle/clip_vit.py:synthetic_init_`) restated on
+    the parameter manifest, so that bench.py's GPU leg and its `cpu_baseline` leg time networks drawn from the same distributions:
+    UNet — PyTorch-default fan-in init U(+-sqrt(3 / fan_in)) for every conv / linear (upstream's zero-initialised layers included, so
+    no gradient path is dead), N(0, 0.02) biases, 1 + N(0, 0.02) norm gains, N(0, 1) class embedding; ViT tower — N(0, 1 / fan_in)
+    matrices, width^-0.5 embeddings / projection.  `head_scale` multiplies the UNet's output conv like `cpu_baseline` does (a
+    full-scale random head makes the learned-variance channel O(1) and a chained trajectory diverges; the arithmetic per step is
+    unchanged)."""
     g = th.Generator(device=device).manual_seed(seed)
+    specs = dict(net.param_specs())
+    is_vit = "class_embedding" in specs
+    width = specs.get("class_embedding", 0)
     sd = {}
-    for name, numel in net.param_specs():
+
+    def randn(n):
+        return th.randn(n, device=device, generator=g)
+
+    for name, numel in specs.items():
         leaf = name.rsplit(".", 1)[-1]
-        is_norm_gain = leaf == "weight" and any(k in name for k in (".in_layers.0.", ".out_layers.0.", ".norm.", "out.0.", "ln_"))
-        if is_norm_gain:
-            t = 1.0 + std * th.randn(numel, device=device, generator=g)
+        is_norm = any(k in name for k in (".in_layers.0.", ".out_layers.0.", ".norm.", "out.0.", "ln_"))
+        if is_norm or leaf in ("bias", "in_proj_bias"):  # 1-D: biases and norm affine parameters
+            t = 0.02 * randn(numel) + (1.0 if (is_norm and leaf == "weight") else 0.0)
         elif name == "label_emb.weight":
-            t = th.randn(numel, device=device, generator=g)
+            t = randn(numel)
+        elif is_vit and name in ("class_embedding", "positional_embedding", "proj"):
+            t = width ** -0.5 * randn(numel)
+        elif is_vit:
+            t = _fan_in(name, numel, specs) ** -0.5 * randn(numel)
         else:
-            t = std * th.randn(numel, device=device, generator=g)
+            bound = (3.0 / _fan_in(name, numel, specs)) ** 0.5
+            t = (th.rand(numel, device=device, generator=g) * 2 - 1) * bound
         if name.startswith("out.2."):
-            # keep the (epsilon, learned-variance) head small: a random head makes v = O(1), so exp(log-variance)
-            # interpolates far outside [posterior, beta] and a multi-step trajectory diverges to inf (real checkpoints
-            # keep v in [-1, 1]); the arithmetic per step is unchanged
-            t = t * 0.05
+            t = t * head_scale
         sd[name] = t
     return sd
 

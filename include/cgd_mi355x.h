@@ -47,6 +47,11 @@ int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks);
  * (the weight-streaming conv kernel of the <= 32x32-pixel maps) [FLOP]: 15 doubles; synchronises the device and resets. */
 int cgd_profile(cgd_ctx* ctx, int enable);
 int cgd_profile_read(cgd_ctx* ctx, double* out15);
+/* number of kinds k above (the buffer of cgd_profile_read holds 3 * cgd_profile_kinds() doubles) */
+int cgd_profile_kinds(void);
+/* measurement: process-wide counters since the library was loaded: out2[0] = kernel launches, out2[1] = split-K reduce launches
+ * among them (bench.py: launches_per_step / splitk_reduce_per_step) */
+int cgd_launch_counts(unsigned long long* out2);
 
 /* ---- UNet epsilon/sigma predictor: replaces guided_diffusion.unet.UNetModel built at
  *      /root/reference/cgd/script_util.py:316 from /root/reference/data/diffusion_model_flags.py ---- */

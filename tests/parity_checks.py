@@ -440,6 +440,8 @@ def check_cutouts_loss():
         (2, 256, 256, 4, 224, 32, [(3, 7, 224), (0, 0, 256), (20, 30, 233), (32, 0, 224)]),
         (1, 256, 288, 3, 224, 32, [(10, 5, 250), (60, 0, 228), (0, 31, 256)]),  # truncated crops (H/W naming quirk)
         (1, 96, 96, 2, 64, 16, [(5, 9, 80), (0, 0, 96)]),
+        # more cutouts than the backward kernel's 256-entry table of division constants (chunked launches that accumulate)
+        (1, 40, 48, 300, 16, 8, [((7 * k) % 17, (5 * k) % 13, 20 + k % 21) for k in range(300)]),
     ]:
         x = th.rand(B, 3, H, W, generator=g(50)) * 2.4 - 1.2
         xr = x.double().requires_grad_()

@@ -259,3 +259,37 @@ def test_checkpoint_download_runs_on_rank0_only_world2(tmp_path):
     assert ok0 and ok1 and same0 and same1
     assert f0 and "Download failed" in f0 and f1 and "rank 0 failed" in f1
     assert ls0 == ["ckpt.pt"] == ls1     # no temporary files left behind
+
+
+def test_forced_collectives_on_a_one_rank_group():
+    """CGD_FORCE_COLLECTIVES=1 (the knob behind the -m gpu RCCL test): an initialised group of ONE rank still takes the broadcast path
+    of shard.broadcast_flat / on_rank0 / load_broadcast — here over gloo."""
+    import subprocess
+    code = (
+        "import os, sys, torch as th, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import cgd_amd\n"
+        "from cgd_amd import shard\n"
+        "dist.init_process_group('gloo', rank=0, world_size=1)\n"
+        "calls = []\n"
+        "orig = dist.broadcast\n"
+        "dist.broadcast = lambda t, src=0, **kw: (calls.append(t.numel()), orig(t, src=src, **kw))[1]\n"
+        "flat = shard.broadcast_flat(lambda: th.arange(10.), 10, 'cpu')\n"
+        "assert shard.on_rank0(lambda: 7) == 7\n"
+        "class Net:\n"
+        "    def param_specs(self): return [('a', 4), ('b', 6)]\n"
+        "    def load_state_dict(self, sd, prefix=''): self.sd = sd; return self\n"
+        "n = shard.load_broadcast(Net(), lambda: {'a': th.ones(4), 'b': th.zeros(2, 3)}, 'cpu')\n"
+        "assert n.sd['a'].sum() == 4 and n.sd['b'].numel() == 6\n"
+        "print('broadcasts', calls)\n"
+        "dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for force, expect in (("1", "broadcasts [10, 10]"), ("0", "broadcasts []")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(env, CGD_FORCE_COLLECTIVES=force), capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert expect in out.stdout, out.stdout

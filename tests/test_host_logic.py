@@ -701,3 +701,42 @@ def test_oracle_ddim_yields_the_unconditioned_prediction():
     eps = 0.1 * x - (1 - ab) ** 0.5 * g_const
     x0c = (1 / ab) ** 0.5 * x - (1 / ab - 1) ** 0.5 * eps
     assert th.allclose(guided["sample"], abp ** 0.5 * x0c + (1 - abp) ** 0.5 * eps, atol=1e-5)
+
+
+def test_synthetic_bench_weights_follow_the_oracle_recipe():
+    """bench.py's GPU leg (cgd_amd.synthetic.synthetic_state_dict) and its cpu_baseline leg (oracle synthetic_init_)
+    draw their weights from the same per-tensor distributions (SURVEY.md 8d fan-in init): compared tensor by tensor through the
+    library's host-only manifests — standard deviation and mean of every parameter of a small UNet and of the ViT-B/32 tower."""
+    import torch as th
+    from cgd_amd import lib, nets, synthetic
+    from oracle import clip_vit as ocv
+    from oracle import unet as ou
+
+    class Manifest:  # what synthetic_state_dict needs of a network handle
+        def __init__(self, specs):
+            self._s = specs
+
+        def param_specs(self):
+            return self._s
+
+    kw = dict(image_size=64, model_channels=64, num_res_blocks=1, attention_resolutions="32,16", num_classes=10, num_head_channels=32,
+              channel_mult=(1, 2, 2))
+    ref = ou.synthetic_init_(ou.UNetModel(**kw))
+    with th.no_grad():
+        ref.out[2].weight.mul_(0.1)
+        ref.out[2].bias.mul_(0.1)
+    cases = [(Manifest(nets.manifest("unet", nets.UNet.make_config(**kw))), dict(ref.named_parameters()), ""),
+             (Manifest(nets.manifest("vit", lib.ViTConfig(*nets.VIT_CONFIGS["ViT-B/32"]))),
+              dict(ocv.synthetic_init_(ocv.ClipImageModel("ViT-B/32")).named_parameters()), "visual.")]
+    for man, oracle_params, prefix in cases:
+        sd = synthetic.synthetic_state_dict(man, seed=7, device="cpu")
+        assert set(sd) == {k[len(prefix):] for k in oracle_params}
+        for name, t in sd.items():
+            r = oracle_params[prefix + name].detach().flatten().double()
+            t = t.double()
+            assert t.numel() == r.numel()
+            if t.numel() < 64:
+                continue  # too few samples for a moment comparison (tiny biases); the rule is the same as for the larger ones
+            tol = 6.0 / t.numel() ** 0.5  # ~4 sigma of the sampling error of a standard deviation, both draws
+            assert abs(t.std() - r.std()) <= tol * float(r.std()) + 1e-12, (name, float(t.std()), float(r.std()))
+            assert abs(t.mean() - r.mean()) <= 6.0 * float(r.std()) / t.numel() ** 0.5 + 1e-12, (name, float(t.mean()), float(r.mean()))
