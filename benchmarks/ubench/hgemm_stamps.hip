@@ -4,7 +4,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include hgemm_stamps.hip -o hgemm_stamps
 // Usage: hgemm_stamps M N K splitk [tm 64|128] [reps] [residual 0|1] [pipeline 0..8]
 //   pipeline (64-row tiles only) = index into {ring depth in k-steps, activation staging sets}: 0 {8,2} (shipped), 1 {8,3}, 2 {8,4}, 3 {12,2},
-//   4 {12,3}, 5 {12,4}, 6 {16,2}, 7 {16,3}, 8 {16,4} — the sweep of the software pipeline's depth against the cold-L2 operand latency
+//   4 {12,3}, 5 {12,4}, 6 {16,2}, 7 {16,3}, 8 {16,4}, 9 = {8,2} with TWO K-groups of wavefronts (512 threads, round 4) — the sweep of the software pipeline's depth against the cold-L2 operand latency
 #ifndef CGD_HGEMM_STAMPS
 #define CGD_HGEMM_STAMPS 1  // 2 (-DCGD_HGEMM_STAMPS=2): a stamp after every chunk as well
 #endif
@@ -93,6 +93,7 @@ int main(int argc, char** argv) {
         case 6: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 2>), HS_ARGS); break;
         case 7: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 3>), HS_ARGS); break;
         case 8: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 16, 4>), HS_ARGS); break;
+        case 9: hipLaunchKernelGGL((hgemm2_kernel<1, 64, 8, 2, 2>), grid, dim3(512), 0, 0, dA, (const uint4*)dB, dC, dbias, dR, dws, p); break;  // two K-groups (K % 128 == 0)
         default: hipLaunchKernelGGL((hgemm2_kernel<1, 64>), HS_ARGS); break;
       }
     } else

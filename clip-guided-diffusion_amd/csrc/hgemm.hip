@@ -31,7 +31,7 @@ constexpr int GPLANE = GM * GPH;
 __device__ unsigned long long* g_hstamps;  // [workgroup (x + gridDim.x * z)][wavefront][32]: 0 entry, 1 first chunk staged, 2 + c chunk c done (level 2), 29 loop done, 30 stores issued, 31 HW id
 #define H_STAMP(I)                                                                                                          \
   do {                                                                                                                      \
-    if ((threadIdx.x & 63) == 0)                                                                                            \
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256)                                                                       \
       g_hstamps[(((long)blockIdx.z * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32 + (I)] = wall_clock64();        \
   } while (0)
 #if CGD_HGEMM_STAMPS >= 2  // a store per chunk slows the 0.75 us chunks by ~30 %: level 1 stamps only around the loop
@@ -44,7 +44,7 @@ __device__ unsigned long long* g_hstamps;  // [workgroup (x + gridDim.x * z)][wa
 #define H_STAMP_END()                                                                                                       \
   do {                                                                                                                      \
     H_STAMP(30);                                                                                                            \
-    if ((threadIdx.x & 63) == 0)                                                                                            \
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256)                                                                       \
       g_hstamps[(((long)blockIdx.z * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32 + 31] =                         \
           ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); \
   } while (0)
@@ -322,18 +322,29 @@ constexpr int h2_lcm(int a, int b) { return a / h2_gcd(a, b) * b; }
 // RING = weight-fragment ring depth in k-steps (a multiple of 4: slots of a chunk are ring[(4 j) % RING ..]), NSET = staging register sets of
 // the activation patch (the patch is fetched NSET chunks ahead).  Defaults = the shipped configuration; benchmarks/ubench/hgemm_stamps.hip
 // instantiates others to sweep the pipeline depth against the cold-L2 operand latency.
-template <int MODE, int TM, int RING = 8, int NSET = (TM == 64 ? 2 : 1)>
-__global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+// KG = 2 (round 4): TWO wavefronts per SIMD.  The round-4 sweep (profiles/r4_hgemm_pipeline_sweep.txt) refuted the latency model: deeper
+// rings / staging sets move the loop by < 10 %, but removing the weight loads or the patch path from the loop shortens it ADDITIVELY
+// (0.94 -> 0.71 / 0.63 -> 0.46 us per chunk = the MFMA stream alone), and a 64 x 128 tile needs 48 KB of operands per 64-deep chunk =
+// 750 cycles of the CU's 64 B/clk vector-memory path against 773 cycles of MFMA: with one wavefront per SIMD an in-order wavefront that is
+// stuck issuing a vector-memory instruction into the full queue issues no MFMA either, so the two costs add instead of overlapping.
+// The workgroup becomes 8 wavefronts = 2 K-groups x 4 column blocks over a 128-deep chunk: group kg multiplies k-steps 4 kg .. 4 kg + 3
+// of every chunk (its own weight fragments, its own accumulators), the 512 threads stage the 64 x 128 patch together, and group 1 hands
+// its partial block to group 0 through LDS before the epilogue.  Per wavefront the instruction stream of a chunk is unchanged.
+template <int MODE, int TM, int RING = 8, int NSET = (TM == 64 ? 2 : 1), int KG = 1>
+__global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                      const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                      const HGemmParams p) {
   constexpr int NPL = MODE == 1 ? 2 : 1;
   constexpr int NI = TM / 32;      // 32-row blocks per wavefront
   constexpr int NPS = TM / 16;     // staging slots per thread: rows r0 + 16 j
-  constexpr int PLANE = TM * GPH;
+  constexpr int GKW = GK * KG;     // chunk width of the workgroup (columns of A staged per turn)
+  constexpr int GPHW = GKW + 8;    // LDS row pitch (bf16): 144 / 272 bytes, 16 consecutive rows start in 16 different 16-byte bank groups
+  constexpr int PLANE = TM * GPHW;
   constexpr int DIST = RING - 1;
   static_assert(RING % 4 == 0 && RING >= 8 && NSET >= 1, "hgemm2: ring depth in whole chunks, at least two");
+  static_assert(KG == 1 || (KG == 2 && MODE == 1), "hgemm2: K-groups need the LDS epilogue of the bf16x3 mode");
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * NPL * PLANE];
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wn = (tid >> 6) & 3, kg = tid >> 8;
   const int l31 = lane & 31, hh = lane >> 5;
   H_STAMP(0);
 
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   const int ntm = (p.M + TM - 1) / TM;
   const int m0 = (p.nmajor ? bid % ntm : bid / ntn) * TM, n0 = (p.nmajor ? bid / ntm : bid % ntn) * GN;
 
-  const int c4 = tid & 15, r0 = tid >> 4;
+  const int c4 = tid & (16 * KG - 1), r0 = tid / (16 * KG);
   int aoff[NPS];
   unsigned amask = 0;
 #pragma unroll
@@ -358,9 +369,9 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   }
   int fro[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) fro[i] = (i * 32 + l31) * GPH + hh * 8;
+  for (int i = 0; i < NI; ++i) fro[i] = (i * 32 + l31) * GPHW + hh * 8 + kg * GK;
 
-  const int nchunk = p.K / GK;
+  const int nchunk = p.K / GKW;
   int c0 = 0, c1 = nchunk;
   if (p.splitk > 1) {
     const int per = (nchunk + p.splitk - 1) / p.splitk;
@@ -369,8 +380,9 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   }
   const int nb0 = (n0 >> 5) + wn, nbN = p.N >> 5;
   const long bstride_nb = (long)(p.K >> 5) * 4 * 64;
-  const uint4* __restrict__ Bw0 = Bg + (long)(nb0 < nbN ? nb0 : nbN - 1) * bstride_nb + lane;
-  const int kq_last = c1 * 4 - 1;
+  // this wavefront's k-steps in its own linear order t = 4 (chunk - c0) + j: k-step (chunk * KG + kg) * 4 + j of the packed weight block
+  const uint4* __restrict__ Bw0 = Bg + (long)(nb0 < nbN ? nb0 : nbN - 1) * bstride_nb + lane + (long)(c0 * KG + kg) * 4 * 128;
+  const int t_last = (c1 - c0) * 4 - 1;
 
   f32x16 acc[NI];
 #pragma unroll
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #define H2_PATCH_LOAD(PR, CH)                                                                     \
   {                                                                                               \
-    const float* __restrict__ Ac = Ag + (long)((CH) < c1 ? (CH) : c1 - 1) * GK;                   \
+    const float* __restrict__ Ac = Ag + (long)((CH) < c1 ? (CH) : c1 - 1) * GKW;                  \
     _Pragma("unroll") for (int j = 0; j < NPS; ++j) PR[j] = *(const f32x4*)(Ac + aoff[j]);        \
   }
 #define H2_PATCH_STORE(PR, DSTB, J0, J1)                                                          \
@@ -393,8 +405,8 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
       const int row = r0 + 16 * j;                                                                \
       const f32x4 v = (amask >> j) & 1u ? PR[j] : z4;                                             \
       const bf16x4 hi = g_to_bf16x4(v);                                                           \
-      *(bf16x4*)&(DSTB)[row * GPH + c4 * 4] = hi;                                                 \
-      if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + row * GPH + c4 * 4] = g_to_bf16x4(g_residual4(v, hi)); \
+      *(bf16x4*)&(DSTB)[row * GPHW + c4 * 4] = hi;                                                \
+      if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + row * GPHW + c4 * 4] = g_to_bf16x4(g_residual4(v, hi)); \
     }                                                                                             \
   }
 #define H2_A_LOAD(DST, SRCB, Q)                                                                   \
@@ -404,10 +416,10 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
       if constexpr (MODE == 1) DST[i][1] = *(const bf16x8*)&(SRCB)[PLANE + fro[i] + (Q) * 16];    \
     }                                                                                             \
   }
-#define H2_B_LOAD(DST, KQ)                                                                        \
+#define H2_B_LOAD(DST, T)                                                                         \
   {                                                                                               \
-    const int kq_ = (KQ) < kq_last ? (KQ) : kq_last;                                              \
-    const uint4* q_ = Bw0 + (long)kq_ * 128;                                                      \
+    const int t_ = (T) < t_last ? (T) : t_last;                                                   \
+    const uint4* q_ = Bw0 + (long)((t_ >> 2) * (4 * KG) + (t_ & 3)) * 128;                        \
     DST[0] = q_[0];                                                                               \
     if constexpr (MODE == 1) DST[1] = q_[64];                                                     \
   }
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
 #define X_A(...) do { if constexpr (!(CGD_HGEMM_EXP & 8)) { __VA_ARGS__; } } while (0)
 #define H2_CHUNK(S, CUR, NXT, C, PR)                                                              \
   {                                                                                               \
-    const int kq = (C) * 4;                                                                       \
+    const int kq = ((C) - c0) * 4; /* this wavefront's linear k-step index */                     \
     X_A(H2_A_LOAD(af[1], CUR, 1));                                                                     \
     X_B(H2_B_LOAD(bq[((S) + 0 + DIST) % RING], kq + 0 + DIST));                                        \
     H2_MFMA(af[0], bq[(S) + 0]);                                                                  \
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
     __bf16* const buf1 = lds + NPL * PLANE;
     H2_PATCH_LOAD(prs[0], c0);
 #pragma unroll
-    for (int q = 0; q < DIST; ++q) H2_B_LOAD(bq[q], c0 * 4 + q);
+    for (int q = 0; q < DIST; ++q) H2_B_LOAD(bq[q], q);
     H2_PATCH_STORE(prs[0], buf0, 0, NPS);
     // A chunk of the 64-row tile has 0.32 us of MFMA work and the L2 starts every launch cold: both operand streams see the Infinity Cache /
     // HBM latency (1.5-1.9 us), and the loop runs at (that latency) / (depth of the prefetch): activations one chunk ahead 1.4 us per chunk
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
   H_STAMP(29);
   // ---- epilogue: D = W x A^T in the 32x32 C/D layout: column (lane & 31) = row m of C, accumulator quad g = columns 8g + 4hh ..
   const int cb0 = n0 + wn * 32;
-  if (MODE == 1 && p.lep) {
+  if (MODE == 1 && (p.lep || KG == 2)) {
     // Stores straight from that layout are 16-byte pieces of 64 different rows per instruction, bound by the CU's store path (the finding
     // of profiles/r3_wconv_timeline.txt for the same layout in wconv_kernel).  The staging buffers are free after the last chunk: each
     // wavefront parks its TM x 32 block in its own slab (16-byte unit q of row r at q ^ (r & 7): conflict-free both ways), reads it
@@ -518,8 +530,29 @@ __global__ __launch_bounds__(256) void hgemm2_kernel(const float* __restrict__ A
     // slab) moves whole 128-byte lines.  Same operations per element in the same order as the per-lane epilogue below, which the
     // single-plane modes (half the LDS) and CGD_HGEMM_EPI=0 keep.
     __syncthreads();  // every wavefront has fetched its last A fragments
-    if (cb0 >= p.N) return;
     float* slab = (float*)lds + wn * (TM * 32);
+    if constexpr (KG == 2) {
+      // K-group 1 hands its partial block to group 0 (same column block wn, same accumulator layout: lane-contiguous 16-byte
+      // units, conflict-free) and is done; group 0 adds it and runs the epilogue
+      if (kg == 1) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(f32x4*)&slab[((i * 4 + g) * 64 + lane) * 4] = f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+      }
+      __syncthreads();
+      if (kg == 1) return;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = *(const f32x4*)&slab[((i * 4 + g) * 64 + lane) * 4];
+          acc[i][4 * g] += o[0]; acc[i][4 * g + 1] += o[1]; acc[i][4 * g + 2] += o[2]; acc[i][4 * g + 3] += o[3];
+        }
+      // (the slab is rewritten below by this same wavefront: LDS operations of a wavefront complete in order)
+    }
+    if (cb0 >= p.N) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int rl = i * 32 + l31;
@@ -763,6 +796,12 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
 #define HG_ARGS grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p
   if (!v2) {
     if (x3) CGD_LAUNCH((hgemm_kernel<1>), HG_ARGS); else CGD_LAUNCH((hgemm_kernel<2>), HG_ARGS);
+  } else if (tm == 64 && x3 && g.K % (2 * GK) == 0 &&
+             (ctx->hgemm_kg == 2 || (ctx->hgemm_kg == 0 && (long)grid.x * grid.z <= ctx->num_cu && g.K / (2 * GK) / (int)grid.z >= 4))) {
+    // two K-groups of wavefronts per workgroup (512 threads): see hgemm2_kernel; always on the LDS epilogue.  Automatic only where the
+    // micro-benchmark shows a gain (profiles/r4_hgemm_kgroups.txt): one workgroup per CU at most (an 8-wavefront workgroup has a CU to itself,
+    // a second round of workgroups costs more than the loop gains) and >= 8 64-deep chunks per slice (the prologue / hand-over are longer)
+    CGD_LAUNCH((hgemm2_kernel<1, 64, 8, 2, 2>), grid, dim3(512), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p);
   } else if (tm == 64) {
     if (x3) CGD_LAUNCH((hgemm2_kernel<1, 64>), HG_ARGS); else CGD_LAUNCH((hgemm2_kernel<2, 64>), HG_ARGS);
   } else {
