@@ -46,6 +46,9 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_WINO")) sscanf(e, "%d,%d", &ctx->wino_mode, &ctx->wino_min_m);
   if (const char* e = getenv("CGD_THIN")) ctx->thin_direct = atoi(e);
   if (const char* e = getenv("CGD_GEMV")) ctx->gemv_mode = atoi(e);
+  if (const char* e = getenv("CGD_WINO_NC")) ctx->wino_nc = atoi(e);
+  ctx->wino_nc_default = ctx->wino_nc;
+  if (const char* e = getenv("CGD_GN_EPI")) ctx->gn_epi = atoi(e);
   if (const char* e = getenv("CGD_HGEMM_KG")) ctx->hgemm_kg = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
   if (const char* e = getenv("CGD_KCONV")) sscanf(e, "%d,%d,%d", &ctx->kconv_mode, &ctx->kconv_max_m, &ctx->kconv_min_chunks);
   if (const char* e = getenv("CGD_HCONV_SPLIT")) sscanf(e, "%d,%d", &ctx->hconv_slots, &ctx->hconv_min_chunks);
@@ -67,6 +70,7 @@ void cgd_ctx_destroy(cgd_ctx* ctx) {
   DeviceScope dev_scope(ctx);
   if (ctx->ws) (void)hipFree(ctx->ws);
   cgd_frag_cache_clear(ctx);
+  cgd_chanstats_clear(ctx);
   if (ctx->frag_tmp) (void)hipFree(ctx->frag_tmp);
   for (ProfRec& r : ctx->prof_recs) {
     (void)hipEventDestroy(r.a);
@@ -272,7 +276,10 @@ int cgd_op_conv3x3_wino(cgd_ctx* ctx, const float* x, int ldx, const float* w_wi
 }
 int cgd_set_wino(cgd_ctx* ctx, int mode, int min_m) {
   CGD_NEED_CTX(ctx);
-  ctx->wino_mode = mode;
+  // mode 5 (tests / micro-benchmarks): 8-row tiles with two 32-channel blocks per wavefront (8 x 16 pixels x 256 channels) wherever N is a multiple
+  // of 256, plain 8-row tiles elsewhere; the other modes leave the channel-block choice automatic
+  ctx->wino_mode = mode == 5 ? 3 : mode;
+  ctx->wino_nc = mode == 5 ? 3 : ctx->wino_nc_default;
   if (min_m > 0) ctx->wino_min_m = min_m;
   return 0;
 }

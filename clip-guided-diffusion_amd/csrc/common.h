@@ -57,6 +57,27 @@ struct PendingReduce {  // a deferred reduction (GemmParams::defer) that has not
   hipStream_t stream = nullptr;  // the stream the slices were produced on: only a consumer on the same stream may take them
 };
 
+// Per-channel statistics of a conv OUTPUT, taken by the conv kernel's own epilogue (round 4: wconv_kernel): for every 8 x 16-pixel half tile and
+// channel the (mean, M2 = sum of squared deviations) pair of its 128 values, [B * HW / 128][N][2] floats.  The GroupNorm that reads the tensor next
+// merges these instead of sweeping the tensor (norm.hip gn_stats_final_ch_kernel): gn_stats_partial_kernel's pass over x disappears for conv-produced
+// tensors.  An entry belongs to the tensor it was taken from (pointer, row stride, rows, channels) and is only valid inside the network pass that
+// produced it (`serial`): a later pass that writes the same buffer with another kernel can never leave stale statistics behind.
+struct ChanStatsEntry {
+  const float* C = nullptr;
+  int ldc = 0, N = 0;
+  long M = 0;
+  float* buf = nullptr;
+  size_t cap = 0;  // floats
+  hipStream_t stream = nullptr;
+  unsigned long long serial = 0;
+  int kind = 0;  // 0: forward statistics (mean, M2); 1: GroupNorm-backward sums (gcoef * sum du, gcoef * sum du (x - mean)) of a dgrad conv's output
+};
+struct ChanSrc {  // what the merging GroupNorm reads: channels [0, n0) from p0 (records of n0 channels), [n0, n0 + n1) from p1 (the two halves of a skip concat)
+  const float* p0 = nullptr;
+  const float* p1 = nullptr;
+  int n0 = 0, n1 = 0;
+};
+
 struct FragEntry {  // fragment-order copy of a persistent weight (hgemm.hip)
   const float* w;
   int N, K, ldw;
@@ -92,6 +113,9 @@ struct cgd_ctx {
   int wino_mode = 1, wino_min_m = 16384;  // Winograd F(2,3) variant of the halo conv (wconv.hip): 0 off, 1 for convs of >= wino_min_m
                                           // pixels whose transformed weights were packed (2 / 3: force 16- / 8-row tiles; A/B knob
                                           // CGD_WINO="<mode>[,<min pixels>]"; same-box A/B: 21.96 -> 20.37 ms/step, 4096: 20.35)
+  int wino_nc_default = 0;  // what cgd_set_wino restores (the CGD_WINO_NC value)
+  int wino_nc = 0;     // wconv_kernel tile: 0 = the 8-row x 256-channel tile (two channel blocks per wavefront) wherever the 16-row x 128-channel tile
+                       // would run and N is a multiple of 256; 1 = never; 3 = wherever N is a multiple of 256 (A/B knob CGD_WINO_NC)
   int attn_x3 = 1;     // 1 (default since round 3): the fused attention kernels contract on bf16x3 MFMA products when the context precision
                        // is bf16x3 (attn.hip); 0 = exact-fp32 MFMA (CGD_ATTN_X3=0).  GPU-validated: strict parity, -0.2 ms/step
                        // (profiles/r3_staged_ab.txt)
@@ -111,6 +135,10 @@ struct cgd_ctx {
   PendingReduce pending;                                       // see SplitSrc
   int defer_mode = 1;  // deferred split-K reductions: 0 never, 1 when the consumer is a many-workgroup kernel (GroupNorm on > 32x32
                        // maps), 2 also for the single-launch small-map GroupNorm (32 workgroups: slower, kept for A/B runs)
+  std::vector<ChanStatsEntry> chanstats;  // see ChanStatsEntry
+  unsigned long long stats_serial = 1;    // current network pass (cgd_unet_forward increments it)
+  int gn_epi = 3;      // bit 0: GroupNorm forward statistics of conv-produced tensors come from the conv epilogue; bit 1: the backward sums of a
+                       // GroupNorm whose upstream gradient a dgrad conv produces come from that conv's epilogue (A/B knob CGD_GN_EPI)
   std::vector<FragEntry> frag_cache;                           // packed weights, keyed by pointer; cleared by finalize / set_param / destroy
   void* frag_tmp = nullptr;                                    // packed copy of a non-persistent B operand (forced hgemm, tests)
   size_t frag_tmp_bytes = 0;
@@ -213,9 +241,24 @@ struct GemmParams {
                        // 49-row GEMMs on the generic kernel (92 -> 25 us)
   const float* gn_ab = nullptr;  // conv on the halo kernel only: apply SiLU(x * a + b) to the input while staging it; {a, b} pairs
                                  // [B][Cin][2] of the GroupNorm(+FiLM) that precedes the conv (kernels.h cgd_gn_ab)
+  // conv on wconv_kernel only (a DGRAD conv whose output dz is the upstream gradient of a GroupNorm+SiLU): the epilogue also takes that GroupNorm's
+  // backward sums per (half tile, channel) from dz, the forward input x of the norm (gnb_x, row stride gnb_ldx: one extra read of the tile, like a
+  // residual) and its folded coefficients (gnb_coef = cgd_gn_coef: {a, b, gcoef, mean} per (sample, channel)); gn_bwd_partial_kernel's sweep over x
+  // and dz disappears (ChanStatsEntry kind 1)
+  const float* gnb_x = nullptr;
+  const float* gnb_coef = nullptr;
+  int gnb_ldx = 0, gnb_act = 0;
+  int stats = 0;       // conv on wconv_kernel only: 1 = the epilogue also takes per-(half tile, channel) statistics of the output for the GroupNorm
+                       // that reads it next (ChanStatsEntry); ignored by the other kernels (their consumers sweep the tensor as before)
   int defer = 0;       // 1: if the launch splits K, leave the slices in the workspace (ctx->pending): the caller guarantees that the
                        // next kernel reading C is one that consumes a SplitSrc (cgd_take_pending); anything else flushes first
 };
+
+// conv-epilogue statistics (norm.hip): the buffer a producer writes its [M / 128][N][2] records to (registered for tensor C in the current pass;
+// nullptr if the shape does not qualify or the allocation fails: the producer then simply takes none) / the sources covering tensor x for a consumer
+float* cgd_chanstats_register(cgd_ctx* ctx, const float* C, int ldc, int N, long M, hipStream_t s, int kind = 0);
+bool cgd_chanstats_find(cgd_ctx* ctx, const float* x, int ldx, long M, int Cn, hipStream_t s, ChanSrc* out, int kind = 0);
+void cgd_chanstats_clear(cgd_ctx* ctx);
 
 // deferred split-K reductions: run the reduce kernel for a pending one (no-op otherwise) / hand it to a consumer of tensor `x`
 int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s);
@@ -237,6 +280,7 @@ size_t cgd_wconv_packed_floats(int Co, int Ci);
 int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w /*[Co][Ci][3][3]*/, float* out, int Co, int Ci, int dgrad, hipStream_t s);
 bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_wconv_nb(const cgd_ctx* ctx, const GemmParams& p);
+int cgd_wconv_nc(const cgd_ctx* ctx, const GemmParams& p);
 long cgd_wconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 

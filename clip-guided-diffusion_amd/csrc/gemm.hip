@@ -727,7 +727,8 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   if (rc != 0) return rc;
   long wg;
   if (kernel == 1) {
-    wg = tile == 516 ? cgd_kconv_tiles_m(p) * (p.N >> 5) : (tile == 515 ? cgd_wconv_tiles_m(&ctx, p) : cgd_hconv_tiles_m(&ctx, p)) * cdiv(p.N, 128);
+    wg = tile == 516 ? cgd_kconv_tiles_m(p) * (p.N >> 5)
+                     : (tile == 515 ? cgd_wconv_tiles_m(&ctx, p) * cdiv(p.N, 128 * cgd_wconv_nc(&ctx, p)) : cgd_hconv_tiles_m(&ctx, p) * cdiv(p.N, 128));
   } else if (kernel == 3) {
     wg = std::min<long>(std::max<long>(cdiv(p.N, 16), 1), 4L * ctx.num_cu);
   } else if (kernel == 2) {

@@ -168,6 +168,34 @@ __device__ __forceinline__ double block_sum256(double v, double* red /*[4]*/) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// stats[b][g] = (mean, rstd) and the folded per-channel coefficients of group g: y = x * a + b;  coef[b][c] = {a, b, gcoef = gamma * (1 + scale), mean}
+// plus the compact {a, b} copy behind bcoef (cgd_gn_ab).  Called by every thread of a 256-thread block that owns (b, g); gridDim.y = B.
+__device__ __forceinline__ void gn_fold_group(int b, int g, int lane, int cpg, float meanf, float rstd, float* __restrict__ stats,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film,
+                                              int ldfilm, float* __restrict__ coef) {
+  if (lane == 0) {
+    stats[((long)b * 32 + g) * 2 + 0] = meanf;
+    stats[((long)b * 32 + g) * 2 + 1] = rstd;
+  }
+  const int C = cpg * 32;
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 256) {
+    float gm = gamma[c], bt = beta[c];
+    if (film) {
+      const float sc = 1.f + film[(long)b * ldfilm + c], sh = film[(long)b * ldfilm + C + c];
+      gm *= sc;
+      bt = bt * sc + sh;
+    }
+    float* o = coef + ((long)b * C + c) * 4;
+    o[0] = gm * rstd;
+    o[1] = bt - meanf * gm * rstd;
+    o[2] = gm;
+    o[3] = meanf;
+    float* ab = coef + (long)gridDim.y * C * 8 + ((long)b * C + c) * 2;
+    ab[0] = o[0];
+    ab[1] = o[1];
+  }
+}
+
 // merge chunks -> stats[b][g] = (mean, rstd); one 256-thread block per (b, g), chunk partials held in registers
 __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __restrict__ part, int nchunk, int HW, int chunk, int cpg,
                                                              float eps, float* __restrict__ stats /*[B][32][2]*/,
@@ -202,29 +230,62 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const float* __rest
   }
   m2 = block_sum256(m2, red);
   const double var = m2 / ((double)HW * cpg);
-  const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
-  if (lane == 0) {
-    stats[((long)b * 32 + g) * 2 + 0] = meanf;
-    stats[((long)b * 32 + g) * 2 + 1] = rstd;
-  }
-  // fold (mean, rstd, gamma, beta, film) into per-channel y = x*a + b; coef[b][c] = {a, b, gcoef = gamma*(1+scale), mean}
-  const int C = cpg * 32;
-  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 256) {
-    float gm = gamma[c], bt = beta[c];
-    if (film) {
-      const float sc = 1.f + film[(long)b * ldfilm + c], sh = film[(long)b * ldfilm + C + c];
-      gm *= sc;
-      bt = bt * sc + sh;
+  gn_fold_group(b, g, lane, cpg, (float)mean, (float)(1.0 / sqrt(var + (double)eps)), stats, gamma, beta, film, ldfilm, coef);
+}
+
+// The same merge from the records a conv epilogue took (common.h ChanStatsEntry): (mean, M2) of every (128-pixel half tile, channel); equal
+// counts, so the group mean is the plain average of the ntile * cpg record means.  One block per (b, group); the records of a group are
+// cpg consecutive pairs per tile (64-768 bytes), read twice (L2-resident: a whole tensor's records are <= 2 MB).
+__global__ __launch_bounds__(256) void gn_stats_final_ch_kernel(const ChanSrc cs, int ntile, int cpg, int lg /*ceil log2 cpg*/, float eps,
+                                                                float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ film, int ldfilm,
+                                                                float* __restrict__ coef) {
+  __shared__ double red[4];
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  // thread = (tile row tr, channel ci of the group): consecutive lanes read consecutive records of one tile; no division in the loops
+  const int ci = lane & ((1 << lg) - 1), tr = lane >> lg, tstep = 256 >> lg;
+  const int c = g * cpg + ci;
+  const bool on = ci < cpg;
+  const bool first = c < cs.n0;
+  const float* base = first ? cs.p0 + ((long)b * ntile * cs.n0 + c) * 2 : cs.p1 + ((long)b * ntile * cs.n1 + (c - cs.n0)) * 2;
+  const long rstride = (first ? cs.n0 : cs.n1) * 2L;
+  // the records come from other XCDs' epilogues, i.e. from beyond this L2 (~1-2 us per dependent access): 8 independent loads in flight per
+  // thread (a plain accumulate loop issued them one at a time: 15 us per launch instead of the 5 us of a dependent launch's floor)
+  constexpr int U = 8;
+  double sum = 0.0;
+  if (on)
+    for (int t0 = tr; t0 < ntile; t0 += U * tstep) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * tstep;
+        v[u] = base[(t < ntile ? t : tr) * rstride];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (t0 + u * tstep < ntile) sum += (double)v[u];
     }
-    float* o = coef + ((long)b * C + c) * 4;
-    o[0] = gm * rstd;
-    o[1] = bt - meanf * gm * rstd;
-    o[2] = gm;
-    o[3] = meanf;
-    float* ab = coef + (long)gridDim.y * C * 8 + ((long)b * C + c) * 2;  // compact copy behind bcoef (cgd_gn_ab)
-    ab[0] = o[0];
-    ab[1] = o[1];
-  }
+  const double items = (double)ntile * cpg;
+  const double mean = block_sum256(sum, red) / items;
+  double m2 = 0.0;
+  if (on)
+    for (int t0 = tr; t0 < ntile; t0 += U * tstep) {
+      float2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * tstep;
+        v[u] = *(const float2*)(base + (t < ntile ? t : tr) * rstride);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (t0 + u * tstep < ntile) {
+          const double d = (double)v[u].x - mean;
+          m2 += (double)v[u].y + 128.0 * d * d;
+        }
+    }
+  m2 = block_sum256(m2, red);
+  const double var = m2 / (items * 128.0);
+  gn_fold_group(b, g, lane, cpg, (float)mean, (float)(1.0 / sqrt(var + (double)eps)), stats, gamma, beta, film, ldfilm, coef);
 }
 
 // y = act(x*a + b)
@@ -370,6 +431,48 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_kernel(const float* __restric
     p1 += v.x;
     p2 += v.y;
   }
+  p1 = block_sum256(p1, red);
+  p2 = block_sum256(p2, red);
+  const double N = (double)HW * cpg;
+  const float rstd = stats[((long)b * 32 + g) * 2 + 1];
+  const float a2 = (float)((double)rstd * rstd * rstd * p2 / N), a3 = (float)((double)rstd * p1 / N);
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 256) {
+    float* o = bcoef + ((long)b * C + c) * 4;
+    o[0] = rstd * coef[((long)b * C + c) * 4 + 2];
+    o[1] = a2;
+    o[2] = a3;
+    o[3] = 0.f;
+  }
+}
+
+// The same from the records a dgrad conv's epilogue took (ChanStatsEntry kind 1): per (128-pixel half tile, channel) the pair
+// (gcoef * sum du, gcoef * sum du (x - mean)).  One block per (b, group); thread mapping and load batching of gn_stats_final_ch_kernel.
+__global__ __launch_bounds__(256) void gn_bwd_coef_ch_kernel(const float* __restrict__ rec, int ntile, int lg, const float* __restrict__ stats,
+                                                             const float* __restrict__ coef, int C, int HW, float* __restrict__ bcoef) {
+  __shared__ double red[4];
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  const int cpg = C / 32;
+  const int ci = lane & ((1 << lg) - 1), tr = lane >> lg, tstep = 256 >> lg;
+  const bool on = ci < cpg;
+  const float* base = rec + ((long)b * ntile * C + g * cpg + ci) * 2;
+  const long rstride = 2L * C;
+  constexpr int U = 8;
+  double p1 = 0.0, p2 = 0.0;
+  if (on)
+    for (int t0 = tr; t0 < ntile; t0 += U * tstep) {
+      float2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * tstep;
+        v[u] = *(const float2*)(base + (t < ntile ? t : tr) * rstride);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (t0 + u * tstep < ntile) {
+          p1 += (double)v[u].x;
+          p2 += (double)v[u].y;
+        }
+    }
   p1 = block_sum256(p1, red);
   p2 = block_sum256(p2, red);
   const double N = (double)HW * cpg;
@@ -1024,6 +1127,11 @@ const float* cgd_gn_ab(const float* scratch, int B, int HW, int C) {
   return scratch + (size_t)B * nchunk * 64 + (size_t)B * 64 + (size_t)B * C * 4 * 2;
 }
 
+const float* cgd_gn_coef(const float* scratch, int B, int HW, int C) {
+  const int nchunk = cdiv(HW, pick_chunk(HW, B));
+  return scratch + (size_t)B * nchunk * 64 + (size_t)B * 64;
+}
+
 // scratch layout: part | stats (B*64) | coef (B*C*4) | bcoef (B*C*4) | ab (B*C*2)
 static void gn_layout(float* scratch, int B, int HW, int C, int* chunk, int* nchunk, float** part, float** stats, float** coef,
                       float** bcoef) {
@@ -1052,8 +1160,27 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
     CGD_TRY(cgd_flush_pending(ctx, s));
     src = SplitSrc();
   }
-  ProfRec pr;  // algorithmic HBM bytes of a GroupNorm forward: one read of x, one write of y; statistics only: the read
+  // statistics a conv epilogue already took for exactly this tensor in this pass (ChanStatsEntry): merge the records, no sweep over x
+  ChanSrc cs;
+  const bool epi = !src.n && HW > GN_SMALL_HW && !(HW & 127) && (ctx->gn_epi & 1) && cgd_chanstats_find(ctx, x, ldx, (long)B * HW, C, s, &cs);
+  ProfRec pr;  // algorithmic HBM bytes of a GroupNorm forward: one read of x, one write of y; statistics only: the read (the
+               // figure is the operation's, also when the producer's epilogue has already taken the statistics and the read never happens)
   CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (y ? 8.0 : 4.0) * B * HW * C, s));
+  if (epi) {
+    int lg = 0;
+    while ((1 << lg) < C / 32) ++lg;
+    CGD_LAUNCH(gn_stats_final_ch_kernel, dim3(32, B), dim3(256), 0, s, cs, HW / 128, C / 32, lg, eps, stats, gamma, beta, film, ldfilm, coef);
+    if (y) {
+      if (act)
+        CGD_LAUNCH((gn_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+      else
+        CGD_LAUNCH((gn_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, y, ldy, HW, C, chunk, coef);
+    }
+    CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
+    cgd_prof_push(ctx, &pr);
+    CGD_HIP(ctx, hipGetLastError());
+    return 0;
+  }
   if (HW <= GN_SMALL_HW) {
     if (act)
       launch_gn_small_fwd<1>(x, ldx, y, ldy, B, HW, C, gamma, beta, film, ldfilm, eps, stats, coef, s, src);
@@ -1103,12 +1230,20 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
-  if (act) {
-    CGD_LAUNCH((gn_bwd_partial_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
+  // the dgrad conv that produced dz may already have taken this norm's backward sums in its epilogue (ChanStatsEntry kind 1): merge its records
+  ChanSrc cs;
+  if (!src.n && !(HW & 127) && (ctx->gn_epi & 2) && cgd_chanstats_find(ctx, dz, lddz, (long)B * HW, C, s, &cs, 1) && cs.n0 == C) {
+    int lg = 0;
+    while ((1 << lg) < C / 32) ++lg;
+    CGD_LAUNCH(gn_bwd_coef_ch_kernel, dim3(32, B), dim3(256), 0, s, cs.p0, HW / 128, lg, stats, coef, C, HW, bcoef);
   } else {
-    CGD_LAUNCH((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
+    if (act) {
+      CGD_LAUNCH((gn_bwd_partial_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
+    } else {
+      CGD_LAUNCH((gn_bwd_partial_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, (float*)dz, lddz, HW, C, chunk, coef, part, src);
+    }
+    CGD_LAUNCH(gn_bwd_coef_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
   }
-  CGD_LAUNCH(gn_bwd_coef_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
   if (act) {
     CGD_LAUNCH((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
                        HW, C, chunk, coef, bcoef);
@@ -1174,4 +1309,57 @@ int cgd_launch_ln_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dy, in
   }
   CGD_HIP(ctx, hipGetLastError());
   return 0;
+}
+
+// ---- conv-epilogue statistics registry (common.h ChanStatsEntry) -----------------------------------------------------------------
+float* cgd_chanstats_register(cgd_ctx* ctx, const float* C, int ldc, int N, long M, hipStream_t s, int kind) {
+  if ((M & 127) || (N & 3)) return nullptr;
+  const size_t need = (size_t)(M / 128) * N * 2;
+  ChanStatsEntry* e = nullptr;
+  for (ChanStatsEntry& q : ctx->chanstats)
+    if (q.C == C && q.kind == kind) e = &q;
+  if (!e) {
+    ctx->chanstats.emplace_back();
+    e = &ctx->chanstats.back();
+    e->C = C;
+    e->kind = kind;
+  }
+  if (e->cap < need) {
+    // grow-only, at most once per tensor shape: the old block may still be read by a kernel in flight on another stream
+    if (e->buf) (void)hipDeviceSynchronize(), (void)hipFree(e->buf);
+    e->buf = nullptr;
+    e->cap = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, need * sizeof(float)) != hipSuccess) {
+      (void)hipGetLastError();
+      e->serial = 0;
+      return nullptr;
+    }
+    e->buf = (float*)p;
+    e->cap = need;
+  }
+  e->ldc = ldc; e->N = N; e->M = M; e->stream = s; e->serial = ctx->stats_serial; e->kind = kind;
+  return e->buf;
+}
+
+bool cgd_chanstats_find(cgd_ctx* ctx, const float* x, int ldx, long M, int Cn, hipStream_t s, ChanSrc* out, int kind) {
+  auto hit = [&](const float* p) -> const ChanStatsEntry* {
+    for (const ChanStatsEntry& q : ctx->chanstats)
+      if (q.C == p && q.ldc == ldx && q.M == M && q.stream == s && q.serial == ctx->stats_serial && q.kind == kind && q.buf) return &q;
+    return nullptr;
+  };
+  const ChanStatsEntry* a = hit(x);
+  if (!a || a->N > Cn) return false;
+  out->p0 = a->buf; out->n0 = a->N; out->p1 = nullptr; out->n1 = 0;
+  if (a->N == Cn) return true;
+  const ChanStatsEntry* b = hit(x + a->N);  // the skip half of a concat
+  if (!b || a->N + b->N != Cn) return false;
+  out->p1 = b->buf; out->n1 = b->N;
+  return true;
+}
+
+void cgd_chanstats_clear(cgd_ctx* ctx) {
+  for (ChanStatsEntry& q : ctx->chanstats)
+    if (q.buf) (void)hipFree(q.buf);
+  ctx->chanstats.clear();
 }

@@ -161,6 +161,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   c1.B = cw1f; c1.Bpk = cw1fp; c1.Bwk = wino_ready ? cw1wp : nullptr; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
   c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
   c1.defer = 1;  // a split-K launch leaves its slices for the GroupNorm right below (SplitSrc)
+  c1.stats = 1;  // ... and a wconv_kernel launch takes the statistics that GroupNorm needs in its epilogue (ChanStatsEntry)
   // in_layers: GN -> SiLU.  When conv1 runs on the halo kernel (and nothing else reads the normalised tensor: `down` blocks
   // pool it first) the kernel applies SiLU(GN(x)) while it stages its input: only the statistics pass runs here and h1 is
   // never materialised.
@@ -196,6 +197,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   c2.A = h2.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.Bwk = wino_ready ? cw2wp : nullptr; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   c2.defer = 1;  // the next module starts with a GroupNorm of this tensor (or the launcher flushes: concat inputs, the head)
+  c2.stats = 1;  // (both halves of a skip concat carry their own records: the GroupNorm of the concat merges the two sources)
   const bool fuse2 = cgd_conv_uses_hconv(ctx, c2);
   if (fuse2) {
     CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, nullptr, 0, B, Ho * Wo, cout, g2, b2, u.emb_all.p + emb_off, (int)u.emb_total, 1, 1e-5f,
@@ -237,6 +239,8 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.Bwk = wino_ready ? cw2wd : nullptr; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   c2.defer = 1;
+  // a wconv_kernel launch takes the backward sums of GN2 (input h2, upstream gradient d3 = this conv's output) in its epilogue
+  c2.gnb_x = h2.p; c2.gnb_ldx = cout; c2.gnb_coef = cgd_gn_coef(s2.p, B, Ho * Wo, cout); c2.gnb_act = 1;
   CGD_TRY(cgd_launch_gemm(ctx, c2, s));
   // GN2 + FiLM + SiLU backward
   CGD_TRY(cgd_launch_gn_bwd(ctx, h2.p, cout, d3.p, cout, d2.p, cout, nullptr, 0, B, Ho * Wo, cout, 1, s2.p, s));
@@ -266,6 +270,9 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.Bwk = wino_ready ? cw1wd : nullptr; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
   c1.M = (int)npo; c1.N = cin; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cout;
   c1.defer = (up || down) ? 0 : 1;  // plain blocks: GN1's backward below consumes the slices; resampling blocks read d1 first
+  if (!up && !down) {  // ... and GN1's backward sums come from this conv's epilogue (its output d1 is GN1's upstream gradient at the same pixels)
+    c1.gnb_x = x.p; c1.gnb_ldx = x.ld; c1.gnb_coef = cgd_gn_coef(s1.p, B, H * W, cin); c1.gnb_act = 1;
+  }
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
   const float* dh1 = d1.p;
   if (down) {
@@ -566,6 +573,7 @@ int UNet::forward(const float* x, const float* t, const int64_t* y, float* out, 
   if (cfg.num_classes > 0 && !y) CGD_FAIL(ctx, "unet: class-conditional model needs y");
   B = Bn; H = Hh; W = Ww;
   have_fwd = false;
+  ++ctx->stats_serial;  // conv-epilogue statistics of earlier passes are dead from here on (ChanStatsEntry)
   const int mc = cfg.model_channels;
   // ---- embeddings (independent of x: no backward) ----
   CGD_TRY(ensure(temb, (size_t)B * mc));

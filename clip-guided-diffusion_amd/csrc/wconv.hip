@@ -79,6 +79,12 @@ struct WConvParams {
   int M, N, H, W, Cin, ups;
   float alpha;
   int nmajor;
+  float* stat;  // per-(half tile, channel) statistics of the output (common.h ChanStatsEntry) or null
+  // dgrad launches whose output is the upstream gradient of a GroupNorm(+SiLU): that norm's backward sums per (half tile, channel) (kind 1)
+  float* bstat;
+  const float* bx;     // the norm's forward input, rows like the output
+  const float* bcoef;  // {a, b, gcoef, mean} per (sample, channel)
+  int ldbx, bact;
 };
 
 __device__ __forceinline__ wbf16x4 w_bf16x4(const wf32x4 v) {
@@ -97,7 +103,12 @@ __device__ __forceinline__ float w_silu(float x, float a, float b) {
   return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));  // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
 }
 
-template <bool GN, int NB>
+// NC (round 4) = 32-channel output blocks per wavefront.  NC = 2 on 8-row tiles (NB = 2): the workgroup covers 8 x 16 pixels x 256 channels with the
+// same 256 accumulators as the 16 x 16 x 128 tile, but every A fragment read from LDS now feeds two MFMA sets (4 ds_read_b128 per 12 MFMAs instead
+// of 8: the 16-row tile keeps the LDS pipe ~2/3 busy with fragment reads alone), and a pixel tile's patch is staged — loaded, normalised, SiLU'd,
+// transformed, split — once per 256 output channels instead of once per 128 (0.56x the staging work per MFMA incl. the taller halo).  The weight
+// fragment traffic per MFMA is unchanged (4 global loads per 12 MFMAs).  Epilogue: one channel block at a time through a 16 KB slab per wavefront.
+template <bool GN, int NB, int NC = 1>
 __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg,
                                                     const float* __restrict__ gng, const WConvParams p) {
@@ -109,14 +120,15 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   const int l31 = lane & 31, hh = lane >> 5;
   W_STAMP(0);
 
-  const int ntn = (p.N + 127) >> 7;
+  constexpr int TN = 128 * NC;  // output channels per workgroup
+  const int ntn = (p.N + TN - 1) / TN;
   int bid = blockIdx.x;
   {
     const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int ntm = gridDim.x / ntn;
-  const int mt = p.nmajor ? bid % ntm : bid / ntn, n0 = (p.nmajor ? bid / ntm : bid % ntn) << 7;
+  const int mt = p.nmajor ? bid % ntm : bid / ntn, n0 = (p.nmajor ? bid / ntm : bid % ntn) * TN;
   const int tpr = p.W >> 4, tpi = (p.H / TR) * tpr;
   const int img = mt / tpi, trem = mt - img * tpi;
   const int y0 = (trem / tpr) * TR, x0 = (trem % tpr) << 4;
@@ -148,18 +160,21 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   for (int t = 0; t < 4; ++t) fro[t] = lr * WROW + lp * 32 + ((hh + lr + t) & 3) * 8;
 
   const int nchunk = p.Cin >> 5;
-  const int nb0 = (n0 >> 5) + wave;
+  const int nb0 = (n0 >> 5) + NC * wave;  // this wavefront's NC consecutive 32-channel blocks
   const int nbN = p.N >> 5;
   const long bstride_nb = (long)nchunk * (WSTEPS * 2 * 64);
   const uint4* __restrict__ Bw0 = Bg + (long)(nb0 < nbN ? nb0 : nbN - 1) * bstride_nb + lane;
+  const long bnext = (NC > 1 && nb0 + 1 < nbN) ? bstride_nb : 0;  // offset of the second block's fragments (clamped like the first)
 
-  wf32x16 acc[4][NB];  // [position][block]
+  wf32x16 acc[4][NB][NC];  // [position][pixel block][channel block]
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[x][b][e] = 0.f;
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[x][b][c][e] = 0.f;
 
   wf32x4 pr[2][4];  // two tasks in flight
   wf32x4 ga[2];     // GN: {a0, b0, a1, b1}, {a2, b2, a3, b3} of this thread's channels in the chunk being staged
@@ -223,21 +238,25 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
 #define W_B_LOAD(DST, BASE, Q)                                                                       \
   {                                                                                                  \
     const uint4* bp_ = (BASE) + (Q) * 128;                                                           \
-    DST[0] = bp_[0];                                                                                 \
-    DST[1] = bp_[64];                                                                                \
+    DST[0][0] = bp_[0];                                                                              \
+    DST[0][1] = bp_[64];                                                                             \
+    if constexpr (NC > 1) {                                                                          \
+      DST[NC - 1][0] = bp_[bnext];                                                                   \
+      DST[NC - 1][1] = bp_[bnext + 64];                                                              \
+    }                                                                                                \
   }
 #define W_MFMA12(XI, AQ, BQ)                                                                         \
   {                                                                                                  \
-    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                   \
-        acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[0]), AQ[b][1], acc[XI][b], 0, 0, 0); \
-    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                   \
-        acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[1]), AQ[b][0], acc[XI][b], 0, 0, 0); \
-    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                   \
-        acc[XI][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[0]), AQ[b][0], acc[XI][b], 0, 0, 0); \
+    _Pragma("unroll") for (int c = 0; c < NC; ++c) _Pragma("unroll") for (int b = 0; b < NB; ++b)    \
+        acc[XI][b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[c][0]), AQ[b][1], acc[XI][b][c], 0, 0, 0); \
+    _Pragma("unroll") for (int c = 0; c < NC; ++c) _Pragma("unroll") for (int b = 0; b < NB; ++b)    \
+        acc[XI][b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[c][1]), AQ[b][0], acc[XI][b][c], 0, 0, 0); \
+    _Pragma("unroll") for (int c = 0; c < NC; ++c) _Pragma("unroll") for (int b = 0; b < NB; ++b)    \
+        acc[XI][b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[c][0]), AQ[b][0], acc[XI][b][c], 0, 0, 0); \
   }
 
   wbf16x8 af[2][NB][2];  // [pipeline slot][block][plane]
-  uint4 bq[WRING][2];    // [ring slot][plane]
+  uint4 bq[WRING][NC][2];  // [ring slot][channel block][plane]
   {
     // prologue: stage chunk 0 completely, start the weight ring
     W_GN_LOAD(0);
@@ -284,14 +303,15 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
       {
         const bool loads = w_load_task<NB>(q) >= 0;
         const bool puts = w_proc_task<NB>(q, 0) >= 0 || w_proc_task<NB>(q, 1) >= 0 || w_proc_task<NB>(q, 2) >= 0;
+        constexpr int NM = 3 * NB * NC;  // MFMAs per step: 12 (16-row tile, or 8-row tile x 2 channel blocks) or 6
 #pragma unroll
-        for (int r = 0; r < 3 * NB; ++r) {
+        for (int r = 0; r < NM; ++r) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       // MFMA
           if (r < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read (2 NB per step)
-          if (NB == 4 ? (r == 8 || r == 10) : (r == 4 || r == 5)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 2 weight fragments
-          if (loads && (NB == 4 ? (r & 1) : r < 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                // 4 patch loads
-          __builtin_amdgcn_sched_group_barrier(0x002, (GN ? 6 : 3) * (NB == 4 ? 1 : 2), 0);       // VALU
-          if (puts && (NB == 4 ? (r % 3) == 2 : r >= 2)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (<= 4 per step)
+          if (NC == 2 ? r >= 8 : (NB == 4 ? (r == 8 || r == 10) : (r == 4 || r == 5))) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 2 NC weight fragments
+          if (loads && (NM == 12 ? (r & 1) && r < 8 : r < 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 4 patch loads
+          __builtin_amdgcn_sched_group_barrier(0x002, (GN ? 6 : 3) * (NM == 12 ? 1 : 2), 0);      // VALU
+          if (puts && (NM == 12 ? (r % 3) == 2 : r >= 2)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (<= 4 per step)
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -312,8 +332,15 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
 
   // ---- epilogue: output transform in registers.  D = U x V^T in the 32x32 C/D layout: column (lane & 31) = pixel pair, row =
   //      channel (r & 3) + 8 (r >> 2) + 4 hh: accumulator quad g holds channels 8g + 4hh .. + 3 of the lane's pair.
-  const int cb0 = nb0 * 32;
-  if (cb0 >= p.N) return;
+#pragma unroll
+  for (int cj = 0; cj < NC; ++cj) {  // one 32-channel block of the wavefront at a time (the slab holds one)
+  const int cb0 = (nb0 + cj) * 32;
+  if (cb0 >= p.N) break;
+  if (cj > 0) {  // the previous block's slab reads are done before this block's writes (same wavefront, in-order LDS; compiler fence only)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   {
     // Stores.  In the C/D layout a lane holds 4 channels of a pixel: a wave-wide 16-byte store would touch 64 different
     // 128-byte lines (profiles/r3_wconv_timeline.txt: 7.6 us per tile on the CU's store path, the MFMA pipes idle).  The patch
@@ -329,7 +356,7 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
       for (int g = 0; g < 4; ++g) {
         wf32x4 m[4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) m[x] = wf32x4{acc[x][b][4 * g], acc[x][b][4 * g + 1], acc[x][b][4 * g + 2], acc[x][b][4 * g + 3]};
+        for (int x = 0; x < 4; ++x) m[x] = wf32x4{acc[x][b][cj][4 * g], acc[x][b][cj][4 * g + 1], acc[x][b][cj][4 * g + 2], acc[x][b][cj][4 * g + 3]};
         const int u = ((2 * g + hh) ^ lp) * 4;
         *(wf32x4*)&slab[pe * 32 + u] = (m[0] + m[1] + m[2]) * p.alpha;
         *(wf32x4*)&slab[(pe + 1) * 32 + u] = (m[1] - m[2] - m[3]) * p.alpha;
@@ -349,6 +376,23 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
     const long crow = (long)p.W * p.ldc, rrow = (long)p.W * p.ldr;
     const bool hb = biasg != nullptr;
     const wf32x4 bv = hb ? wf32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]} : z4;
+    // GroupNorm statistics of the finished tensor (p.stat, round 4): the lane sees 16 of the 128 pixels of every 8-row half tile for its 4 channels;
+    // sums shifted by the half tile's first pixel (robust when |mean| >> std, like norm.hip), merged over the 8 lanes of a channel quad with three
+    // xor-shuffles, written by the psub == 0 lanes as (mean, M2) per channel: 256 contiguous bytes per wavefront and half tile
+    const bool st_on = p.stat != nullptr;
+    wf32x4 s1 = z4, s2 = z4, kk = z4;
+    const bool bs_on = p.bstat != nullptr;
+    wf32x4 q1 = z4, q2 = z4, cfa = z4, cfb = z4, cfg_ = z4, cfm = z4;
+    const float* bxp = nullptr;
+    const long xrow = (long)p.W * p.ldbx;
+    if (bs_on) {
+      bxp = p.bx + m00 * p.ldbx + col;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const wf32x4 c_ = *(const wf32x4*)(p.bcoef + ((long)img * p.N + col + e) * 4);
+        cfa[e] = c_[0]; cfb[e] = c_[1]; cfg_[e] = c_[2]; cfm[e] = c_[3];
+      }
+    }
 #pragma unroll
     for (int i0 = 0; i0 < 2 * TR; i0 += 8) {  // 8 instructions = 4 tile rows in flight
       wf32x4 v[8];
@@ -370,8 +414,75 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) *(wf32x4*)&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc] = v[u];
+      if (bs_on) {
+        // du = dz * SiLU'(x a + b); sums of du and du (x - mean) over the half tile (norm.hip gn_bwd_partial_kernel's arithmetic, v_rcp for the
+        // division); x is read like a residual would be (whole lines)
+        wf32x4 xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = *(const wf32x4*)&bxp[((i0 + u) >> 1) * xrow + 8 * (u & 1) * p.ldbx];
+        if ((i0 & 15) == 0) q1 = q2 = z4;
+        // (vector arithmetic: the compiler packs it into v_pk_fma / v_pk_mul / v_pk_add; the two transcendentals per element dominate)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          wf32x4 d = v[u];
+          if (p.bact) {
+            const wf32x4 uu = xv[u] * cfa + cfb;
+            wf32x4 sg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sg[e] = __builtin_amdgcn_rcpf(1.f + __expf(-uu[e]));
+            d *= sg * (1.f + uu * (1.f - sg));
+          }
+          q1 += d;
+          q2 += d * (xv[u] - cfm);
+        }
+        if ((i0 & 15) == 8) {
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              q1[e] += __shfl_xor(q1[e], o, 64);
+              q2[e] += __shfl_xor(q2[e], o, 64);
+            }
+          if (psub == 0) {
+            const long pt = ((long)img * (p.H >> 3) + (y0 >> 3) + (i0 >> 4)) * (p.W >> 4) + (x0 >> 4);
+            float* so = p.bstat + (pt * p.N + col) * 2;
+            *(wf32x4*)so = wf32x4{cfg_[0] * q1[0], cfg_[0] * q2[0], cfg_[1] * q1[1], cfg_[1] * q2[1]};
+            *(wf32x4*)(so + 4) = wf32x4{cfg_[2] * q1[2], cfg_[2] * q2[2], cfg_[3] * q1[3], cfg_[3] * q2[3]};
+          }
+        }
+      }
+      if (st_on) {
+        if ((i0 & 15) == 0) {  // first 4 rows of a half tile: the shift is the value of its first pixel (lane `quad` holds it in v[0])
+          s1 = s2 = z4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) kk[e] = __shfl(v[0][e], quad, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const wf32x4 d = v[u] - kk;
+          s1 += d;
+          s2 += d * d;
+        }
+        if ((i0 & 15) == 8) {  // last 4 rows of the half tile
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s1[e] += __shfl_xor(s1[e], o, 64);
+              s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+          if (psub == 0) {
+            const long pt = ((long)img * (p.H >> 3) + (y0 >> 3) + (i0 >> 4)) * (p.W >> 4) + (x0 >> 4);
+            float* so = p.stat + (pt * p.N + col) * 2;
+            const wf32x4 mean = kk + s1 * (1.f / 128.f), m2 = s2 - s1 * s1 * (1.f / 128.f);
+            *(wf32x4*)so = wf32x4{mean[0], m2[0], mean[1], m2[1]};
+            *(wf32x4*)(so + 4) = wf32x4{mean[2], m2[2], mean[3], m2[3]};
+          }
+        }
+      }
     }
   }
+  }  // cj
   W_STAMP(30);
 #ifdef CGD_WCONV_STAMPS
   if (lane == 0)
@@ -432,18 +543,26 @@ int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w, float* out, int Co, int 
 }
 
 // blocks of 4 tile rows per workgroup: 16-row tiles while they give every CU a workgroup, 8-row tiles otherwise (the 128x128 level)
-int cgd_wconv_nb(const cgd_ctx* ctx, const GemmParams& p) {
-  if (ctx->wino_mode == 2) return 4;  // A/B knob: 16-row tiles everywhere
-  if (ctx->wino_mode == 3) return 2;  //           8-row tiles everywhere
+static int wconv_nb_plain(const cgd_ctx* ctx, const GemmParams& p) {
+  if ((ctx->wino_mode & 3) == 2) return 4;  // A/B knob: 16-row tiles everywhere
+  if ((ctx->wino_mode & 3) == 3) return 2;  //           8-row tiles everywhere
   const long t16 = (long)(p.M / (p.H * p.W)) * (p.H >> 4) * (p.W >> 4) * cdiv(p.N, 128);
   return (!(p.H & 15) && t16 >= ctx->num_cu) ? 4 : 2;
 }
+// 32-channel blocks per wavefront (round 4): where the 16-row x 128-channel tile would run and the layer has whole 256-channel panels, the
+// 8-row x 256-channel tile takes its place (same workgroup count, same accumulators; see wconv_kernel); A/B knob CGD_WINO_NC=1 keeps the 16-row tile
+int cgd_wconv_nc(const cgd_ctx* ctx, const GemmParams& p) {
+  if (ctx->wino_nc == 1) return 1;
+  if (ctx->wino_nc == 3) return (p.N % 256 == 0) ? 2 : 1;  // everywhere it fits (A/B)
+  return (wconv_nb_plain(ctx, p) == 4 && p.N % 256 == 0) ? 2 : 1;
+}
+int cgd_wconv_nb(const cgd_ctx* ctx, const GemmParams& p) { return cgd_wconv_nc(ctx, p) == 2 ? 2 : wconv_nb_plain(ctx, p); }
 
 bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
   if (!p.conv || !p.Bwk || ctx->precision != CGD_PREC_BF16X3 || p.nbatch != 1 || p.splitk > 1) return false;
   if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
   if (p.H <= 0 || p.W <= 0 || (p.H & 7) || (p.W & 15) || p.M % (p.H * p.W)) return false;
-  if ((p.H & 15) && ctx->wino_mode == 2) return false;
+  if ((p.H & 15) && (ctx->wino_mode & 3) == 2) return false;
   if (p.ups && ((p.H | p.W) & 1)) return false;
   if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
   if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
@@ -459,14 +578,19 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.alpha = g.alpha;
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 12L * g.N >= g.M)) ? 1 : 0;
-  dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128));
-  const int nb = cgd_wconv_nb(ctx, g);
-#define WC_LAUNCH(GN_, NB_) \
-  CGD_LAUNCH((wconv_kernel<GN_, NB_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
+  // statistics for the GroupNorm that reads the output next (the tensor's rows are whole 8 x 16-pixel half tiles here: H % 8 == 0, W % 16 == 0)
+  p.stat = (g.stats && (ctx->gn_epi & 1)) ? cgd_chanstats_register(ctx, g.C, g.ldc, g.N, g.M, s) : nullptr;
+  p.bstat = nullptr; p.bx = g.gnb_x; p.bcoef = g.gnb_coef; p.ldbx = g.gnb_ldx; p.bact = g.gnb_act;
+  if (g.gnb_x && g.gnb_coef && (ctx->gn_epi & 2) && !(g.gnb_ldx & 3) && !((uintptr_t)g.gnb_x & 15) && !g.stats)
+    p.bstat = cgd_chanstats_register(ctx, g.C, g.ldc, g.N, g.M, s, 1);
+  const int nb = cgd_wconv_nb(ctx, g), nc = cgd_wconv_nc(ctx, g);
+  dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128 * nc));
+#define WC_LAUNCH(GN_, NB_, NC_) \
+  CGD_LAUNCH((wconv_kernel<GN_, NB_, NC_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
   if (g.gn_ab) {
-    if (nb == 4) WC_LAUNCH(true, 4); else WC_LAUNCH(true, 2);
+    if (nc == 2) WC_LAUNCH(true, 2, 2); else if (nb == 4) WC_LAUNCH(true, 4, 1); else WC_LAUNCH(true, 2, 1);
   } else {
-    if (nb == 4) WC_LAUNCH(false, 4); else WC_LAUNCH(false, 2);
+    if (nc == 2) WC_LAUNCH(false, 2, 2); else if (nb == 4) WC_LAUNCH(false, 4, 1); else WC_LAUNCH(false, 2, 1);
   }
 #undef WC_LAUNCH
   return 0;

@@ -297,11 +297,16 @@ def check_wconv():
     from cgd_amd import ops
     ctx = _ctx(1)
     out = []
-    for mode in (2, 3):  # 2: 16x16-pixel tiles (4 column blocks per wavefront), 3: 8x16-pixel tiles (2 blocks)
+    # 2: 16x16-pixel tiles (4 pixel blocks per wavefront), 3: 8x16-pixel tiles (2 blocks), 5 (round 4): 8x16 pixels x 256 channels (2 pixel
+    # blocks x 2 channel blocks per wavefront) wherever N is a multiple of 256
+    for mode in (2, 3, 5):
         ctx.check(ctx.lib.cgd_set_wino(ctx.h, mode, 0))
-        for (Bn, H, W, Ci, Co, ups, gn) in [(1, 16, 16, 32, 32, 0, 0), (1, 32, 48, 64, 160, 0, 0), (2, 16, 32, 96, 128, 0, 1),
-                                            (1, 64, 64, 64, 96, 1, 0), (1, 32, 32, 128, 256, 1, 1), (1, 128, 128, 32, 64, 0, 1),
-                                            (1, 256, 256, 32, 32, 0, 0), (2, 24, 32, 64, 64, 0, 1)]:
+        cases = [(1, 16, 16, 32, 32, 0, 0), (1, 32, 48, 64, 160, 0, 0), (2, 16, 32, 96, 128, 0, 1), (1, 64, 64, 64, 96, 1, 0),
+                 (1, 32, 32, 128, 256, 1, 1), (1, 128, 128, 32, 64, 0, 1), (1, 256, 256, 32, 32, 0, 0), (2, 24, 32, 64, 64, 0, 1)]
+        if mode == 5:  # several 256-channel panels forward, a 256-channel dgrad (N = Ci), three panels with a residual, batch + fused GN
+            cases = [(1, 32, 32, 128, 256, 1, 1), (1, 16, 32, 64, 512, 0, 0), (1, 32, 32, 256, 64, 0, 0), (1, 16, 16, 32, 768, 0, 0),
+                     (2, 24, 32, 64, 256, 0, 1), (1, 64, 64, 256, 256, 0, 0)]
+        for (Bn, H, W, Ci, Co, ups, gn) in cases:
             if mode == 2 and H % 16:
                 continue
             Hs, Ws = (H // 2, W // 2) if ups else (H, W)
