@@ -3,9 +3,13 @@
 // wall_clock64() (the 100 MHz constant clock) at entry, after chunk 0 is staged, after every chunk and after the epilogue's stores are
 // issued, plus XCC_ID / HW_ID, so that the workgroups a CU runs back to back can be lined up.  One extra 8-byte store per chunk.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include wconv_stamps.hip -o wconv_stamps
-// Usage: wconv_stamps H Cin N [gn 0|1] [nb 4|2] [reps] [csv|-] [unused] [residual 0|1]
+// Usage: wconv_stamps H Cin N [gn 0|1] [nb 4|2|22] [reps] [csv|-] [unused] [residual 0|1]     (nb 22 = 8-row tile x two channel blocks per wavefront)
+// -DCGD_WCONV_EXP=<bits>: ablation builds (see wconv.hip), timing only
 #define CGD_WCONV_STAMPS 1
 #include "../../clip-guided-diffusion_amd/csrc/wconv.hip"
+
+// the launcher in wconv.hip asks norm.hip for a statistics buffer; this stand-alone build takes no statistics
+float* cgd_chanstats_register(cgd_ctx*, const float*, int, int, long, hipStream_t, int) { return nullptr; }
 
 #include <string.h>
 
@@ -31,10 +35,10 @@ static double med(std::vector<double> v) {
 static double vmin(const std::vector<double>& v) { return v.empty() ? 0.0 : *std::min_element(v.begin(), v.end()); }
 static double vmax(const std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); }
 
-template <bool GN, int NB>
+template <bool GN, int NB, int NC = 1>
 static void launch(dim3 grid, const float* A, const uint4* B, float* C, const float* bias, const float* R, const float* gn, const WConvParams& p, int lep) {
   (void)lep;
-  hipLaunchKernelGGL((wconv_kernel<GN, NB>), grid, dim3(256), 0, 0, A, B, C, bias, R, gn, p);
+  hipLaunchKernelGGL((wconv_kernel<GN, NB, NC>), grid, dim3(256), 0, 0, A, B, C, bias, R, gn, p);
 }
 
 int main(int argc, char** argv) {
@@ -43,11 +47,12 @@ int main(int argc, char** argv) {
     return 2;
   }
   const int H = atoi(argv[1]), Cin = atoi(argv[2]), N = atoi(argv[3]);
-  const int gn = argc > 4 ? atoi(argv[4]) : 0, nb = argc > 5 ? atoi(argv[5]) : 4, reps = argc > 6 ? atoi(argv[6]) : 10;
+  const int gn = argc > 4 ? atoi(argv[4]) : 0, nbarg = argc > 5 ? atoi(argv[5]) : 4, reps = argc > 6 ? atoi(argv[6]) : 10;
+  const int nc = nbarg == 22 ? 2 : 1, nb = nbarg == 22 ? 2 : nbarg;
   const char* csv = argc > 7 && strcmp(argv[7], "-") ? argv[7] : nullptr;
   const int lep = argc > 8 ? atoi(argv[8]) : 0, res = argc > 9 ? atoi(argv[9]) : 0;
   const int W = H, TR = 4 * nb;
-  if ((H % TR) || (W & 15) || (Cin & 31) || (N & 127) || (nb != 4 && nb != 2)) {
+  if ((H % TR) || (W & 15) || (Cin & 31) || (N % (128 * nc)) || (nb != 4 && nb != 2)) {
     fprintf(stderr, "unsupported shape\n");
     return 2;
   }
@@ -81,20 +86,22 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(pack_wino_kernel, dim3(4096), dim3(256), 0, 0, dW, (__bf16*)dB, N, Cin, 0);
   CK(hipDeviceSynchronize());
 
-  WConvParams p;
+  WConvParams p = {};
   p.lda = Cin; p.ldc = N; p.ldr = res ? N : 0;
   p.M = (int)M; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ups = 0; p.alpha = 1.f;
   p.nmajor = 12L * N >= M ? 1 : 0;
-  const int tiles_m = (H / TR) * (W >> 4), nwg = tiles_m * (N >> 7), nchunk = Cin >> 5;
+  const int tiles_m = (H / TR) * (W >> 4), nwg = tiles_m * (N / (128 * nc)), nchunk = Cin >> 5;
   unsigned long long* dst;
   CK(hipMalloc(&dst, (size_t)nwg * 4 * 32 * 8));
   CK(hipMemset(dst, 0, (size_t)nwg * 4 * 32 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), &dst, sizeof(dst)));
   auto go = [&]() {
     if (gn) {
-      if (nb == 4) launch<true, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep); else launch<true, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep);
+      if (nc == 2) launch<true, 2, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep);
+      else if (nb == 4) launch<true, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep); else launch<true, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep);
     } else {
-      if (nb == 4) launch<false, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, nullptr, p, lep); else launch<false, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, nullptr, p, lep);
+      if (nc == 2) launch<false, 2, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, nullptr, p, lep);
+      else if (nb == 4) launch<false, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, nullptr, p, lep); else launch<false, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, nullptr, p, lep);
     }
   };
   hipEvent_t e0, e1;
@@ -150,6 +157,7 @@ int main(int argc, char** argv) {
     starts.push_back(x.start);
     ends.push_back(x.end);
   }
+  if (CGD_WCONV_EXP) printf("ABLATION %d (wrong results, timing only): ", CGD_WCONV_EXP);
   printf("wconv_kernel<%s, %d>%s  %dx%d  %d -> %d : %d workgroups, %d chunks; %.1f us per launch (events over %d launches); clock %d kHz\n",
          gn ? "true" : "false", nb, res ? " + residual" : "", H, W, Cin, N, nwg, nchunk, ms * 1e3 / reps, reps, khz);
   printf("last launch, us from the first wavefront's entry: last entry %.1f, first exit %.1f, last exit %.1f\n", vmax(starts), vmin(ends), vmax(ends));

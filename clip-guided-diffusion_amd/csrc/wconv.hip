@@ -74,6 +74,30 @@ __device__ unsigned long long* g_wstamps;  // [workgroup][wavefront][32]: 0 entr
   } while (0)
 #endif
 
+// Ablation switches for benchmarks/ubench/wconv_stamps.hip ONLY (results become wrong; the library build never defines the macro): which element of
+// the chunk loop costs what?  bit 0: no weight-fragment loads inside the loop, bit 1: no patch loads / transform / LDS writes inside the loop,
+// bit 2: no barrier per chunk, bit 3: no A-fragment LDS reads inside the loop, bit 4: no sched_group_barrier pattern (the compiler's own schedule)
+#ifndef CGD_WCONV_EXP
+#define CGD_WCONV_EXP 0
+#endif
+
+// De-phasing of the four wavefronts (round 4, profiles/r4_wconv_ablation.txt): they run the same schedule in lock-step after every barrier, so their
+// weight-fragment loads (and LDS reads) reach the CU's single vector-memory path at the same moment and each wavefront waits for the other three
+// (~60 cycles per global_load_dwordx4 with the MFMA issue of that in-order wavefront stopped).  CGD_WCONV_SKEW = n: wavefront w sleeps n * 64 * w
+// cycles after every barrier, which keeps the four schedules apart for the whole chunk.
+#ifndef CGD_WCONV_SKEW
+#define CGD_WCONV_SKEW 0
+#endif
+__device__ __forceinline__ void w_skew(int wave) {
+#if CGD_WCONV_SKEW > 0
+  if (wave == 1) __builtin_amdgcn_s_sleep(CGD_WCONV_SKEW);
+  if (wave == 2) __builtin_amdgcn_s_sleep(2 * CGD_WCONV_SKEW);
+  if (wave == 3) __builtin_amdgcn_s_sleep(3 * CGD_WCONV_SKEW);
+#else
+  (void)wave;
+#endif
+}
+
 struct WConvParams {
   int lda, ldc, ldr;
   int M, N, H, W, Cin, ups;
@@ -273,6 +297,7 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
     }
   }
   __syncthreads();
+  w_skew(wave);
   W_STAMP(1);
   for (int c = 0; c < nchunk; ++c) {
     const bool more = c + 1 < nchunk;
@@ -286,21 +311,23 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
 #pragma unroll
     for (int q = 0; q < WSTEPS; ++q) {
       // ---- issue: A fragments one step ahead, B fragments WDIST steps ahead, one staging task every 4 steps
-      if (q + 1 < WSTEPS) W_A_LOAD(af[(q + 1) & 1], cur, q + 1);
-      {
+      if constexpr (!(CGD_WCONV_EXP & 8))
+        if (q + 1 < WSTEPS) W_A_LOAD(af[(q + 1) & 1], cur, q + 1);
+      if constexpr (!(CGD_WCONV_EXP & 1)) {
         const int q2 = (q + WDIST) % WSTEPS;
         const uint4* __restrict__ base = (q + WDIST < WSTEPS) ? cb : nb;
         W_B_LOAD(bq[(q + WDIST) % WRING], base, q2);
       }
-      if (w_load_task<NB>(q) >= 0) W_TASK_LOAD(pr[w_load_task<NB>(q) & 1], (w_load_task<NB>(q) < 0 ? 0 : w_load_task<NB>(q)), cn);
+      if constexpr (!(CGD_WCONV_EXP & 2))
+        if (w_load_task<NB>(q) >= 0) W_TASK_LOAD(pr[w_load_task<NB>(q) & 1], (w_load_task<NB>(q) < 0 ? 0 : w_load_task<NB>(q)), cn);
       W_MFMA12((q >> 1) & 3, af[q & 1], bq[q % WRING]);
-      {
+      if constexpr (!(CGD_WCONV_EXP & 2)) {
         const int k1 = w_proc_task<NB>(q, 0), k2 = w_proc_task<NB>(q, 1), k3 = w_proc_task<NB>(q, 2);
         if (k1 >= 0) W_TASK_P1(nxt, pr[k1 & 1], (k1 < 0 ? 0 : k1));
         if (k2 >= 0) W_TASK_P2(nxt, pr[k2 & 1], (k2 < 0 ? 0 : k2));
         if (k3 >= 0) W_TASK_P3(nxt, pr[k3 & 1], (k3 < 0 ? 0 : k3));
       }
-      {
+      if constexpr (!(CGD_WCONV_EXP & 16)) {
         const bool loads = w_load_task<NB>(q) >= 0;
         const bool puts = w_proc_task<NB>(q, 0) >= 0 || w_proc_task<NB>(q, 1) >= 0 || w_proc_task<NB>(q, 2) >= 0;
         constexpr int NM = 3 * NB * NC;  // MFMAs per step: 12 (16-row tile, or 8-row tile x 2 channel blocks) or 6
@@ -316,7 +343,8 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();  // patch c consumed by every wavefront, patch c + 1 written
+    if constexpr (!(CGD_WCONV_EXP & 4)) __syncthreads();  // patch c consumed by every wavefront, patch c + 1 written
+    if (c + 1 < nchunk) w_skew(wave);
     W_STAMP(2 + (c < 27 ? c : 27));
   }
 #undef W_TASK_LOAD
