@@ -383,9 +383,10 @@ def test_launcher_shards_the_batch_like_the_single_process_run(tmp_path, monkeyp
     assert [(b, os.path.relpath(p, tmp_path / "one")) for b, p in single] == [(b, os.path.relpath(p, tmp_path / "two")) for b, p in sharded]
     for (_, a), (_, b) in zip(single, sharded):
         fa, fb = np.asarray(Image.open(a)).astype(int), np.asarray(Image.open(b)).astype(int)
-        # batch-1 and batch-2 launches pick different tiles / split-K factors: equal up to the last bits, i.e. at most 1 LSB on a
-        # uint8 frame and only on a handful of pixels
-        assert np.abs(fa - fb).max() <= 1 and (fa != fb).mean() < 1e-2, (a, np.abs(fa - fb).max(), (fa != fb).mean())
+        # batch-1 and batch-2 launches pick different tiles / split-K factors: equal up to the last bits, i.e. a uint8 frame that differs by
+        # an LSB or two on a handful of pixels (round 4: with the fan-in synthetic weights this 4-step full-schedule run is further from a
+        # trained model's tame regime and one element of the 12288 has been seen 2 LSB apart; a sharding bug would move whole frames)
+        assert np.abs(fa - fb).max() <= 2 and (fa != fb).mean() < 1e-3, (a, np.abs(fa - fb).max(), (fa != fb).mean())
 
 
 def test_use_augs_guided_steps_against_the_oracle():
