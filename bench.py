@@ -338,12 +338,12 @@ def main():
         tp = time.perf_counter()
         for _ in range(args.profile_steps):
             next(steps)
-        assert ctx.lib.cgd_profile_kinds() == 5
-        buf = (C.c_double * 15)()
+        assert ctx.lib.cgd_profile_kinds() == 6
+        buf = (C.c_double * 18)()
         ctx.check(ctx.lib.cgd_profile_read(ctx.h, buf))
         dtp = time.perf_counter() - tp
         ctx.check(ctx.lib.cgd_profile(ctx.h, 0))
-        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n, gn_ms, gn_bytes, gn_n, w_ms, w_flop, w_n, k_ms, k_flop, k_n = list(buf)
+        ig_ms, ig_flop, ig_n, h_ms, h_flop, h_n, gn_ms, gn_bytes, gn_n, w_ms, w_flop, w_n, k_ms, k_flop, k_n, wb_ms, wb_flop, wb_n = list(buf)
         ps = args.profile_steps
         nprod = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
 
@@ -367,6 +367,16 @@ def main():
         if legs:
             legs.sort(key=lambda leg: -leg["kernel_time_share"])  # the dominant kernel leads; the other 3x3-conv kernel rides along
             roof = dict({"bound": "mfma"}, **legs[0])
+            if w_n > 0 and wb_n > 0 and w_n > wb_n:
+                # the same kernel's launches apart: those whose epilogue also takes a GroupNorm's backward sums (dgrad convs: an extra read of the
+                # norm's input and two transcendentals per element with the MFMA pipe idle; the time it saves is gn_bwd_partial_kernel's) and the rest
+                pa = (w_flop - wb_flop) / ((w_ms - wb_ms) * 1e-3) / 1e12
+                pb = wb_flop / (wb_ms * 1e-3) / 1e12
+                roof["launch_classes"] = {
+                    "plain": {"launches_per_step": (w_n - wb_n) / ps, "avg_launch_us": round((w_ms - wb_ms) * 1e3 / (w_n - wb_n), 2),
+                              "achieved": round(pa, 2), "frac": round(pa / 2500.0, 4)},
+                    "with_groupnorm_backward_epilogue": {"launches_per_step": wb_n / ps, "avg_launch_us": round(wb_ms * 1e3 / wb_n, 2),
+                                                         "achieved": round(pb, 2), "frac": round(pb / 2500.0, 4)}}
             roof["measured_in"] = f"untimed pass of {ps} steps after the timed region"
             if len(legs) > 1:
                 roof["other_conv_kernel"] = legs[1]

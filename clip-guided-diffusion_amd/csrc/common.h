@@ -26,7 +26,9 @@ enum { CGD_PREC_F32 = 0, CGD_PREC_BF16X3 = 1, CGD_PREC_BF16 = 2 };
 // kinds of profiled launches (bench.py): MFMA GEMM kernels (igemm / hgemm incl. their split-K reduce), the direct halo conv kernel
 // alone, GroupNorm forward / backward (all launches of one norm; `work` = algorithmic HBM bytes), the Winograd halo conv kernel
 // (the dominant kernel of the step: the 3x3 convs of the >= 128x128-pixel levels), the weight-streaming halo conv kernel of the <= 32x32 maps
-enum { CGD_PROF_GEMM = 0, CGD_PROF_HCONV = 1, CGD_PROF_GN = 2, CGD_PROF_WCONV = 3, CGD_PROF_KCONV = 4, CGD_PROF_KINDS = 5 };
+// (round 4) kind 5: the wconv_kernel launches whose epilogue also takes a GroupNorm's backward sums (they are included in kind 3 as well: kind 3 stays
+// "every wconv_kernel launch", kind 5 lets bench.py report the two classes apart)
+enum { CGD_PROF_GEMM = 0, CGD_PROF_HCONV = 1, CGD_PROF_GN = 2, CGD_PROF_WCONV = 3, CGD_PROF_KCONV = 4, CGD_PROF_WCONV_GNB = 5, CGD_PROF_KINDS = 6 };
 
 struct ProfRec {
   hipEvent_t a = nullptr, b = nullptr;

@@ -676,8 +676,16 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
     }
 #undef GV_LAUNCH
   } else if (use_h) {
-    if (tile == 515)
+    if (tile == 515) {
+      ProfRec pr2;  // second record of the same launch for the launches that carry the GroupNorm-backward epilogue (kind 5)
+      const bool gnb = ctx->prof_on && p.gnb_x && p.gnb_coef && (ctx->gn_epi & 2) && !p.stats && !p.R;
+      if (gnb) CGD_TRY(cgd_prof_begin(ctx, &pr2, CGD_PROF_WCONV_GNB, 2.0 * p.M * p.N * p.K * p.nbatch, s));
       CGD_TRY(cgd_launch_wconv(ctx, p, s));
+      if (gnb) {
+        CGD_TRY(cgd_prof_stamp(ctx, &pr2, s));
+        cgd_prof_push(ctx, &pr2);
+      }
+    }
     else if (tile == 516)
       CGD_TRY(cgd_launch_kconv(ctx, p, s));
     else

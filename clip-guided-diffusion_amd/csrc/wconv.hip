@@ -421,19 +421,36 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
         cfa[e] = c_[0]; cfb[e] = c_[1]; cfg_[e] = c_[2]; cfm[e] = c_[3];
       }
     }
+    // The second operand of a group of 4 tile rows (the residual, or the norm's input x of the backward sums) comes from global memory behind a
+    // ~1.5 us latency and cannot be hoisted by the compiler above the stores of the previous group (it may alias the output): it is fetched one
+    // group ahead by hand (rows of different groups never overlap, also when the residual IS the output buffer)
+    wf32x4 opn[8];
+    const bool second = Rg != nullptr || bs_on;
+    const float* o2 = Rg ? rp : bxp;
+    const long o2row = Rg ? rrow : xrow;
+    const int o2ld = Rg ? p.ldr : p.ldbx;
+    if (second) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) opn[u] = *(const wf32x4*)&o2[(u >> 1) * o2row + 8 * (u & 1) * o2ld];
+    }
 #pragma unroll
     for (int i0 = 0; i0 < 2 * TR; i0 += 8) {  // 8 instructions = 4 tile rows in flight
-      wf32x4 v[8];
+      wf32x4 v[8], op[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = *(const wf32x4*)&((u & 1) ? sl1 : sl0)[(i0 + u) * 256];
-      if (Rg) {
-        wf32x4 r[8];
+      if (second) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) r[u] = *(const wf32x4*)&rp[((i0 + u) >> 1) * rrow + 8 * (u & 1) * p.ldr];
+        for (int u = 0; u < 8; ++u) op[u] = opn[u];
+        if (i0 + 8 < 2 * TR) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) opn[u] = *(const wf32x4*)&o2[((i0 + 8 + u) >> 1) * o2row + 8 * (u & 1) * o2ld];
+        }
+      }
+      if (Rg) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           if (hb) v[u] += bv;
-          v[u] += r[u];
+          v[u] += op[u];
         }
       } else {
 #pragma unroll
@@ -445,9 +462,7 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
       if (bs_on) {
         // du = dz * SiLU'(x a + b); sums of du and du (x - mean) over the half tile (norm.hip gn_bwd_partial_kernel's arithmetic, v_rcp for the
         // division); x is read like a residual would be (whole lines)
-        wf32x4 xv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) xv[u] = *(const wf32x4*)&bxp[((i0 + u) >> 1) * xrow + 8 * (u & 1) * p.ldbx];
+        const wf32x4(&xv)[8] = op;  // (a launch has a residual or the backward sums, never both: the launcher checks)
         if ((i0 & 15) == 0) q1 = q2 = z4;
         // (vector arithmetic: the compiler packs it into v_pk_fma / v_pk_mul / v_pk_add; the two transcendentals per element dominate)
 #pragma unroll
@@ -609,7 +624,7 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   // statistics for the GroupNorm that reads the output next (the tensor's rows are whole 8 x 16-pixel half tiles here: H % 8 == 0, W % 16 == 0)
   p.stat = (g.stats && (ctx->gn_epi & 1)) ? cgd_chanstats_register(ctx, g.C, g.ldc, g.N, g.M, s) : nullptr;
   p.bstat = nullptr; p.bx = g.gnb_x; p.bcoef = g.gnb_coef; p.ldbx = g.gnb_ldx; p.bact = g.gnb_act;
-  if (g.gnb_x && g.gnb_coef && (ctx->gn_epi & 2) && !(g.gnb_ldx & 3) && !((uintptr_t)g.gnb_x & 15) && !g.stats)
+  if (g.gnb_x && g.gnb_coef && (ctx->gn_epi & 2) && !(g.gnb_ldx & 3) && !((uintptr_t)g.gnb_x & 15) && !g.stats && !g.R)
     p.bstat = cgd_chanstats_register(ctx, g.C, g.ldc, g.N, g.M, s, 1);
   const int nb = cgd_wconv_nb(ctx, g), nc = cgd_wconv_nc(ctx, g);
   dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128 * nc));

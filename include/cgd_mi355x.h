@@ -44,9 +44,10 @@ int cgd_set_hgemm(cgd_ctx* ctx, int mode, int min_m, int min_chunks);
  * cgd_profile_read: out[3k .. 3k+2] = {summed ms, algorithmic work, launches} of kind k: 0 = igemm_kernel / hgemm_kernel launches
  * incl. their split-K reduce [FLOP], 1 = hconv2_kernel launches alone [FLOP], 2 = GroupNorm forward / backward ops, all launches
  * of one norm [algorithmic HBM bytes], 3 = wconv_kernel launches alone (the dominant kernel) [FLOP], 4 = kconv_kernel launches alone
- * (the weight-streaming conv kernel of the <= 32x32-pixel maps) [FLOP]: 15 doubles; synchronises the device and resets. */
+ * (the weight-streaming conv kernel of the <= 32x32-pixel maps) [FLOP], 5 = the wconv_kernel launches that carry a GroupNorm-backward
+ * epilogue (a subset of kind 3) [FLOP]: 3 * cgd_profile_kinds() = 18 doubles; synchronises the device and resets. */
 int cgd_profile(cgd_ctx* ctx, int enable);
-int cgd_profile_read(cgd_ctx* ctx, double* out15);
+int cgd_profile_read(cgd_ctx* ctx, double* out18);
 /* number of kinds k above (the buffer of cgd_profile_read holds 3 * cgd_profile_kinds() doubles) */
 int cgd_profile_kinds(void);
 /* measurement: process-wide counters since the library was loaded: out2[0] = kernel launches, out2[1] = split-K reduce launches

@@ -126,7 +126,7 @@ int main() {
     cgd_ctx_destroy(nullptr);
     EXPECT(cgd_set_precision(nullptr, 1) == -3);
     EXPECT(cgd_profile(nullptr, 1) == -3);
-    double buf[15];
+    double buf[18];  // 3 * cgd_profile_kinds()
     EXPECT(cgd_profile_read(nullptr, buf) == -3);
     cgd_unet_config c = unet_cfg(64, 64, 1, {1, 2}, {2}, 0, 4, -1, 0);
     cgd_unet* u = nullptr;
