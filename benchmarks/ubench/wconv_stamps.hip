@@ -35,10 +35,10 @@ static double med(std::vector<double> v) {
 static double vmin(const std::vector<double>& v) { return v.empty() ? 0.0 : *std::min_element(v.begin(), v.end()); }
 static double vmax(const std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); }
 
-template <bool GN, int NB, int NC = 1>
+template <bool GN, int NB, int NC = 1, int OCC = 1>
 static void launch(dim3 grid, const float* A, const uint4* B, float* C, const float* bias, const float* R, const float* gn, const WConvParams& p, int lep) {
   (void)lep;
-  hipLaunchKernelGGL((wconv_kernel<GN, NB, NC>), grid, dim3(256), 0, 0, A, B, C, bias, R, gn, p);
+  hipLaunchKernelGGL((wconv_kernel<GN, NB, NC, OCC>), grid, dim3(256), 0, 0, A, B, C, bias, R, gn, p);
 }
 
 int main(int argc, char** argv) {
@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
   }
   const int H = atoi(argv[1]), Cin = atoi(argv[2]), N = atoi(argv[3]);
   const int gn = argc > 4 ? atoi(argv[4]) : 0, nbarg = argc > 5 ? atoi(argv[5]) : 4, reps = argc > 6 ? atoi(argv[6]) : 10;
-  const int nc = nbarg == 22 ? 2 : 1, nb = nbarg == 22 ? 2 : nbarg;
+  const int nc = nbarg == 22 ? 2 : 1, nb = (nbarg == 22 || nbarg == 222) ? 2 : nbarg, occ2 = nbarg == 222;  // 222: 8-row tile, two workgroups per CU
   const char* csv = argc > 7 && strcmp(argv[7], "-") ? argv[7] : nullptr;
   const int lep = argc > 8 ? atoi(argv[8]) : 0, res = argc > 9 ? atoi(argv[9]) : 0;
   const int W = H, TR = 4 * nb;
@@ -96,7 +96,9 @@ int main(int argc, char** argv) {
   CK(hipMemset(dst, 0, (size_t)nwg * 4 * 32 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), &dst, sizeof(dst)));
   auto go = [&]() {
-    if (gn) {
+    if (occ2) {
+      if (gn) launch<true, 2, 1, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep); else launch<false, 2, 1, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, nullptr, p, lep);
+    } else if (gn) {
       if (nc == 2) launch<true, 2, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep);
       else if (nb == 4) launch<true, 4>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep); else launch<true, 2>(dim3(nwg), dA, (const uint4*)dB, dC, dbias, dR, dab, p, lep);
     } else {

@@ -48,14 +48,16 @@ constexpr int WRING = 8, WDIST = WRING - 1;
 // in three pieces at the steps w_proc_task(q, piece) == k.  NB = 4 (16 tile rows, 12 MFMAs per step): 5 tasks, loaded every 4th
 // step, transformed 5..7 steps (1920 MFMA cycles) later.  NB = 2 (8 tile rows, 6 MFMAs per step): 3 tasks, loads at steps 0, 4 and
 // 13 (slot 0 is free after step 12), transformed from steps 10, 14 and 21.
-template <int NB>
+template <int NB, int OCC = 1>
 __host__ __device__ constexpr int w_load_task(int q) {
+  if (OCC == 2) return q == 0 ? 0 : q == 8 ? 1 : q == 16 ? 2 : -1;  // one staging register set: a task is transformed before the next is loaded
   if (NB == 4) return ((q & 3) == 0 && q < 20) ? (q >> 2) : -1;
   return q == 0 ? 0 : q == 4 ? 1 : q == 13 ? 2 : -1;
 }
-template <int NB>
+template <int NB, int OCC = 1>
 __host__ __device__ constexpr int w_proc_task(int q, int piece) {
   const int s = q - piece;
+  if (OCC == 2) return s == 5 ? 0 : s == 13 ? 1 : s == 21 ? 2 : -1;
   if (NB == 4) return (s >= 5 && ((s - 5) & 3) == 0) ? ((s - 5) >> 2) : -1;
   return s == 10 ? 0 : s == 14 ? 1 : s == 21 ? 2 : -1;
 }
@@ -132,8 +134,12 @@ __device__ __forceinline__ float w_silu(float x, float a, float b) {
 // of 8: the 16-row tile keeps the LDS pipe ~2/3 busy with fragment reads alone), and a pixel tile's patch is staged — loaded, normalised, SiLU'd,
 // transformed, split — once per 256 output channels instead of once per 128 (0.56x the staging work per MFMA incl. the taller halo).  The weight
 // fragment traffic per MFMA is unchanged (4 global loads per 12 MFMAs).  Epilogue: one channel block at a time through a 16 KB slab per wavefront.
-template <bool GN, int NB, int NC = 1>
-__global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+// OCC = 2 (round 4, 8-row tile with one channel block only): TWO workgroups per CU = two wavefronts per SIMD, the one thing the ablations say
+// overlaps a wavefront's vector-memory / staging instructions with MFMA issue (profiles/r4_wconv_ablation.txt).  The 8-row tile's two patch buffers
+// are exactly half of the CU's 160 KB of LDS and its 128 accumulators leave 128 registers per wavefront: the weight ring shrinks to 4 steps
+// (the other workgroup's MFMAs cover the shorter prefetch distance).
+template <bool GN, int NB, int NC = 1, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg,
                                                     const float* __restrict__ gng, const WConvParams p) {
   constexpr int TR = 4 * NB;               // tile rows (16 or 8); the tile is 16 pixels wide
@@ -144,6 +150,8 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   const int l31 = lane & 31, hh = lane >> 5;
   W_STAMP(0);
 
+  static_assert(OCC == 1 || (NB == 2 && NC == 1), "two workgroups per CU: 8-row tile, one channel block");
+  constexpr int RING = OCC == 2 ? 4 : WRING, DIST = RING - 1;  // weight-fragment ring (steps)
   constexpr int TN = 128 * NC;  // output channels per workgroup
   const int ntn = (p.N + TN - 1) / TN;
   int bid = blockIdx.x;
@@ -200,7 +208,8 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[x][b][c][e] = 0.f;
 
-  wf32x4 pr[2][4];  // two tasks in flight
+  wf32x4 pr[OCC == 2 ? 1 : 2][4];  // two tasks in flight (one with two workgroups per CU)
+  constexpr int PM = OCC == 2 ? 0 : 1;  // staging set of task k = pr[k & PM]
   wf32x4 ga[2];     // GN: {a0, b0, a1, b1}, {a2, b2, a3, b3} of this thread's channels in the chunk being staged
   const wf32x4 z4 = wf32x4{0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ gnimg = GN ? gng + ((long)img * p.Cin + c4 * 4) * 2 : nullptr;
@@ -280,12 +289,12 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
   }
 
   wbf16x8 af[2][NB][2];  // [pipeline slot][block][plane]
-  uint4 bq[WRING][NC][2];  // [ring slot][channel block][plane]
+  uint4 bq[RING][NC][2];  // [ring slot][channel block][plane]
   {
     // prologue: stage chunk 0 completely, start the weight ring
     W_GN_LOAD(0);
 #pragma unroll
-    for (int q = 0; q < WDIST; ++q) W_B_LOAD(bq[q], Bw0, q);
+    for (int q = 0; q < DIST; ++q) W_B_LOAD(bq[q], Bw0, q);
     wf32x4 pro[NTASK][4];  // all tasks in flight (the accumulators are not live yet)
 #pragma unroll
     for (int j = 0; j < NTASK; ++j) W_TASK_LOAD(pro[j], j, 0);
@@ -314,22 +323,23 @@ __global__ __launch_bounds__(256) void wconv_kernel(const float* __restrict__ Ag
       if constexpr (!(CGD_WCONV_EXP & 8))
         if (q + 1 < WSTEPS) W_A_LOAD(af[(q + 1) & 1], cur, q + 1);
       if constexpr (!(CGD_WCONV_EXP & 1)) {
-        const int q2 = (q + WDIST) % WSTEPS;
-        const uint4* __restrict__ base = (q + WDIST < WSTEPS) ? cb : nb;
-        W_B_LOAD(bq[(q + WDIST) % WRING], base, q2);
+        const int q2 = (q + DIST) % WSTEPS;
+        const uint4* __restrict__ base = (q + DIST < WSTEPS) ? cb : nb;
+        W_B_LOAD(bq[(q + DIST) % RING], base, q2);
       }
+      const int lt = w_load_task<NB, OCC>(q);  // (folded: q is a constant in the unrolled loop)
       if constexpr (!(CGD_WCONV_EXP & 2))
-        if (w_load_task<NB>(q) >= 0) W_TASK_LOAD(pr[w_load_task<NB>(q) & 1], (w_load_task<NB>(q) < 0 ? 0 : w_load_task<NB>(q)), cn);
-      W_MFMA12((q >> 1) & 3, af[q & 1], bq[q % WRING]);
+        if (lt >= 0) W_TASK_LOAD(pr[lt & PM], (lt < 0 ? 0 : lt), cn);
+      W_MFMA12((q >> 1) & 3, af[q & 1], bq[q % RING]);
       if constexpr (!(CGD_WCONV_EXP & 2)) {
-        const int k1 = w_proc_task<NB>(q, 0), k2 = w_proc_task<NB>(q, 1), k3 = w_proc_task<NB>(q, 2);
-        if (k1 >= 0) W_TASK_P1(nxt, pr[k1 & 1], (k1 < 0 ? 0 : k1));
-        if (k2 >= 0) W_TASK_P2(nxt, pr[k2 & 1], (k2 < 0 ? 0 : k2));
-        if (k3 >= 0) W_TASK_P3(nxt, pr[k3 & 1], (k3 < 0 ? 0 : k3));
+        const int k1 = w_proc_task<NB, OCC>(q, 0), k2 = w_proc_task<NB, OCC>(q, 1), k3 = w_proc_task<NB, OCC>(q, 2);
+        if (k1 >= 0) W_TASK_P1(nxt, pr[k1 & PM], (k1 < 0 ? 0 : k1));
+        if (k2 >= 0) W_TASK_P2(nxt, pr[k2 & PM], (k2 < 0 ? 0 : k2));
+        if (k3 >= 0) W_TASK_P3(nxt, pr[k3 & PM], (k3 < 0 ? 0 : k3));
       }
       if constexpr (!(CGD_WCONV_EXP & 16)) {
-        const bool loads = w_load_task<NB>(q) >= 0;
-        const bool puts = w_proc_task<NB>(q, 0) >= 0 || w_proc_task<NB>(q, 1) >= 0 || w_proc_task<NB>(q, 2) >= 0;
+        const bool loads = w_load_task<NB, OCC>(q) >= 0;
+        const bool puts = w_proc_task<NB, OCC>(q, 0) >= 0 || w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 2) >= 0;
         constexpr int NM = 3 * NB * NC;  // MFMAs per step: 12 (16-row tile, or 8-row tile x 2 channel blocks) or 6
 #pragma unroll
         for (int r = 0; r < NM; ++r) {
