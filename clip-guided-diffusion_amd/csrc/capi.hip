@@ -49,7 +49,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_WINO_NC")) ctx->wino_nc = atoi(e);
   ctx->wino_nc_default = ctx->wino_nc;
   if (const char* e = getenv("CGD_GN_EPI")) ctx->gn_epi = atoi(e);
-  if (const char* e = getenv("CGD_HGEMM_KG")) ctx->hgemm_kg = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
+  if (const char* e = getenv("CGD_HGEMM_KG")) ctx->hgemm_kg = atoi(e) < 0 || atoi(e) > 2 ? 1 : atoi(e);
   if (const char* e = getenv("CGD_KCONV")) sscanf(e, "%d,%d,%d", &ctx->kconv_mode, &ctx->kconv_max_m, &ctx->kconv_min_chunks);
   if (const char* e = getenv("CGD_HCONV_SPLIT")) sscanf(e, "%d,%d", &ctx->hconv_slots, &ctx->hconv_min_chunks);
   if (ctx->kconv_min_chunks < 1) ctx->kconv_min_chunks = 1;  // divisors of the split-K policy

@@ -128,9 +128,11 @@ struct cgd_ctx {
   int tile_order = 0;  // XCD tile order of hgemm2 / hconv2: 0 auto (weight-panel major when the weights are the larger operand),
                        // 1 always weight-panel (N) major, 2 always row-panel (M) major (A/B knob)
   int hgemm_epi = 1;   // hgemm2_kernel (bf16x3) epilogue: 1 = block through LDS, whole-line accesses; 0 = per-lane 16-byte accesses (CGD_HGEMM_EPI)
-  int hgemm_kg = 0;    // hgemm2_kernel on 64-row tiles (bf16x3) with two K-groups of wavefronts per workgroup (8 wavefronts, two per SIMD): 0 = where it
-                       // pays (<= one workgroup per CU, >= 8 chunks per slice: chunk loop 0.94 -> 0.75 us, qkv launch 17.9 -> 16.1 us), 1 = never,
-                       // 2 = wherever K allows (slower on the step: 312-workgroup launches lose their co-resident second workgroup; A/B knob CGD_HGEMM_KG)
+  int hgemm_kg = 1;    // hgemm2_kernel on 64-row tiles (bf16x3) with two K-groups of wavefronts per workgroup (8 wavefronts, two per SIMD): 1 = never
+                       // (default), 0 = where the micro-benchmark wins (<= one workgroup per CU, >= 8 chunks per slice: chunk loop 0.94 -> 0.75 us, qkv
+                       // launch 17.9 -> 16.1 us with warm caches), 2 = wherever K allows.  Step-level A/B (profiles/r4_hgemm_kgroups.txt): 0 is 0.055 ms
+                       // and 2 is 0.29 ms SLOWER than 1 — inside a step every launch starts on cold L2s and the longer prologue / hand-over of the
+                       // 8-wavefront workgroup costs more than its faster loop gains (A/B knob CGD_HGEMM_KG)
   int hgemm_var = 1;   // weight GEMM kernel variant (hgemm.hip cgd_hgemm_tile_m): 0 hgemm_kernel, 1 hgemm2 auto tile, 2 / 3 hgemm2 128 / 64 rows
   int hgemm_mode = 1, hgemm_min_m = 64, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
                                                                 // igemm's finer tiles win), chunks per split-K slice

@@ -717,6 +717,11 @@ int cgd_unet_manifest(const cgd_unet_config* cfg, void (*cb)(const char*, int64_
 }
 void cgd_unet_destroy(cgd_unet* u) {
   if (u) cgd_frag_cache_clear(u->net.ctx);  // packed copies are keyed by weight pointers that die with the net
+  if (u) {  // ... and the conv-epilogue record buffers by activation pointers that do
+    DeviceScope dev_scope(u->net.ctx);
+    (void)hipDeviceSynchronize();
+    cgd_chanstats_clear(u->net.ctx);
+  }
   delete u;
 }
 int cgd_unet_num_params(cgd_unet* u) {

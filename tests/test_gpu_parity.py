@@ -101,6 +101,15 @@ def test_attention(precision):
     _assert_all(pc.check_attn(precision))
 
 
+def test_gemm_and_vit_with_two_k_groups_of_wavefronts(monkeypatch):
+    """hgemm2_kernel<1,64,8,2,2> (round 4: 8 wavefronts = two K-groups over a 128-deep chunk, partial blocks merged through LDS) is not the
+    default (step-level A/B: slower), so it is exercised here explicitly: CGD_HGEMM_KG=2 routes every eligible weight GEMM through it — the
+    GEMM cases (ragged M, partial N tiles, split-K) and a CLIP ViT-B/32 tower forward + dgrad."""
+    monkeypatch.setenv("CGD_HGEMM_KG", "2")
+    _assert_all(pc.check_gemm(1))
+    _assert_all(pc.check_vit("ViT-B/32", 1))
+
+
 def test_cutouts_and_spherical_loss():
     _assert_all(pc.check_cutouts_loss())
 
