@@ -120,6 +120,12 @@ def test_unet_small(case, precision, B, hw):
     _assert_all(pc.check_unet(case, precision, B=B, hw=hw))
 
 
+def test_unet_batch2_on_the_winograd_kernel_with_epilogue_records():
+    """Round 4: batch 2 at 128x128 puts the first level's convs (2 x 16384 pixels) on wconv_kernel, whose epilogues take the GroupNorm forward
+    statistics and backward sums per (sample, half tile, channel): the per-sample indexing of the records and of the folded coefficients."""
+    _assert_all(pc.check_unet("mini", 1, B=2, hw=(128, 128)))
+
+
 def test_unet_64_checkpoint_shape():
     _assert_all(pc.check_unet("cfg64", 1))
 
