@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 10: de-phasing the four wavefronts of wconv_kernel after every barrier (s_sleep w * n * 64 cycles)
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/benchmarks/ubench"
 O=../../gpurun_out/r4b10
 mkdir -p $O

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 11: wconv epilogue with its second operand (residual / norm input) fetched one row group ahead: parity of the touched paths, A/B GN_EPI 1 vs 3
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out/r4b11
 mkdir -p $O

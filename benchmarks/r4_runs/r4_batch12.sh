@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 12: hconv2 split-K target (two resident workgroups per CU on the 64x64 level), the two wconv launch classes in the bench line
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out/r4b12
 mkdir -p $O

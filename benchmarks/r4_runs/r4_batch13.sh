@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 13: hconv2 on the 64x64 level with a split-K target of two resident workgroups per CU (CGD_HCONV_SMALL = max pixels, slots, min chunks)
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out/r4b13
 mkdir -p $O

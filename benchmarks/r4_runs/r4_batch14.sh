@@ -2,7 +2,7 @@
 # r4 GPU call 14: wconv_kernel<GN,2,1,2> — 8-row tile with TWO workgroups per CU (two wavefronts per SIMD), against the 16-row tile (4) and the
 # 8-row x 256-channel tile (22)
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/benchmarks/ubench"
 O=../../gpurun_out/r4b14
 mkdir -p $O

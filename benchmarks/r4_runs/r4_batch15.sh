@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 15: step-level A/B of the automatic two-K-group hgemm2 selection (CGD_HGEMM_KG=0 auto vs 1 never)
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out/r4b15
 mkdir -p $O

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 2: the new parity tests + the bench on the fan-in synthetic weights (finite trajectory check) with the launch counters
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 mkdir -p gpurun_out/r4b2
 python -m pytest tests -m gpu -x -q -k "config1_full or full_scale_head or rccl or cutouts" -s > gpurun_out/r4b2/pytest_new.log 2>&1

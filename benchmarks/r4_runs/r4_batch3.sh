@@ -2,7 +2,7 @@
 # r4 GPU call 3: hgemm2 with two K-groups of wavefronts (KG = 2): micro-benchmark against the 4-wavefront kernel with float64 checks,
 # the GEMM / ViT / UNet parity tests on the new default, step-level A/B
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 mkdir -p gpurun_out/r4b3
 (

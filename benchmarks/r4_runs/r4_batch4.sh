@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 4: last-arriver probe (sc1 relaxed atomics vs fences vs two launches) and the 128-row hgemm2 tile on the ViT shapes with more split-K
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/benchmarks/ubench"
 mkdir -p ../../gpurun_out/r4b4
 (

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 5: GroupNorm forward statistics from the wconv epilogue: UNet / headline parity, step-level A/B (CGD_GN_EPI=0 / 1)
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 mkdir -p gpurun_out/r4b5
 python -m pytest tests -m gpu -x -q -k "test_unet or headline_shape_single or groupnorm or winograd" > gpurun_out/r4b5/pytest.log 2>&1

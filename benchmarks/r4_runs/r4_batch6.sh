@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 6: A/B of the conv-epilogue GroupNorm statistics with the batched merge kernel + a kernel trace of the step
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out/r4b6
 mkdir -p $O

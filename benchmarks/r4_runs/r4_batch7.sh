@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 7: GroupNorm BACKWARD sums from the dgrad conv's epilogue (CGD_GN_EPI bit 1): UNet / headline parity, step-level A/B 1 vs 3
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out/r4b7
 mkdir -p $O

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 8: wconv_kernel with two channel blocks per wavefront (8 x 16 pixels x 256 channels): parity, step-level A/B
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT"
 O=gpurun_out/r4b8
 mkdir -p $O

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # r4 GPU call 9: wconv_kernel chunk-loop ablation (which element of the loop costs what), 16-row tile and the 8-row x 256-channel tile, plain and fused GN
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/benchmarks/ubench"
 O=../../gpurun_out/r4b9
 mkdir -p $O

@@ -7,7 +7,7 @@
 # activation staging sets 2 / 3 / 4) on the ViT GEMM shapes; every configuration must print the same checksum per shape and "ok" against float64 on
 # the small shapes.  ~25 s of box time.  Then: make the best configuration the default of the library instantiation, same-box A/B of the step, full suite.
 set -uo pipefail
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd "$ROOT/benchmarks/ubench"
 [ -x hgemm_stamps ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include hgemm_stamps.hip -o hgemm_stamps
 for cfg in 0 1 2 3 4 5 6 7 8; do
