@@ -123,6 +123,32 @@ __device__ __forceinline__ void am_mma_nt64(am_f32x16& acc, const float* As, con
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
   }
 }
+// The A operand of an nt64 product that a workgroup multiplies against EVERY key block (Q in the forward kernel's two passes, dO in the dQ
+// kernel) is split once into registers (32 VGPRs) instead of being re-read from LDS and re-split per key block (round 4: half of the split
+// arithmetic of those products, 33 VALU per MFMA overall before; same values, same operation order: bit-identical).
+struct AmPre {
+  am_bf16x8 h[4], l[4];
+};
+__device__ __forceinline__ void am_presplit64(AmPre& p, const float* As, int hh) {
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+    const am_f32x4 a0 = *(const am_f32x4*)(As + 16 * s2 + 4 * hh), a1 = *(const am_f32x4*)(As + 16 * s2 + 8 + 4 * hh);
+    const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    am_split8(av, p.h[s2], p.l[s2]);
+  }
+}
+__device__ __forceinline__ void am_mma_nt64_pre(am_f32x16& acc, const AmPre& a, const float* Bs, int hh) {
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+    const am_f32x4 b0 = *(const am_f32x4*)(Bs + 16 * s2 + 4 * hh), b1 = *(const am_f32x4*)(Bs + 16 * s2 + 8 + 4 * hh);
+    const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    am_bf16x8 bh, bl;
+    am_split8(bv, bh, bl);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s2], bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s2], bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s2], bh, acc, 0, 0, 0);
+  }
+}
 // acc += sum_{k<8*NM} A[row][k] * B[k][col]   (A k-contiguous: As = row base; B lane-contiguous: Bs = &B[0][col])
 template <int NM, bool X3>
 __device__ __forceinline__ void am_mma_nn(am_f32x16& acc, const float* As, const float* Bs, int pitchB, int hh) {
@@ -221,6 +247,7 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
   const int nkb = (T + 127) >> 7;  // key blocks; keys >= T are masked (score -inf, probability 0), query rows >= T not stored
   const int srow = tid >> 3, seg = tid & 7;
   float m_run = -INFINITY, l_run = 0.f;
+  AmPre qpre;  // X3: this lane's Q fragments, split once (am_presplit64)
   am_f32x4 kr[8], vr[8];
   am_gload<128>(kr, base + ko, ldq, tid, T);
   for (int j = 0; j < nkb; ++j) {
@@ -234,7 +261,12 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
     am_f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-    am_mma_nt64<X3>(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
+    if constexpr (X3) {
+      if (j == 0) am_presplit64(qpre, &Qs[l31 * AM_P68], hh);  // (Qs is complete: two barriers since it was staged)
+      am_mma_nt64_pre(sacc, qpre, &Ks[(32 * w + l31) * AM_P68], hh);
+    } else {
+      am_mma_nt64<X3>(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       Ss[((r & 3) + 8 * (r >> 2) + 4 * hh) * AM_PS + 32 * w + l31] = (j * 128 + 32 * w + l31 < T) ? sacc[r] * alpha : -INFINITY;
@@ -288,7 +320,10 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(const float* __restri
     am_f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-    am_mma_nt64<X3>(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
+    if constexpr (X3)
+      am_mma_nt64_pre(sacc, qpre, &Ks[(32 * w + l31) * AM_P68], hh);
+    else
+      am_mma_nt64<X3>(sacc, &Qs[l31 * AM_P68], &Ks[(32 * w + l31) * AM_P68], hh);
     const int key = j * 128 + 32 * w + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -355,6 +390,7 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
   am_f32x16 qacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) qacc[e] = 0.f;
+  AmPre gpre;  // X3: this lane's dO fragments, split once
   const long pbase = (((long)n * H + h) * T + (long)qb * 32) * Tp + 32 * w + l31;
   am_f32x4 kr[8], vr[8];
   am_gload<128>(vr, base + vo, ldq, tid, T);
@@ -380,7 +416,12 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_dq_kernel(const float* __res
     am_f32x16 dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dp[e] = 0.f;
-    am_mma_nt64<X3>(dp, &dOs[l31 * AM_P68], &Vs[(32 * w + l31) * AM_P68], hh);
+    if constexpr (X3) {
+      if (j == 0) am_presplit64(gpre, &dOs[l31 * AM_P68], hh);
+      am_mma_nt64_pre(dp, gpre, &Vs[(32 * w + l31) * AM_P68], hh);
+    } else {
+      am_mma_nt64<X3>(dp, &dOs[l31 * AM_P68], &Vs[(32 * w + l31) * AM_P68], hh);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
