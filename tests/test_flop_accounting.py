@@ -104,6 +104,16 @@ def test_launch_plan_agrees_with_the_committed_bench_line():
     assert roof["launches_per_step"] == pytest.approx(136.0)  # round 1: 136 launches (16x16 .. 256x256), all on hconv2_kernel
     r1 = sum(r[10] for r in wconv + hconv + kconv if r[3] >= 256)
     assert roof["flop_per_launch"] * roof["launches_per_step"] == pytest.approx(r1 * 1e9, rel=1e-3)
+    # round 4 line: the same 52 wconv launches (now counted apart: plain / with the GroupNorm-backward epilogue), library launch counters
+    with open(os.path.join(ROOT, "profiles", "r4_bench_1gpu.json")) as f:
+        r4 = json.loads(f.read().strip().splitlines()[-1])
+    assert r4["roofline"]["launches_per_step"] == pytest.approx(len(wconv))
+    cls = r4["roofline"]["launch_classes"]
+    assert cls["plain"]["launches_per_step"] + cls["with_groupnorm_backward_epilogue"]["launches_per_step"] == pytest.approx(len(wconv))
+    # dgrad convs of plain ResBlocks (both convs) and of the resampling blocks (conv2 only) on wconv: 26 dgrad launches, 3 of them conv1 of up / down blocks
+    assert cls["with_groupnorm_backward_epilogue"]["launches_per_step"] == pytest.approx(23.0)
+    assert r4["config"]["launches_per_step"] < 1065 and r4["config"]["splitk_reduce_per_step"] == pytest.approx(181.0)
+    assert r4["roofline"]["traffic_source"].startswith("profiles/pmc_traffic.json")
     # every ViT linear (16 cutouts = 800 token rows) goes to the weight GEMM kernel; the 8x8-pixel convs and M = 1 embeddings do not
     vit = [r for r in rows if r[0] == "vit" and r[1] == "linear" and r[3] == 800]
     assert len(vit) == 96 and all(r[6] == "hgemm" for r in vit)
