@@ -691,6 +691,10 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
+  if (attn_mid_ok(sh, ldq, ldo) && x3 && ctx->attn_flash) {
+    // round 5: no materialised P; row statistics (LSE) kept in bufs.P for the recomputing backward kernels (attn_flash.hip)
+    return cgd_attn_flash_fwd(ctx, sh, qkv, ldq, out, ldo, bufs, ho.q, ho.k, ho.v, ho.step, s);
+  }
   if (attn_mid_ok(sh, ldq, ldo)) {
     if (x3) {
       CGD_LAUNCH((attn_mid_fwd_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
@@ -749,6 +753,9 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
     }
     CGD_HIP(ctx, hipGetLastError());
     return 0;
+  }
+  if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3) && x3 && ctx->attn_flash) {
+    return cgd_attn_flash_bwd(ctx, sh, qkv, ldq, dout, lddo, dqkv, lddq, bufs, ho.q, ho.k, ho.v, ho.step, s);
   }
   if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3)) {
     if (x3) {

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-resul
 mkdir -p build
 objs=()
 pids=()
-for src in gemm hconv kconv wconv hgemm conv_thin norm elem attn guidance unet vit resnet lpips capi; do
+for src in gemm hconv kconv wconv hgemm conv_thin norm elem attn attn_flash guidance unet vit resnet lpips capi; do
   obj=build/$src.o
   objs+=("$obj")
   if [[ ! -f $obj || $src.hip -nt $obj || common.h -nt $obj || kernels.h -nt $obj || net.h -nt $obj || guidance.h -nt $obj \

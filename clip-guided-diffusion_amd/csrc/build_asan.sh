@@ -12,7 +12,7 @@ mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -Wno-option-ignored -fsanitize=address,undefined -fno-sanitize=vptr -fno-omit-frame-pointer"
 objs=()
 pids=()
-for src in gemm hconv kconv wconv hgemm conv_thin norm elem attn guidance unet vit resnet lpips capi; do
+for src in gemm hconv kconv wconv hgemm conv_thin norm elem attn attn_flash guidance unet vit resnet lpips capi; do
   obj=$OUT/$src.o
   objs+=("$obj")
   if [[ ! -f $obj || $src.hip -nt $obj || common.h -nt $obj || kernels.h -nt $obj || net.h -nt $obj || guidance.h -nt $obj \

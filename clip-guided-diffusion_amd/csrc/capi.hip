@@ -43,6 +43,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_FUSE_ACT")) ctx->fuse_act = atoi(e);
   if (const char* e = getenv("CGD_HCONV_W8")) ctx->hconv_w8 = atoi(e);
   if (const char* e = getenv("CGD_ATTN_X3")) ctx->attn_x3 = atoi(e);
+  if (const char* e = getenv("CGD_ATTN_FLASH")) ctx->attn_flash = atoi(e);
   if (const char* e = getenv("CGD_WINO")) sscanf(e, "%d,%d", &ctx->wino_mode, &ctx->wino_min_m);
   if (const char* e = getenv("CGD_THIN")) ctx->thin_direct = atoi(e);
   if (const char* e = getenv("CGD_GEMV")) ctx->gemv_mode = atoi(e);

@@ -86,6 +86,13 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
 int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, const float* dout, int lddo, float* dqkv, int lddq,
                  const AttnBufs& bufs, hipStream_t s);
 
+// attn_flash.hip (round 5): d = 64, T > 64 in bf16x3 contexts; P is never materialised, bufs.P holds the row statistics (LSE | D),
+// bufs.qkvT a copy of O for the backward's D = rowsum(dO * O).  qo / ko / vo / step: column offsets of head 0 and the per-head step
+int cgd_attn_flash_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, float* out, int ldo, const AttnBufs& bufs, long qo,
+                       long ko, long vo, long step, hipStream_t s);
+int cgd_attn_flash_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, const float* dout, int lddo, float* dqkv, int lddq,
+                       const AttnBufs& bufs, long qo, long ko, long vo, long step, hipStream_t s);
+
 // ---- guidance.hip -----------------------------------------------------------------------------------------
 struct CutoutGeom {
   int oy, ox, h, w;  // crop origin and (possibly truncated) extent

@@ -98,7 +98,15 @@ def test_attention_exact_kernels_in_bf16x3_context(monkeypatch):
 
 @pytest.mark.parametrize("precision", [0, 1])
 def test_attention(precision):
+    """precision 1 (bf16x3): T > 64 at d = 64 runs on the round-5 kernels of attn_flash.hip (online softmax, no materialised P / dS, backward
+    recomputes P from the saved row statistics) — T = 100 / 192 / 197 / 256 / 257 / 1024 incl. ragged last blocks, both head layouts."""
     _assert_all(pc.check_attn(precision))
+
+
+def test_attention_materialised_kernels_in_bf16x3_context(monkeypatch):
+    """CGD_ATTN_FLASH=0 keeps attn_mid_*<true> (P / dS written to global memory, rounds 2-4) selectable: grade that path too."""
+    monkeypatch.setenv("CGD_ATTN_FLASH", "0")
+    _assert_all(pc.check_attn(1))
 
 
 def test_gemm_and_vit_with_two_k_groups_of_wavefronts(monkeypatch):
