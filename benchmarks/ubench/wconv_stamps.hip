@@ -64,6 +64,10 @@ int main(int argc, char** argv) {
   const float ws = 1.f / sqrtf(9.f * Cin);
   for (auto& v : hW) v = nd(rng) * ws;
   for (auto& v : hb) v = nd(rng);
+  if (getenv("CGD_UBENCH_ZERO")) {  // the DVFS check of MI355X_MICROARCH.md (zero-filled operands toggle no MFMA datapath bits): power probe only
+    std::fill(hA.begin(), hA.end(), 0.f);
+    std::fill(hW.begin(), hW.end(), 0.f);
+  }
   for (int c = 0; c < Cin; ++c) {
     hab[2 * c] = 0.5f + 0.5f * fabsf(nd(rng));
     hab[2 * c + 1] = 0.5f * nd(rng);
