@@ -262,10 +262,11 @@ def main():
     # flow (weight broadcast, barriers, all_gather, all_reduce MAX) — RCCL on a 1-GPU box (tests/test_gpu_step.py)
     dist_on = world > 1 or os.environ.get("CGD_FORCE_COLLECTIVES") == "1"
     if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(free_port()))
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
+        if world == 1:  # the forced one-rank group only: a multi-rank launch that forgot MASTER_PORT / RANK must fail fast in
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")  # init_process_group, not form N one-rank groups
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl":
             dist.init_process_group("nccl", device_id=th.device(dev))  # "nccl" is RCCL on ROCm
         else:

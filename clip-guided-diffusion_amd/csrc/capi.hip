@@ -44,11 +44,13 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_HCONV_W8")) ctx->hconv_w8 = atoi(e);
   if (const char* e = getenv("CGD_ATTN_X3")) ctx->attn_x3 = atoi(e);
   if (const char* e = getenv("CGD_ATTN_FLASH")) ctx->attn_flash = atoi(e);
-  if (const char* e = getenv("CGD_WINO")) sscanf(e, "%d,%d", &ctx->wino_mode, &ctx->wino_min_m);
+  int wino_env_mode = -1;
+  if (const char* e = getenv("CGD_WINO")) sscanf(e, "%d,%d", &wino_env_mode, &ctx->wino_min_m);
   if (const char* e = getenv("CGD_THIN")) ctx->thin_direct = atoi(e);
   if (const char* e = getenv("CGD_GEMV")) ctx->gemv_mode = atoi(e);
   if (const char* e = getenv("CGD_WINO_NC")) ctx->wino_nc = atoi(e);
   ctx->wino_nc_default = ctx->wino_nc;
+  if (wino_env_mode >= 0) cgd_apply_wino_mode(ctx, wino_env_mode);  // same meaning as cgd_set_wino(mode) (mode 5)
   if (const char* e = getenv("CGD_GN_EPI")) ctx->gn_epi = atoi(e);
   if (const char* e = getenv("CGD_HGEMM_KG")) ctx->hgemm_kg = atoi(e) < 0 || atoi(e) > 2 ? 1 : atoi(e);
   if (const char* e = getenv("CGD_KCONV")) sscanf(e, "%d,%d,%d", &ctx->kconv_mode, &ctx->kconv_max_m, &ctx->kconv_min_chunks);
@@ -275,12 +277,34 @@ int cgd_op_conv3x3_wino(cgd_ctx* ctx, const float* x, int ldx, const float* w_wi
   p.M = Bn * H * W; p.N = Cout; p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.ups = ups; p.force_tile = 515;
   return cgd_launch_gemm(ctx, p, S(stream));
 }
+int cgd_op_conv3x3_wino_ex(cgd_ctx* ctx, const float* x, int ldx, const float* w_wino, float* y, int ldy, const float* bias, const float* R,
+                           int ldr, const float* gn_ab, int Bn, int H, int W, int Cin, int Cout, int ups, int stats, const float* gnb_x,
+                           int gnb_ldx, const float* gnb_scratch, void* stream) {
+  CGD_NEED_CTX(ctx);
+  GemmParams p;
+  p.Bwk = w_wino;
+  p.A = x; p.lda = ldx; p.B = x /* unused */; p.ldb = 9 * Cin; p.C = y; p.ldc = ldy;
+  p.bias = bias; p.R = R; p.ldr = ldr; p.gn_ab = gn_ab;
+  p.M = Bn * H * W; p.N = Cout; p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.ups = ups; p.force_tile = 515;
+  p.stats = stats;
+  if (gnb_x && gnb_scratch) {
+    p.gnb_x = gnb_x; p.gnb_ldx = gnb_ldx; p.gnb_coef = cgd_gn_coef(gnb_scratch, Bn, H * W, Cout); p.gnb_act = 1;
+  }
+  return cgd_launch_gemm(ctx, p, S(stream));
+}
+int cgd_op_new_pass(cgd_ctx* ctx) {
+  CGD_NEED_CTX(ctx);
+  ++ctx->stats_serial;
+  return 0;
+}
+int64_t cgd_op_gn_stats_offset(int B, int HW, int C) { return (int64_t)cgd_gn_stats_offset(B, HW, C); }
+int64_t cgd_op_gn_record_merges(cgd_ctx* ctx) { return ctx ? (int64_t)ctx->gn_record_merges : -3; }
 int cgd_set_wino(cgd_ctx* ctx, int mode, int min_m) {
   CGD_NEED_CTX(ctx);
   // mode 5 (tests / micro-benchmarks): 8-row tiles with two 32-channel blocks per wavefront (8 x 16 pixels x 256 channels) wherever N is a multiple
   // of 256, plain 8-row tiles elsewhere; the other modes leave the channel-block choice automatic
-  ctx->wino_mode = mode == 5 ? 3 : mode;
-  ctx->wino_nc = mode == 5 ? 3 : ctx->wino_nc_default;
+  if (mode < 0 || (mode > 3 && mode != 5)) CGD_FAIL(ctx, "cgd_set_wino: mode must be 0, 1, 2, 3 or 5");
+  cgd_apply_wino_mode(ctx, mode);
   if (min_m > 0) ctx->wino_min_m = min_m;
   return 0;
 }
@@ -367,4 +391,10 @@ int cgd_op_attn_bwd(cgd_ctx* ctx, const float* qkv, const float* dout, float* dq
   AttnBufs bf{bufs[0], bufs[1], bufs[2], bufs[3], bufs[4]};
   return cgd_attn_bwd(ctx, sh, qkv, 3 * heads * d, dout, heads * d, dqkv, 3 * heads * d, bf, S(stream));
 }
+}
+
+void cgd_apply_wino_mode(cgd_ctx* ctx, int mode) {
+  if (mode < 0 || (mode > 3 && mode != 5)) mode = 1;  // unknown values from the environment: the default
+  ctx->wino_mode = mode == 5 ? 3 : mode;
+  ctx->wino_nc = mode == 5 ? 3 : ctx->wino_nc_default;
 }

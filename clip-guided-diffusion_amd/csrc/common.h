@@ -142,7 +142,11 @@ struct cgd_ctx {
   int defer_mode = 1;  // deferred split-K reductions: 0 never, 1 when the consumer is a many-workgroup kernel (GroupNorm on > 32x32
                        // maps), 2 also for the single-launch small-map GroupNorm (32 workgroups: slower, kept for A/B runs)
   std::vector<ChanStatsEntry> chanstats;  // see ChanStatsEntry
-  unsigned long long stats_serial = 1;    // current network pass (cgd_unet_forward increments it)
+  std::vector<float*> chanstats_retired;  // record buffers that were outgrown: kept until cgd_chanstats_clear (a kernel in flight may still read them;
+                                          // no synchronisation and no hipFree inside a network pass)
+  unsigned long long stats_serial = 1;    // current network pass (cgd_unet_forward and cgd_unet_dgrad increment it)
+  unsigned long long gn_record_merges = 0;  // GroupNorm launches that merged epilogue records instead of sweeping (cgd_op_gn_record_merges: tests)
+  bool last_wconv_bstat = false;          // did the last cgd_launch_wconv take a GroupNorm's backward sums in its epilogue? (profiling: kind 5)
   int gn_epi = 3;      // bit 0: GroupNorm forward statistics of conv-produced tensors come from the conv epilogue; bit 1: the backward sums of a
                        // GroupNorm whose upstream gradient a dgrad conv produces come from that conv's epilogue (A/B knob CGD_GN_EPI)
   std::vector<FragEntry> frag_cache;                           // packed weights, keyed by pointer; cleared by finalize / set_param / destroy
@@ -265,6 +269,13 @@ struct GemmParams {
 float* cgd_chanstats_register(cgd_ctx* ctx, const float* C, int ldc, int N, long M, hipStream_t s, int kind = 0);
 bool cgd_chanstats_find(cgd_ctx* ctx, const float* x, int ldx, long M, int Cn, hipStream_t s, ChanSrc* out, int kind = 0);
 void cgd_chanstats_clear(cgd_ctx* ctx);
+// a kernel that takes NO records is about to (re)write tensor C: records registered for it in this pass die (a later GroupNorm must
+// never merge sums of a previous content); called by every launcher that writes an activation
+void cgd_chanstats_invalidate(cgd_ctx* ctx, const float* C);
+// would the GroupNorm launchers merge epilogue records for a tensor of HW pixels per sample? (the producer registers records only then)
+bool cgd_gn_merges_records(int HW);
+// the one place that maps a CGD_WINO / cgd_set_wino mode to (wino_mode, wino_nc): mode 5 = 8-row tiles with two channel blocks per wavefront
+void cgd_apply_wino_mode(cgd_ctx* ctx, int mode);
 
 // deferred split-K reductions: run the reduce kernel for a pending one (no-op otherwise) / hand it to a consumer of tensor `x`
 int cgd_flush_pending(cgd_ctx* ctx, hipStream_t s);

@@ -654,6 +654,7 @@ bool cgd_take_pending(cgd_ctx* ctx, const float* x, long rows, int cols, int ldx
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return 0;
   CGD_TRY(cgd_flush_pending(ctx, s));  // a deferred reduction nobody consumed: its slices are about to be overwritten
+  cgd_chanstats_invalidate(ctx, p.C);  // epilogue records of an earlier content of C die here; wconv_kernel re-registers the ones it takes
   int tile = 0, kernel = 0;
   CGD_TRY(cgd_plan_gemm(ctx, p, &tile, &kernel));
   const bool use_h = kernel == 1, use_g = kernel == 2;
@@ -677,13 +678,19 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
 #undef GV_LAUNCH
   } else if (use_h) {
     if (tile == 515) {
-      ProfRec pr2;  // second record of the same launch for the launches that carry the GroupNorm-backward epilogue (kind 5)
-      const bool gnb = ctx->prof_on && p.gnb_x && p.gnb_coef && (ctx->gn_epi & 2) && !p.stats && !p.R;
-      if (gnb) CGD_TRY(cgd_prof_begin(ctx, &pr2, CGD_PROF_WCONV_GNB, 2.0 * p.M * p.N * p.K * p.nbatch, s));
+      ProfRec pr2;  // second record of the same launch for the launches that carry the GroupNorm-backward epilogue (kind 5): begun for every
+                    // candidate, filed only if the launcher really set the epilogue up (ctx->last_wconv_bstat)
+      const bool cand = ctx->prof_on && p.gnb_x && p.gnb_coef;
+      if (cand) CGD_TRY(cgd_prof_begin(ctx, &pr2, CGD_PROF_WCONV_GNB, 2.0 * p.M * p.N * p.K * p.nbatch, s));
       CGD_TRY(cgd_launch_wconv(ctx, p, s));
-      if (gnb) {
+      if (cand) {
         CGD_TRY(cgd_prof_stamp(ctx, &pr2, s));
-        cgd_prof_push(ctx, &pr2);
+        if (ctx->last_wconv_bstat) {
+          cgd_prof_push(ctx, &pr2);
+        } else if (pr2.live) {  // not an epilogue-carrying launch: recycle the events, file nothing
+          ctx->prof_pool.push_back(pr2.a);
+          ctx->prof_pool.push_back(pr2.b);
+        }
       }
     }
     else if (tile == 516)

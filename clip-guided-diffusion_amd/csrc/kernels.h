@@ -16,6 +16,7 @@ const float* cgd_gn_ab(const float* scratch, int B, int HW, int C);
 // the full folded coefficients {a, b, gcoef = gamma (1 + scale), mean} per (sample, channel) of a finished forward pass: what a dgrad conv's
 // epilogue needs to take the norm's backward sums itself (GemmParams::gnb_coef)
 const float* cgd_gn_coef(const float* scratch, int B, int HW, int C);
+size_t cgd_gn_stats_offset(int B, int HW, int C);  // float offset of the {mean, rstd} pairs [B][32][2] inside the scratch
 // dx = dGN/dx (dz) (+ add) (+ add2);  needs the forward's scratch.  add / add2: residual-path and skip-connection gradients
 // that meet at this tensor (both optional, own row strides).
 int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, int lddz, float* dx, int lddx, const float* add,

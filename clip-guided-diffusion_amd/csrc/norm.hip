@@ -41,12 +41,26 @@ __device__ __forceinline__ float dsilu_f(float u) {
 }
 
 // ---- tensors that still lie in split-K slices (common.h SplitSrc): summed in the same order as splitk_reduce_kernel ----------
+// (round 5) The slice loads are issued eight at a time with clamped indices, like splitk_reduce_kernel's: a `for k < n` loop of load + add is a
+// dependent chain of n round trips to memory the other XCDs wrote (~1.7 us each when cold), which is what made consumer-side summation on the
+// small maps (CGD_DEFER=2) no faster than a separate reduce launch in round 3.  Same summation order as before (and as the reduce kernel).
+template <int U = 8>
 __device__ __forceinline__ float4 split_load4(const SplitSrc& s, long row, int col) {
   const float* p = s.ws + row * s.N + col;
-  float4 a = *(const float4*)p;
-  for (int k = 1; k < s.n; ++k) {
-    const float4 v = *(const float4*)(p + (long)k * s.stride);
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k0 = 0; k0 < s.n; k0 += U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u < s.n ? k0 + u : s.n - 1;  // clamped: the loads stay unconditional, the sum is not
+      v[u] = *(const float4*)(p + (long)k * s.stride);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k0 + u < s.n) {
+        a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+      }
+    }
   }
   a.x *= s.alpha; a.y *= s.alpha; a.z *= s.alpha; a.w *= s.alpha;
   if (s.bias) {
@@ -61,8 +75,15 @@ __device__ __forceinline__ float4 split_load4(const SplitSrc& s, long row, int c
 }
 __device__ __forceinline__ float split_load1(const SplitSrc& s, long row, int col) {
   const float* p = s.ws + row * s.N + col;
-  float a = *p;
-  for (int k = 1; k < s.n; ++k) a += p[(long)k * s.stride];
+  float a = 0.f;
+  for (int k0 = 0; k0 < s.n; k0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long)(k0 + u < s.n ? k0 + u : s.n - 1) * s.stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < s.n) a += v[u];
+  }
   a *= s.alpha;
   if (s.bias) a += s.bias[col];
   if (s.R) a += s.R[row * s.ldr + col];
@@ -746,7 +767,7 @@ __device__ __forceinline__ typename VecT<VEC>::T split_load(const SplitSrc& s, l
   if constexpr (VEC == 1) {
     return split_load1(s, row, col);
   } else {
-    const float4 a = split_load4(s, row, col);
+    const float4 a = split_load4<4>(s, row, col);  // (1024-thread kernels: 128 registers per lane; several of these are in flight per thread)
     return typename VecT<4>::T{a.x, a.y, a.z, a.w};
   }
 }
@@ -1127,6 +1148,11 @@ const float* cgd_gn_ab(const float* scratch, int B, int HW, int C) {
   return scratch + (size_t)B * nchunk * 64 + (size_t)B * 64 + (size_t)B * C * 4 * 2;
 }
 
+size_t cgd_gn_stats_offset(int B, int HW, int C) {  // {mean, rstd} per (sample, group), [B][32][2]
+  (void)C;
+  return (size_t)B * cdiv(HW, pick_chunk(HW, B)) * 64;
+}
+
 const float* cgd_gn_coef(const float* scratch, int B, int HW, int C) {
   const int nchunk = cdiv(HW, pick_chunk(HW, B));
   return scratch + (size_t)B * nchunk * 64 + (size_t)B * 64;
@@ -1167,6 +1193,7 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
                // figure is the operation's, also when the producer's epilogue has already taken the statistics and the read never happens)
   CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (y ? 8.0 : 4.0) * B * HW * C, s));
   if (epi) {
+    ++ctx->gn_record_merges;
     int lg = 0;
     while ((1 << lg) < C / 32) ++lg;
     CGD_LAUNCH(gn_stats_final_ch_kernel, dim3(32, B), dim3(256), 0, s, cs, HW / 128, C / 32, lg, eps, stats, gamma, beta, film, ldfilm, coef);
@@ -1233,6 +1260,7 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
   // the dgrad conv that produced dz may already have taken this norm's backward sums in its epilogue (ChanStatsEntry kind 1): merge its records
   ChanSrc cs;
   if (!src.n && !(HW & 127) && (ctx->gn_epi & 2) && cgd_chanstats_find(ctx, dz, lddz, (long)B * HW, C, s, &cs, 1) && cs.n0 == C) {
+    ++ctx->gn_record_merges;
     int lg = 0;
     while ((1 << lg) < C / 32) ++lg;
     CGD_LAUNCH(gn_bwd_coef_ch_kernel, dim3(32, B), dim3(256), 0, s, cs.p0, HW / 128, lg, stats, coef, C, HW, bcoef);
@@ -1325,8 +1353,9 @@ float* cgd_chanstats_register(cgd_ctx* ctx, const float* C, int ldc, int N, long
     e->kind = kind;
   }
   if (e->cap < need) {
-    // grow-only, at most once per tensor shape: the old block may still be read by a kernel in flight on another stream
-    if (e->buf) (void)hipDeviceSynchronize(), (void)hipFree(e->buf);
+    // grow-only, at most once per tensor shape (the first pass at that shape, like every activation buffer of the networks): the old block may
+    // still be read by a kernel in flight, so it is retired, not freed — no synchronisation and no hipFree inside a network pass
+    if (e->buf) ctx->chanstats_retired.push_back(e->buf);
     e->buf = nullptr;
     e->cap = 0;
     void* p = nullptr;
@@ -1361,5 +1390,14 @@ bool cgd_chanstats_find(cgd_ctx* ctx, const float* x, int ldx, long M, int Cn, h
 void cgd_chanstats_clear(cgd_ctx* ctx) {
   for (ChanStatsEntry& q : ctx->chanstats)
     if (q.buf) (void)hipFree(q.buf);
+  for (float* p : ctx->chanstats_retired) (void)hipFree(p);
   ctx->chanstats.clear();
+  ctx->chanstats_retired.clear();
 }
+
+void cgd_chanstats_invalidate(cgd_ctx* ctx, const float* C) {
+  for (ChanStatsEntry& q : ctx->chanstats)
+    if (q.C == C) q.serial = 0;  // serial 0 never matches a pass (stats_serial starts at 1 and only grows)
+}
+
+bool cgd_gn_merges_records(int HW) { return HW > GN_SMALL_HW && !(HW & 127); }

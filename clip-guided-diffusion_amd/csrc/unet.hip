@@ -651,6 +651,7 @@ int UNet::forward(const float* x, const float* t, const int64_t* y, float* out, 
 
 int UNet::dgrad(const float* gout, float* gx, hipStream_t s) {
   if (!have_fwd) CGD_FAIL(ctx, "unet: dgrad() needs a preceding forward()");
+  ++ctx->stats_serial;  // backward-sum records of an earlier dgrad() (and the forward's statistics, which only the forward reads) are dead from here on
   // head
   CGD_TRY(ensure(dheadn, (size_t)B * H * W * ch0));
   CGD_TRY(ensure(dhead, (size_t)B * H * W * ch0));

@@ -632,10 +632,14 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.alpha = g.alpha;
   p.nmajor = (ctx->tile_order == 1 || (ctx->tile_order == 0 && 12L * g.N >= g.M)) ? 1 : 0;
   // statistics for the GroupNorm that reads the output next (the tensor's rows are whole 8 x 16-pixel half tiles here: H % 8 == 0, W % 16 == 0)
-  p.stat = (g.stats && (ctx->gn_epi & 1)) ? cgd_chanstats_register(ctx, g.C, g.ldc, g.N, g.M, s) : nullptr;
+  // ... and only when that GroupNorm will merge records at all (cgd_gn_merges_records: > 32 x 32 pixels per sample; ADVICE r4: at batch >= 16 a
+  // 32 x 32 conv reaches this kernel, whose records nobody would read)
+  const bool merges = cgd_gn_merges_records(g.H * g.W);
+  p.stat = (g.stats && merges && (ctx->gn_epi & 1)) ? cgd_chanstats_register(ctx, g.C, g.ldc, g.N, g.M, s) : nullptr;
   p.bstat = nullptr; p.bx = g.gnb_x; p.bcoef = g.gnb_coef; p.ldbx = g.gnb_ldx; p.bact = g.gnb_act;
-  if (g.gnb_x && g.gnb_coef && (ctx->gn_epi & 2) && !(g.gnb_ldx & 3) && !((uintptr_t)g.gnb_x & 15) && !g.stats && !g.R)
+  if (g.gnb_x && g.gnb_coef && merges && (ctx->gn_epi & 2) && !(g.gnb_ldx & 3) && !((uintptr_t)g.gnb_x & 15) && !g.stats && !g.R)
     p.bstat = cgd_chanstats_register(ctx, g.C, g.ldc, g.N, g.M, s, 1);
+  ctx->last_wconv_bstat = p.bstat != nullptr;
   const int nb = cgd_wconv_nb(ctx, g), nc = cgd_wconv_nc(ctx, g);
   dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128 * nc));
 #define WC_LAUNCH(GN_, NB_, NC_) \

@@ -115,6 +115,10 @@ _SIGS = {
     "cgd_op_pack_conv3x3_wino": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cgd_op_conv3x3_wino": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "cgd_set_wino": (i32, [vp, i32, i32]),
+    "cgd_op_conv3x3_wino_ex": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    "cgd_op_new_pass": (i32, [vp]),
+    "cgd_op_gn_record_merges": (i64, [vp]),
+    "cgd_op_gn_stats_offset": (i64, [i32, i32, i32]),
     "cgd_op_wconv_schedule": (i32, [i32, i32, C.POINTER(i32)]),
     "cgd_op_conv_in": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cgd_op_conv_thin_out": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -14,8 +14,6 @@ def _fan_in(name, numel, specs):
     sib = name[:-len("weight")] + "bias" if name.endswith("weight") else None
     if sib in specs:
         return numel // specs[sib]
-    if name.endswith("in_proj_weight"):
-        return numel // specs[name[:-len("weight")] + "bias"]
     if name == "conv1.weight":  # ViT patch embedding [W][3][P][P], no bias
         return numel // specs["class_embedding"]
     raise KeyError(f"synthetic weights: no fan-in rule for {name}")

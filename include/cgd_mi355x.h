@@ -232,6 +232,23 @@ int cgd_op_conv3x3_wino(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float*
                         const float* R, int ldr, const float* gn_ab, int Bn, int H, int W, int Cin, int Cout, int upsample_input,
                         void* stream);
 int cgd_set_wino(cgd_ctx* ctx, int mode, int min_m);
+/* Round 5, test support for the conv-epilogue GroupNorm records: cgd_op_conv3x3_wino with the add-ons the UNet's
+ * ResBlocks switch on.  stats = 1: the epilogue also takes per-(8 x 16-pixel half tile, channel) statistics of y for the cgd_op_gn_fwd that
+ * reads y next (same pointer / row stride / rows; y may be a channel slice of a wider concat buffer).  gnb_x (+ gnb_ldx, gnb_scratch =
+ * the scratch of the FORWARD cgd_op_gn_fwd over gnb_x with act = 1): y is the upstream gradient dz of that GroupNorm + SiLU and the
+ * epilogue also takes the norm's backward sums, which the cgd_op_gn_bwd called on (gnb_x, y) then merges instead of sweeping x and dz.
+ * Records belong to the current pass: cgd_op_new_pass starts the next one (what cgd_unet_forward / cgd_unet_dgrad do), after which no
+ * earlier record can be served; a launch that rewrites y without taking records kills y's records too. */
+int cgd_op_conv3x3_wino_ex(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_wino, float* y_nhwc, int ldy, const float* bias,
+                           const float* R, int ldr, const float* gn_ab, int Bn, int H, int W, int Cin, int Cout, int upsample_input,
+                           int stats, const float* gnb_x, int gnb_ldx, const float* gnb_scratch, void* stream);
+int cgd_op_new_pass(cgd_ctx* ctx);
+/* number of GroupNorm launches since context creation that MERGED conv-epilogue records (forward statistics + backward sums) instead of
+ * sweeping their input: lets a test assert which path a cgd_op_gn_fwd / cgd_op_gn_bwd call took */
+int64_t cgd_op_gn_record_merges(cgd_ctx* ctx);
+/* host-only: float offset of the per-(sample, group) statistics {mean, rstd} [B][32][2] inside a cgd_op_gn_fwd scratch buffer (tests compare
+ * them with float64 group statistics) */
+int64_t cgd_op_gn_stats_offset(int B, int HW, int C);
 /* host-only (no GPU, no context): the software pipeline of wconv_kernel's patch staging inside one 24-step channel chunk, nb = 4 (16-row
  * tiles) or 2 (8-row tiles): out4 = {task whose 4 pixel loads are issued at step q, tasks whose transform piece 1 / 2 / 3 runs at step
  * q}, -1 = none; task k lives in register slot k & 1.  CPU tests check that no slot is reloaded while its task is still live. */

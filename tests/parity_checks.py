@@ -380,6 +380,126 @@ def check_norm():
     return out
 
 
+def _flag(name, cond):
+    """a boolean record (which path a launch took, counters): shows up in the same report as the numeric ones"""
+    return {"name": name, "err_abs": 0.0 if cond else 1.0, "err_rel": 0.0 if cond else 1.0, "ref_max": 1.0, "ok_strict": bool(cond),
+            "criterion": "strict", "ok": bool(cond)}
+
+
+def check_gn_records():
+    """Op-level parity of the conv-epilogue GroupNorm records (VERDICT r4 "missing" 4; csrc/wconv.hip `stat` / `bstat`, norm.hip
+    gn_stats_final_ch_kernel / gn_bwd_coef_ch_kernel): wconv_kernel launches write the two channel halves of a concat buffer with
+    |mean| / sigma = 10^3 (bias 1000, unit-variance conv output), B = 2; the GroupNorm that follows must MERGE the records (counter) and its
+    group statistics, output, and — with the dgrad conv's backward-sum records — input gradient must match float64 computed from the
+    tensors as stored.  Negative cases: a later pass (cgd_op_new_pass) and a rewrite of the tensor by a kernel that takes no records must
+    both send the GroupNorm back to the sweep path, with correct results for the NEW content."""
+    import ctypes as C
+    from cgd_amd import lib as L
+    from cgd_amd import ops
+    ctx = _ctx(1)
+    lib, out = ctx.lib, []
+    B, H, W, Ci, C0, C1 = 2, 64, 64, 32, 128, 64  # 192 channels: 6 per group, group 21 straddles the two halves (as 1024 + 512 does in the UNet)
+    HW, Ct = H * W, C0 + C1
+    merges = lambda: int(lib.cgd_op_gn_record_merges(ctx.h))  # noqa: E731
+    cat = th.zeros(B, HW, Ct, device=DEV)
+
+    def conv_into(c_off, Cn, seed, stats, bias_mean=1000.0, gnb=None):
+        x = th.randn(B, H, W, Ci, generator=g(seed)).to(DEV)
+        w = (th.randn(Cn, Ci, 3, 3, generator=g(seed + 1)) / math.sqrt(9 * Ci)).to(DEV)
+        b = (bias_mean + 3.0 * th.randn(Cn, generator=g(seed + 2))).to(DEV)
+        ww = ops.pack_conv3x3_wino(ctx, w)
+        ysl = cat[:, :, c_off:c_off + Cn]
+        gx, gld, gscr = (gnb[0].data_ptr(), gnb[1], gnb[2].data_ptr()) if gnb else (None, 0, None)
+        ctx.check(lib.cgd_op_conv3x3_wino_ex(ctx.h, x.data_ptr(), Ci, ww.data_ptr(), ysl.data_ptr(), Ct, b.data_ptr(), None, 0, None, B, H, W, Ci,
+                                             Cn, 0, int(stats), gx, gld, gscr, L.stream_ptr()))
+        return x, w, b
+
+    def gn_fwd(x3, Cn, ld, act=1):
+        gamma = (1 + 0.1 * th.randn(Cn, generator=g(91))).to(DEV)
+        beta = (0.1 * th.randn(Cn, generator=g(92))).to(DEV)
+        scr = ops.gn_scratch(ctx, B, HW, Cn, DEV)
+        y = th.empty(B, HW, Cn, device=DEV)
+        ctx.check(lib.cgd_op_gn_fwd(ctx.h, x3.data_ptr(), ld, y.data_ptr(), Cn, B, HW, Cn, gamma.data_ptr(), beta.data_ptr(), None, act, 1e-5,
+                                    scr.data_ptr(), L.stream_ptr()))
+        return y, scr, gamma, beta
+
+    def ref_fwd(x3, gamma, beta, act=1):
+        xr = x3.detach().double().cpu().requires_grad_()
+        y = F.group_norm(xr.permute(0, 2, 1), 32, gamma.double().cpu(), beta.double().cpu(), 1e-5)
+        if act:
+            y = F.silu(y)
+        return xr, y.permute(0, 2, 1)
+
+    def stats_recs(tag, scr, x3, Cn):
+        off = int(lib.cgd_op_gn_stats_offset(B, HW, Cn))
+        st = scr[off:off + B * 64].reshape(B, 32, 2).double().cpu()
+        xg = x3.detach().double().cpu().reshape(B, HW, 32, Cn // 32).permute(0, 2, 1, 3).reshape(B, 32, -1)
+        mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+        sig = var.sqrt()
+        # the mean in units of the group's sigma (|mean| / sigma = 1e3 here: a relative criterion on the mean would be vacuous)
+        return [rec(f"{tag} (group mean - float64 mean) / sigma [atol 2e-4, fp32 ulp of the mean = 6e-5 sigma]", (st[..., 0] - mean) / sig,
+                    th.zeros_like(mean), rtol=0.0, atol=2e-4, allow_small=True),
+                rec(f"{tag} group rstd", st[..., 1], 1.0 / (var + 1e-5).sqrt())]
+
+    # ---- forward: both concat halves carry their own records; the GroupNorm over the concat merges the two sources
+    conv_into(0, C0, 100, True)
+    conv_into(C0, C1, 110, True)
+    m0 = merges()
+    y, scr, gamma, beta = gn_fwd(cat, Ct, Ct)
+    out.append(_flag("gn records: forward GroupNorm of the concat merged the records of both halves", merges() == m0 + 1))
+    xr, yref = ref_fwd(cat, gamma, beta)
+    out += stats_recs("gn records fwd [concat 128 + 64, B2, |mean|/sigma 1e3]", scr, cat, Ct)
+    out.append(rec("gn records fwd y [concat, B2, |mean|/sigma 1e3]", y, yref.float()))
+    # ---- the same tensor through the sweep path (records dead after cgd_op_new_pass): same verdicts, and the two paths agree
+    ctx.check(lib.cgd_op_new_pass(ctx.h))
+    m0 = merges()
+    y2, scr2, _, _ = gn_fwd(cat, Ct, Ct)
+    out.append(_flag("gn records: no record is served in a later pass (sweep path taken)", merges() == m0))
+    out += stats_recs("gn sweep fwd [same tensor]", scr2, cat, Ct)
+    out.append(rec("gn sweep fwd y [same tensor]", y2, yref.float()))
+    # ---- negative: records registered, then the tensor is rewritten in the SAME pass by a kernel that takes none (generic GEMM writing the slice)
+    conv_into(0, C0, 100, True)
+    conv_into(C0, C1, 110, True)
+    a = th.randn(B * HW, 32, generator=g(120)).to(DEV)
+    bmat = th.randn(C0, 32, generator=g(121)).to(DEV)
+    ctx.check(lib.cgd_op_gemm(ctx.h, a.data_ptr(), 32, bmat.data_ptr(), 32, cat.data_ptr(), Ct, None, None, 0, B * HW, C0, 32, 0.2, 0, 1,
+                              L.stream_ptr()))
+    m0 = merges()
+    y3, scr3, _, _ = gn_fwd(cat, Ct, Ct)
+    out.append(_flag("gn records: a rewrite by a record-less kernel kills the tensor's records (sweep path taken)", merges() == m0))
+    _, yref3 = ref_fwd(cat, gamma, beta)
+    out.append(rec("gn fwd y after the rewrite (new content, not the stale records)", y3, yref3.float()))
+    # ---- backward: y = SiLU(GN(xn)); dz comes out of a dgrad conv whose epilogue takes the norm's backward sums from (dz, xn, coef)
+    ctx.check(lib.cgd_op_new_pass(ctx.h))
+    Cn = 64
+    xn = (1000.0 + th.randn(B, HW, Cn, generator=g(130))).to(DEV)  # the norm's input, |mean| / sigma = 1e3
+    yb, scrb, gam_b, bet_b = gn_fwd(xn, Cn, Cn)
+    dzb = th.zeros(B, HW, Cn, device=DEV)
+    cat_saved = cat
+    cat = dzb  # conv_into writes `cat`: point it at dz (row stride Cn)
+    Ct_saved, Ct = Ct, Cn
+    conv_into(0, Cn, 140, False, bias_mean=0.0, gnb=(xn, Cn, scrb))
+    m0 = merges()
+    dx = th.empty(B, HW, Cn, device=DEV)
+    ctx.check(lib.cgd_op_gn_bwd(ctx.h, xn.data_ptr(), Cn, dzb.data_ptr(), Cn, dx.data_ptr(), Cn, None, 0, B, HW, Cn, 1, scrb.data_ptr(),
+                                L.stream_ptr()))
+    out.append(_flag("gn records: backward GroupNorm merged the dgrad conv's backward-sum records", merges() == m0 + 1))
+    xr, yref = ref_fwd(xn, gam_b, bet_b)
+    (yref * dzb.double().cpu()).sum().backward()
+    sd = unit_seed(xr.grad)
+    out.append(rec("gn records bwd dx [B2, |mean|/sigma 1e3] (unit peak)", dx * sd, (xr.grad * sd).float()))
+    ctx.check(lib.cgd_op_new_pass(ctx.h))
+    m0 = merges()
+    dx2 = th.empty(B, HW, Cn, device=DEV)
+    ctx.check(lib.cgd_op_gn_bwd(ctx.h, xn.data_ptr(), Cn, dzb.data_ptr(), Cn, dx2.data_ptr(), Cn, None, 0, B, HW, Cn, 1, scrb.data_ptr(),
+                                L.stream_ptr()))
+    out.append(_flag("gn records: backward sums are not served in a later pass (sweep path taken)", merges() == m0))
+    out.append(rec("gn sweep bwd dx [same tensors] (unit peak)", dx2 * sd, (xr.grad * sd).float()))
+    cat, Ct = cat_saved, Ct_saved
+    th.cuda.synchronize()
+    return out
+
+
 def check_elem():
     from cgd_amd import ops
     ctx = _ctx(1)
