@@ -681,6 +681,33 @@ def check_unet(case, precision, B=1, hw=None, timestep=417.0):
     return [rec(f"{tag} forward", od, o.detach()), rec(f"{tag} dgrad", gx, xr.grad * sd)]
 
 
+def check_unet_knob_toggle():
+    """a knob change between forward() and dgrad() (cgd_set_wino(0): the dgrad convs leave wconv_kernel, so no backward-sum records
+    are taken) and a SECOND dgrad() after one that did take records must both give the gradient of the default route — a GroupNorm backward
+    that merged records of the earlier pass would be wrong by O(1).  Device against device (the default route is graded against the oracle
+    by check_unet)."""
+    ctx = _ctx(1)
+    _, dev = build_unet_pair(ctx, "mini")
+    B, H, W = 1, 128, 128  # the first level's convs (16384 pixels) run on wconv_kernel and take records
+    x = th.randn(B, 3, H, W, generator=g(60)).to(DEV)
+    t = th.tensor([417.0] * B).to(DEV)
+    y = th.randint(0, 10, (B,), generator=g(61)).to(DEV)
+    gout = th.randn(B, 6, H, W, generator=g(62))
+    gout[:, 3:] = 0
+    gout = gout.to(DEV)
+    dev.forward(x, t, y)
+    g1 = dev.dgrad(gout).clone()
+    sd = unit_seed(g1)
+    g1b = dev.dgrad(gout).clone()  # second backward pass of the same forward: its own records, not the first one's
+    dev.forward(x, t, y)
+    ctx.check(ctx.lib.cgd_set_wino(ctx.h, 0, 0))
+    g2 = dev.dgrad(gout).clone()
+    ctx.check(ctx.lib.cgd_set_wino(ctx.h, 1, 0))
+    th.cuda.synchronize()
+    return [rec("unet dgrad twice after one forward (unit peak)", g1b * sd, g1 * sd),
+            rec("unet dgrad with the Winograd kernel switched off between forward and dgrad (unit peak)", g2 * sd, g1 * sd)]
+
+
 def build_vit_pair(ctx, name="ViT-B/32", seed=4321):
     from cgd_amd import nets
     from oracle.clip_vit import ClipImageModel, synthetic_init_

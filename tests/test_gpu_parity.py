@@ -140,6 +140,10 @@ def test_unet_batch2_on_the_winograd_kernel_with_epilogue_records():
     _assert_all(pc.check_unet("mini", 1, B=2, hw=(128, 128)))
 
 
+def test_unet_dgrad_survives_a_knob_change_between_the_passes():
+    _assert_all(pc.check_unet_knob_toggle())
+
+
 def test_unet_64_checkpoint_shape():
     _assert_all(pc.check_unet("cfg64", 1))
 
