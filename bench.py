@@ -170,6 +170,48 @@ def pmc_traffic(kernel):
         return None
 
 
+def sample_power_clock(step_fn, th, seconds=2.5):
+    """Runs `step_fn` back to back for `seconds` while a thread samples `rocm-smi --showpower --showclocks`; returns the medians of the
+    samples taken while the GPU was busy ({} if rocm-smi is not there)."""
+    import re
+    import threading
+    smi = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return {}
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                out = subprocess.run([smi, "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:  # noqa: BLE001
+                return
+            clk = re.findall(r"sclk clock level.*?\((\d+)Mhz\)", out)
+            pw = re.findall(r"Power \(W\):\s*([\d.]+)", out)
+            if clk and pw:
+                samples.append((float(clk[0]), float(pw[0])))
+
+    t = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 0.5:  # fill the queue before the first sample
+        step_fn()
+        n += 1
+    t.start()
+    while time.perf_counter() - t0 < seconds + 0.5:
+        step_fn()
+        n += 1
+    stop.set()
+    th.cuda.synchronize()
+    t.join(timeout=6)
+    if not samples:
+        return {}
+    clk = sorted(s[0] for s in samples)[len(samples) // 2]
+    pw = sorted(s[1] for s in samples)[len(samples) // 2]
+    return {"clock_ghz": round(clk / 1e3, 3), "power_w": pw, "power_clock_samples": len(samples),
+            "power_clock_source": f"rocm-smi median over {len(samples)} samples during an untimed pass of {n} steps"}
+
+
 def build_device(ctx, cfg, dev):
     import torch as th
     from cgd_amd import diffusion as dd
@@ -283,7 +325,7 @@ def main():
     th.manual_seed(1000 + rank)
     loop = smp.ddim_sample_loop_progressive if cfg["ddim"] else smp.p_sample_loop_progressive
 
-    def trajectory():
+    def trajectory(unet=unet, guid=guid, loop=loop, x0_star=x0_star):
         """Endless stream of guided steps: chains of start+1 steps, each step consuming the previous step's sample."""
         while True:
             gen = loop(unet, (1, 3, H, W), clip_denoised=False, cond_fn=guid, model_kwargs={"y": th.zeros(1, dtype=th.long, device=dev)},
@@ -407,6 +449,32 @@ def main():
                    "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                    "algorithmic_gbytes_per_step": round(gn_bytes / ps / 1e9, 3), "ms_per_step": round(gn_ms / ps, 3), "ops_per_step": gn_n / ps,
                    "kernel_time_share": round(gn_ms * 1e-3 / dtp, 4)}
+    # board power and shader clock while the step loop runs (rocm-smi sampled from a thread during a separate UNTIMED pass: the sampler's
+    # subprocesses stay out of the timed region); the dominant kernel is power-limited (profiles/r5_wconv_power.txt), so the clock the step
+    # sustains belongs next to its roofline fraction
+    if roof is not None and rank == 0 and not args.no_profile:
+        roof.update(sample_power_clock(lambda: next(steps), th, seconds=2.5))
+    # the exact-fp32 MFMA mode (the reference's own arithmetic) beside the headline mode: a second context + networks, short untimed pass
+    precision_modes = None
+    if rank == 0 and world == 1 and args.config == 2 and args.precision == "bf16x3" and not args.no_profile:
+        try:
+            ctx32 = lib.Context(local, "f32")
+            unet32, _t32, smp32, guid32, x032 = build_device(ctx32, cfg, dev)
+            st32 = trajectory(unet32, guid32, smp32.p_sample_loop_progressive, x032)
+            for _ in range(2):
+                next(st32)
+            th.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(12):
+                next(st32)
+            th.cuda.synchronize()
+            d32 = (time.perf_counter() - tq) / 12
+            precision_modes = {"f32": {"steps_per_sec": round(1.0 / d32, 3), "ms_per_step": round(d32 * 1e3, 3), "steps": 12,
+                                       "note": "exact fp32 MFMA products (v_mfma_f32_32x32x2_f32), same workload, untimed-region pass on a "
+                                               "second context; `value` above is the bf16x3 mode"}}
+            del st32, unet32, guid32, smp32, ctx32
+        except Exception as e:  # never lose the headline number to the side column
+            precision_modes = {"f32": {"error": f"{type(e).__name__}: {e}"}}
     assert finite, "non-finite sample"
     tdev = dev if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
     tmax = th.tensor([dt], device=tdev, dtype=th.float64)
@@ -459,6 +527,8 @@ def main():
                        "timed_seconds": round(tmax, 3), "last_sample_peak": round(peak, 3),
                        "tflop_per_step": cfg["tflop"], "achieved_tflops_whole_step": round(cfg["tflop"] * args.steps / tmax, 2)},
         }
+        if precision_modes:
+            res["precision_modes"] = precision_modes
         if roof:
             res["roofline"] = roof
         if hbm:

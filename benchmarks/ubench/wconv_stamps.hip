@@ -10,6 +10,7 @@
 
 // the launcher in wconv.hip asks norm.hip for a statistics buffer; this stand-alone build takes no statistics
 float* cgd_chanstats_register(cgd_ctx*, const float*, int, int, long, hipStream_t, int) { return nullptr; }
+bool cgd_gn_merges_records(int) { return false; }
 
 #include <string.h>
 

@@ -135,6 +135,8 @@ struct cgd_ctx {
                        // launch 17.9 -> 16.1 us with warm caches), 2 = wherever K allows.  Step-level A/B (profiles/r4_hgemm_kgroups.txt): 0 is 0.055 ms
                        // and 2 is 0.29 ms SLOWER than 1 — inside a step every launch starts on cold L2s and the longer prologue / hand-over of the
                        // 8-wavefront workgroup costs more than its faster loop gains (A/B knob CGD_HGEMM_KG)
+  int kgemm_mode = 1, kgemm_max_m = 256;  // (round 5) weight GEMMs of 5 .. kgemm_max_m rows run on kgemm_kernel (hgemm.hip, tile code 518): K split inside the
+                       // workgroup, one slice, no reduce launch (A/B knob CGD_KGEMM="<mode>[,<max rows>]")
   int hgemm_var = 1;   // weight GEMM kernel variant (hgemm.hip cgd_hgemm_tile_m): 0 hgemm_kernel, 1 hgemm2 auto tile, 2 / 3 hgemm2 128 / 64 rows
   int hgemm_mode = 1, hgemm_min_m = 64, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
                                                                 // igemm's finer tiles win), chunks per split-K slice
@@ -235,7 +237,8 @@ struct GemmParams {
   int no_split = 0;  // 1: never split K automatically (the caller keeps data of its own in the workspace)
   float* ws = nullptr;
   int force_tile = 0;  // 0 auto; 64 / 128 / 256 / 257 (+1000: 2-deep prefetch) igemm tiles; 512 halo conv kernel; 513 weight GEMM kernel;
-                       // 515 Winograd halo conv kernel (wconv.hip); 516 weight-streaming halo conv kernel (kconv.hip); 517 GEMV kernel (M <= 4)
+                       // 515 Winograd halo conv kernel (wconv.hip); 516 weight-streaming halo conv kernel (kconv.hip); 517 GEMV kernel (M <= 4);
+                       // 518 few-row weight GEMM kernel (hgemm.hip kgemm_kernel, M <= 256, K split inside the workgroup)
   int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
   const void* Bwk = nullptr;  // conv only: Winograd F(2,3)-transformed weights in fragment order (cgd_pack_conv3x3_wino) for wconv.hip
@@ -313,6 +316,9 @@ int cgd_hgemm_tiles(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_hgemm_chunks(const GemmParams& p);
 int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 void cgd_frag_cache_clear(cgd_ctx* ctx);
+bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p);
+int cgd_kgemm_tiles(const cgd_ctx* ctx, const GemmParams& p);
+int cgd_launch_kgemm(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s);
 // would cgd_launch_gemm run this conv on the halo kernel (the only one that can apply a GroupNorm on the fly)?

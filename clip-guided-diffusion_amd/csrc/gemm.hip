@@ -492,6 +492,14 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
     return 0;
   }
   if (p.force_tile == 517) CGD_FAIL(ctx, "cgd_launch_gemm: the GEMV kernel takes M <= 4, one batch, K and ldb multiples of 4");
+  // few-row weight GEMM (tile code 518, kernel 4): K split inside the workgroup, always one slice
+  if ((p.force_tile == 518 || !p.force_tile) && !p.conv && cgd_kgemm_supported(ctx, p)) {
+    p.splitk = 1;
+    *tile_out = 518;
+    *kernel_out = 4;
+    return 0;
+  }
+  if (p.force_tile == 518) CGD_FAIL(ctx, "cgd_launch_gemm: the few-row weight GEMM kernel does not support this problem");
   const int nkt = cdiv(p.K, BK);
   if (p.splitk <= 0) p.splitk = 1;
   int tile = p.force_tile;
@@ -676,6 +684,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
       default: GV_LAUNCH(4); break;
     }
 #undef GV_LAUNCH
+  } else if (kernel == 4) {
+    CGD_TRY(cgd_launch_kgemm(ctx, p, s));
   } else if (use_h) {
     if (tile == 515) {
       ProfRec pr2;  // second record of the same launch for the launches that carry the GroupNorm-backward epilogue (kind 5): begun for every
@@ -744,6 +754,8 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   if (kernel == 1) {
     wg = tile == 516 ? cgd_kconv_tiles_m(p) * (p.N >> 5)
                      : (tile == 515 ? cgd_wconv_tiles_m(&ctx, p) * cdiv(p.N, 128 * cgd_wconv_nc(&ctx, p)) : cgd_hconv_tiles_m(&ctx, p) * cdiv(p.N, 128));
+  } else if (kernel == 4) {
+    wg = cgd_kgemm_tiles(&ctx, p);
   } else if (kernel == 3) {
     wg = std::min<long>(std::max<long>(cdiv(p.N, 16), 1), 4L * ctx.num_cu);
   } else if (kernel == 2) {

@@ -696,6 +696,127 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// kgemm_kernel (round 5): weight GEMMs with FEW rows (M <= 256: the 1x1 convolutions / qkv / proj_out of the UNet's 8x8 and 16x16 levels).
+// hgemm2 gives such a launch M / 64 x N / 128 = 8-96 workgroups and therefore splits K 2-12 ways across workgroups to put the weight stream
+// on enough CUs: 2-12 fp32 slabs + a reduce launch per GEMM (84 of the step's 181 reduce launches, VERDICT r4 "weak" 7).  Here K is split INSIDE
+// the workgroup instead (kconv.hip's recipe): a workgroup owns 32 * NI rows x ONE 32-column block, its 4 wavefronts take the 16-deep k-steps
+// w, w + 4, w + 8, ... (each streams only its own weight fragments, a register ring RING k-steps deep, and fetches its own 32-byte activation
+// runs straight from global memory: an activation element is used by exactly one wavefront, so there is nothing to share through LDS and no
+// barrier in the loop), and the four partial accumulators are summed through LDS at the end.  N / 32 x M / (32 NI) workgroups without any
+// inter-workgroup split: no slabs, no reduce launch.  Same packed weights as hgemm2 (cgd_frag_cache).
+template <int MODE, int NI, int RING>
+__global__ __launch_bounds__(256) void kgemm_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+                                                    const float* __restrict__ biasg, const float* Rg, const HGemmParams p) {
+  constexpr int NPL = MODE == 1 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float red[4 * NI * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbN = p.N >> 5;
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // column-block major: the row tiles that share a weight block are neighbours on one XCD
+  const int ntm = gridDim.x / nbN;
+  const int mt = bid % ntm, nb = bid / ntm;
+  const int m0 = mt * (32 * NI);
+  const int nks = p.K >> 4;                       // 16-deep k-steps
+  const int mine = (nks - w + 3) >> 2;            // k-steps w, w + 4, ... of this wavefront
+  const uint4* __restrict__ Bw = Bg + ((long)nb * nks) * (2 * 64) + lane;  // k-step kq: Bw[kq * 128] (hi), Bw[kq * 128 + 64] (lo)
+  long arow[NI];
+  bool aok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int r = m0 + 32 * i + l31;
+    aok[i] = r < p.M;
+    arow[i] = (long)(aok[i] ? r : p.M - 1) * p.lda + 8 * hh;
+  }
+  f32x16 acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  uint4 bq[RING][NPL];
+  f32x4 aq[RING][NI][2];
+#define KG_LOAD(SLOT, T)                                                                          \
+  {                                                                                               \
+    const int t_ = (T) < mine ? (T) : mine - 1; /* clamped: the loads stay unconditional */       \
+    const int kq_ = w + 4 * t_;                                                                   \
+    bq[SLOT][0] = Bw[(long)kq_ * 128];                                                            \
+    if constexpr (MODE == 1) bq[SLOT][1] = Bw[(long)kq_ * 128 + 64];                              \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
+      aq[SLOT][i][0] = *(const f32x4*)(Ag + arow[i] + 16 * kq_);                                  \
+      aq[SLOT][i][1] = *(const f32x4*)(Ag + arow[i] + 16 * kq_ + 4);                              \
+    }                                                                                             \
+  }
+#define KG_STEP(SLOT)                                                                             \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
+      const f32x4 a0 = aok[i] ? aq[SLOT][i][0] : f32x4{0.f, 0.f, 0.f, 0.f};                       \
+      const f32x4 a1 = aok[i] ? aq[SLOT][i][1] : f32x4{0.f, 0.f, 0.f, 0.f};                       \
+      bf16x8 ah, al;                                                                              \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+        ah[e] = (__bf16)a0[e];                                                                    \
+        ah[4 + e] = (__bf16)a1[e];                                                                \
+        al[e] = (__bf16)(a0[e] - (float)ah[e]);                                                   \
+        al[4 + e] = (__bf16)(a1[e] - (float)ah[4 + e]);                                           \
+      }                                                                                           \
+      if constexpr (MODE == 1) {                                                                  \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[SLOT][0]), al, acc[i], 0, 0, 0); \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[SLOT][1]), ah, acc[i], 0, 0, 0); \
+      }                                                                                           \
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[SLOT][0]), ah, acc[i], 0, 0, 0); \
+    }                                                                                             \
+  }
+  if (mine > 0) {
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) KG_LOAD(q, q);
+    int t = 0;
+    for (; t + RING <= mine; t += RING) {
+#pragma unroll
+      for (int u = 0; u < RING; ++u) {
+        KG_LOAD((u + RING - 1) % RING, t + u + RING - 1);
+        KG_STEP(u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u)
+      if (t + u < mine) {
+        KG_LOAD((u + RING - 1) % RING, t + u + RING - 1);
+        KG_STEP(u);
+      }
+  }
+#undef KG_LOAD
+#undef KG_STEP
+  // ---- the four K partitions meet in LDS: element (wavefront, row block i, register r, lane) at ((w * NI + i) * 16 + r) * 64 + lane (conflict-free
+  //      4-byte accesses); wavefront w' then finishes registers 4 w' .. 4 w' + 3 of every row block = 4 consecutive columns 8 w' + 4 hh .. + 3
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((w * NI + i) * 16 + r) * 64 + lane] = acc[i][r];
+  __syncthreads();
+  const int col = nb * 32 + 8 * w + 4 * hh;
+  f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (biasg) bv = *(const f32x4*)(biasg + col);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += red[((k * NI + i) * 16 + 4 * w + e) * 64 + lane];
+    const long row = m0 + 32 * i + l31;
+    if (row < p.M) {
+      o = o * p.alpha;
+      if (biasg) o += bv;
+      if (Rg) o += *(const f32x4*)(Rg + row * p.ldr + col);
+      *(f32x4*)(Cg + row * p.ldc + col) = o;
+    }
+  }
+}
+
 // w [N][ldw] row-major (k contiguous) -> fragment order [N/32][K/32][ks][plane][lane][8] (bf16 hi / lo)
 __global__ __launch_bounds__(256) void pack_frag_linear_kernel(const float* __restrict__ w, int ldw, __bf16* __restrict__ out, int N, int K) {
   const long total = (long)N * K;
@@ -755,6 +876,35 @@ int cgd_hgemm_tile_m(const cgd_ctx* ctx, const GemmParams& p) {
 }
 int cgd_hgemm_tiles(const cgd_ctx* ctx, const GemmParams& p) { return cdiv(p.M, cgd_hgemm_tile_m(ctx, p)) * cdiv(p.N, GN); }
 int cgd_hgemm_chunks(const GemmParams& p) { return p.K / GK; }
+
+// kgemm_kernel takes persistent-weight GEMMs of 5 .. kgemm_max_m rows in one slice, without the epilogue options only hgemm2 has
+bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p) {
+  return ctx->kgemm_mode && p.weight && p.M > 4 && p.M <= ctx->kgemm_max_m && cgd_hgemm_supported(ctx, p) && !p.act_out && !p.act_in && !p.skip_group &&
+         p.splitk <= 1 && (long)p.M * p.lda < (1L << 31);
+}
+int cgd_kgemm_ni(const cgd_ctx* ctx, const GemmParams& p) {  // 64-row tiles only where 32-row tiles would exceed two workgroups per CU
+  return (long)cdiv(p.M, 32) * (p.N >> 5) > 2L * ctx->num_cu ? 2 : 1;
+}
+int cgd_kgemm_tiles(const cgd_ctx* ctx, const GemmParams& p) { return cdiv(p.M, 32 * cgd_kgemm_ni(ctx, p)) * (p.N >> 5); }
+
+int cgd_launch_kgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
+  const void* packed = cgd_frag_cache_get(ctx, g.B, g.N, g.K, g.ldb, s);
+  if (!packed) CGD_FAIL(ctx, "kgemm: out of memory for the packed weight copy");
+  HGemmParams p = {};
+  p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
+  p.M = g.M; p.N = g.N; p.K = g.K; p.splitk = 1; p.alpha = g.alpha;
+  const int ni = cgd_kgemm_ni(ctx, g);
+  dim3 grid(cgd_kgemm_tiles(ctx, g));
+  const bool x3 = ctx->precision == CGD_PREC_BF16X3;
+#define KG_ARGS grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, p
+  if (ni == 2) {
+    if (x3) CGD_LAUNCH((kgemm_kernel<1, 2, 4>), KG_ARGS); else CGD_LAUNCH((kgemm_kernel<2, 2, 4>), KG_ARGS);
+  } else {
+    if (x3) CGD_LAUNCH((kgemm_kernel<1, 1, 6>), KG_ARGS); else CGD_LAUNCH((kgemm_kernel<2, 1, 6>), KG_ARGS);
+  }
+#undef KG_ARGS
+  return 0;
+}
 
 int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   const void* packed = nullptr;

@@ -203,7 +203,8 @@ int cgd_sample_update(cgd_ctx* ctx, const float* x, const float* pred_xstart, co
 /* ---- single ops, exported for parity tests and for user-supplied cond_fn plumbing ---- */
 /* C[M][N] = alpha * A[M][K] B[N][K]^T (+bias[N]) (+R[M][N]); conv3x3: A is NHWC (Bn,H,W,Cin), B = [N][9*Cin].
  * force_tile: 0 auto, 64 / 128 / 256 / 257 (+1000: two-deep prefetch) igemm tiles, 513 weight GEMM kernel (B re-packed per call),
- * 514 the same with the packed copy cached by B's pointer (B must persist; micro-benchmarks).  splitk: >= 1 slices (1 = automatic), -1 = one
+ * 514 the same with the packed copy cached by B's pointer (B must persist; micro-benchmarks), 518 the few-row weight GEMM kernel (M <= 256, K split
+ * inside the workgroup, one slice; the packed-weight cache is emptied first).  splitk: >= 1 slices (1 = automatic), -1 = one
  * slice, never split automatically. */
 int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, const float* R,
                 int ldr, int M, int N, int K, float alpha, int force_tile, int splitk, void* stream);

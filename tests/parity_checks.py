@@ -103,6 +103,10 @@ def check_gemm(precision):
     if precision != 0:  # weight GEMM kernel (hgemm.hip, tile code 513): ragged M, partial N tile, split-K, single chunk
         cases += [(800, 768, 768, 513, 1), (200, 96, 256, 513, 2), (128, 160, 64, 513, 1), (1000, 2304, 768, 513, 1),
                   (70, 32, 3072, 513, 5), (784, 768, 3072, 513, 0)]
+        # few-row weight GEMM kernel (hgemm.hip kgemm_kernel, tile code 518, round 5): the UNet's 8x8 / 16x16-level 1x1 convs (M = 64 / 256), 64-row
+        # tiles (8 x 96 > 512 workgroups), ragged M with a partly and a wholly empty last row block, one k-step per wavefront, 5 rows
+        cases += [(64, 1024, 1024, 518, 1), (256, 3072, 1024, 518, 1), (64, 1024, 3072, 518, 1), (70, 96, 256, 518, 1), (200, 3072, 512, 518, 1),
+                  (256, 512, 64, 518, 1), (5, 64, 192, 518, 1), (50, 768, 768, 518, 1)]
     for (M, N, K, tile, sk) in cases:
         # O(1) outputs: unit-variance product term (alpha = 1/sqrt(K)), small bias and residual
         A = th.randn(M, K, generator=g(1))

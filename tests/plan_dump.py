@@ -13,7 +13,7 @@ import torch as th  # noqa: E402
 import cgd_amd  # noqa: E402,F401
 from cgd_amd import lib  # noqa: E402
 
-KERNELS = {0: "igemm", 1: "hconv2", 2: "hgemm", 3: "gemv"}
+KERNELS = {0: "igemm", 1: "hconv2", 2: "hgemm", 3: "gemv", 4: "kgemm"}
 
 
 def record_shapes(net, *args, call=None):

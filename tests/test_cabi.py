@@ -110,13 +110,15 @@ def test_dispatch_policy_of_the_contraction_launcher():
     assert _plan(handle, M=800, N=3072, K=768, weight=1) == (0, (2, 513, 1, 312))
     assert _plan(handle, M=800, N=768, K=3072, weight=1) == (0, (2, 513, 3, 234))
     assert _plan(handle, M=65536, N=256, K=512, weight=1) == (0, (2, 513, 1, 1024))  # 1x1 skip conv at 256^2
-    # activations x activations (no persistent weight) and 4 < M < 64 stay on the generic kernel; the
-    # 16x16-level qkv / proj GEMMs (M = 256) take the 64-row weight GEMM tile
+    # activations x activations (no persistent weight) stay on the generic kernel; (round 5) weight GEMMs of 5 .. 256 rows — the 8x8- and
+    # 16x16-level qkv / proj / skip GEMMs — take the few-row kernel (tile code 518: K split inside the workgroup, ONE slice, no reduce launch)
     assert _plan(handle, M=800, N=768, K=768, weight=0)[1][0] == 0
-    assert _plan(handle, M=256, N=3072, K=1024, weight=1)[1][0] == 2
+    assert _plan(handle, M=256, N=3072, K=1024, weight=1) == (0, (4, 518, 1, 384))   # 8 x 96 32-row tiles would be > 2 per CU: 64-row tiles
+    assert _plan(handle, M=64, N=1024, K=3072, weight=1) == (0, (4, 518, 1, 64))     # was 12 split-K slices + a reduce
+    assert _plan(handle, M=257, N=1024, K=1024, weight=1)[1][0] == 2
     assert _plan(handle, M=1, N=1024, K=256, weight=1) == (0, (3, 517, 1, 64))      # M <= 4: the weight-streaming GEMV, no split-K
     assert _plan(handle, M=1, N=103424, K=1024, weight=1) == (0, (3, 517, 1, 1024))  # all FiLM projections of the 256x256 UNet at once
-    assert _plan(handle, M=5, N=1024, K=256, weight=1)[1][0] == 0
+    assert _plan(handle, M=5, N=1024, K=256, weight=1)[1][:2] == (4, 518)
     # fewer CUs -> fewer slices; argument validation happens before any launch
     assert _plan(handle, conv=1, M=64 * 64, N=512, H=64, W=64, Cin=512, num_cu=256)[1][2] == 2
     assert _plan(handle, conv=1, M=64 * 64, N=512, H=64, W=64, Cin=512, num_cu=64)[1][2] == 1
