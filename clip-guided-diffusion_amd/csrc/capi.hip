@@ -53,7 +53,8 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (wino_env_mode >= 0) cgd_apply_wino_mode(ctx, wino_env_mode);  // same meaning as cgd_set_wino(mode) (mode 5)
   if (const char* e = getenv("CGD_GN_EPI")) ctx->gn_epi = atoi(e);
   if (const char* e = getenv("CGD_HGEMM_KG")) ctx->hgemm_kg = atoi(e) < 0 || atoi(e) > 2 ? 1 : atoi(e);
-  if (const char* e = getenv("CGD_KGEMM")) sscanf(e, "%d,%d", &ctx->kgemm_mode, &ctx->kgemm_max_m);
+  if (const char* e = getenv("CGD_HGEMM_TM96")) ctx->hgemm_tm96 = atoi(e);
+  if (const char* e = getenv("CGD_KGEMM")) sscanf(e, "%d,%d,%d", &ctx->kgemm_mode, &ctx->kgemm_max_m, &ctx->kgemm_var);
   if (const char* e = getenv("CGD_KCONV")) sscanf(e, "%d,%d,%d", &ctx->kconv_mode, &ctx->kconv_max_m, &ctx->kconv_min_chunks);
   if (const char* e = getenv("CGD_HCONV_SPLIT")) sscanf(e, "%d,%d", &ctx->hconv_slots, &ctx->hconv_min_chunks);
   if (ctx->kconv_min_chunks < 1) ctx->kconv_min_chunks = 1;  // divisors of the split-K policy
@@ -252,6 +253,10 @@ int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, 
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.force_tile = force_tile; p.splitk = splitk;
   if (force_tile == 518) {  // few-row weight GEMM kernel (kgemm_kernel): it reads the fragment copy cached by B's pointer; tests hand over a fresh B
     cgd_frag_cache_clear(ctx);  // per call, possibly at a recycled address, so the cache is emptied first (hipFree waits for kernels in flight)
+    p.weight = 1;
+  }
+  if (force_tile == 519) {  // micro-benchmarks: kgemm_kernel with the fragment copy cached by B's pointer (B must persist)
+    p.force_tile = 518;
     p.weight = 1;
   }
   if (force_tile == 514) {  // micro-benchmarks: weight GEMM kernel with the fragment copy cached by B's pointer (B must persist)

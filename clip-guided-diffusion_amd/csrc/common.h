@@ -135,8 +135,10 @@ struct cgd_ctx {
                        // launch 17.9 -> 16.1 us with warm caches), 2 = wherever K allows.  Step-level A/B (profiles/r4_hgemm_kgroups.txt): 0 is 0.055 ms
                        // and 2 is 0.29 ms SLOWER than 1 — inside a step every launch starts on cold L2s and the longer prologue / hand-over of the
                        // 8-wavefront workgroup costs more than its faster loop gains (A/B knob CGD_HGEMM_KG)
+  int kgemm_var = 0;   // A/B variants of kgemm_kernel's launch (cgd_launch_kgemm)
   int kgemm_mode = 1, kgemm_max_m = 256;  // (round 5) weight GEMMs of 5 .. kgemm_max_m rows run on kgemm_kernel (hgemm.hip, tile code 518): K split inside the
                        // workgroup, one slice, no reduce launch (A/B knob CGD_KGEMM="<mode>[,<max rows>]")
+  int hgemm_tm96 = 1;  // (round 5) hgemm2 on 96-row tiles where they turn two rounds of 64-row workgroups into one (cgd_hgemm_tile_m; A/B knob CGD_HGEMM_TM96)
   int hgemm_var = 1;   // weight GEMM kernel variant (hgemm.hip cgd_hgemm_tile_m): 0 hgemm_kernel, 1 hgemm2 auto tile, 2 / 3 hgemm2 128 / 64 rows
   int hgemm_mode = 1, hgemm_min_m = 64, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
                                                                 // igemm's finer tiles win), chunks per split-K slice

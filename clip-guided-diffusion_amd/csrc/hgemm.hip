@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 bv = hb ? f32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]} : z4;
     const float ka = p.act == 2 ? 1.702f : 1.f;  // QuickGELU x * sigmoid(1.702 x) / SiLU
-    constexpr int EB = TM == 64 ? 8 : 4;         // rows in flight per lane (the 128-row instantiation must stay within 256 registers)
+    constexpr int EB = TM == 64 ? 8 : 4;         // rows in flight per lane (the 96- / 128-row instantiations must stay within 256 registers)
 #pragma unroll
     for (int i0 = 0; i0 < TM / 8; i0 += EB) {
       f32x4 v[EB], rv[EB], uv[EB];
@@ -871,7 +871,13 @@ void cgd_frag_cache_clear(cgd_ctx* ctx) {
 // while 128-row tiles would not give every CU a workgroup, 128 rows otherwise; 2 / 3 force hgemm2 with 128 / 64 rows
 int cgd_hgemm_tile_m(const cgd_ctx* ctx, const GemmParams& p) {
   if (ctx->hgemm_var == 3) return 64;
-  if (ctx->hgemm_var == 1 && (long)cdiv(p.M, GM) * cdiv(p.N, GN) < ctx->num_cu) return 64;
+  if (ctx->hgemm_var == 1 && (long)cdiv(p.M, GM) * cdiv(p.N, GN) < ctx->num_cu) {
+    // (round 5) 96-row tiles where 64-row tiles need more workgroups than the chip has CUs but 96-row tiles do not: the ViT's M = 800,
+    // N = 3072 linears are 13 x 24 = 312 workgroups (56 CUs run two, the makespan is theirs) on 64 rows, 9 x 24 = 216 = one round on 96
+    const long t64 = (long)cdiv(p.M, 64) * cdiv(p.N, GN), t96 = (long)cdiv(p.M, 96) * cdiv(p.N, GN);
+    if (ctx->hgemm_tm96 && ctx->precision != CGD_PREC_F32 && t64 > ctx->num_cu && t96 <= ctx->num_cu) return 96;
+    return 64;
+  }
   return GM;
 }
 int cgd_hgemm_tiles(const cgd_ctx* ctx, const GemmParams& p) { return cdiv(p.M, cgd_hgemm_tile_m(ctx, p)) * cdiv(p.N, GN); }
@@ -893,14 +899,21 @@ int cgd_launch_kgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   HGemmParams p = {};
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.K = g.K; p.splitk = 1; p.alpha = g.alpha;
-  const int ni = cgd_kgemm_ni(ctx, g);
-  dim3 grid(cgd_kgemm_tiles(ctx, g));
+  int ni = cgd_kgemm_ni(ctx, g);
+  if (ctx->kgemm_var & 1) ni = 2;   // A/B variants (CGD_KGEMM="<mode>,<max rows>,<variant bits>"): bit 0 = 64-row tiles everywhere,
+  if (ctx->kgemm_var & 2) ni = 1;   // bit 1 = 32-row tiles everywhere, bit 2 = deep rings (10 / 6 k-steps instead of 6 / 4)
+  dim3 grid(cdiv(g.M, 32 * ni) * (g.N >> 5));
   const bool x3 = ctx->precision == CGD_PREC_BF16X3;
+  const bool deep = (ctx->kgemm_var & 4) != 0;
 #define KG_ARGS grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, p
   if (ni == 2) {
-    if (x3) CGD_LAUNCH((kgemm_kernel<1, 2, 4>), KG_ARGS); else CGD_LAUNCH((kgemm_kernel<2, 2, 4>), KG_ARGS);
+    if (!x3) CGD_LAUNCH((kgemm_kernel<2, 2, 4>), KG_ARGS);
+    else if (deep) CGD_LAUNCH((kgemm_kernel<1, 2, 6>), KG_ARGS);
+    else CGD_LAUNCH((kgemm_kernel<1, 2, 4>), KG_ARGS);
   } else {
-    if (x3) CGD_LAUNCH((kgemm_kernel<1, 1, 6>), KG_ARGS); else CGD_LAUNCH((kgemm_kernel<2, 1, 6>), KG_ARGS);
+    if (!x3) CGD_LAUNCH((kgemm_kernel<2, 1, 6>), KG_ARGS);
+    else if (deep) CGD_LAUNCH((kgemm_kernel<1, 1, 10>), KG_ARGS);
+    else CGD_LAUNCH((kgemm_kernel<1, 1, 6>), KG_ARGS);
   }
 #undef KG_ARGS
   return 0;
@@ -952,6 +965,8 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
     // micro-benchmark shows a gain (profiles/r4_hgemm_kgroups.txt): one workgroup per CU at most (an 8-wavefront workgroup has a CU to itself,
     // a second round of workgroups costs more than the loop gains) and >= 8 64-deep chunks per slice (the prologue / hand-over are longer)
     CGD_LAUNCH((hgemm2_kernel<1, 64, 8, 2, 2>), grid, dim3(512), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p);
+  } else if (tm == 96) {
+    if (x3) CGD_LAUNCH((hgemm2_kernel<1, 96, 8, 2>), HG_ARGS); else CGD_LAUNCH((hgemm2_kernel<2, 96, 8, 2>), HG_ARGS);
   } else if (tm == 64) {
     if (x3) CGD_LAUNCH((hgemm2_kernel<1, 64>), HG_ARGS); else CGD_LAUNCH((hgemm2_kernel<2, 64>), HG_ARGS);
   } else {

@@ -107,7 +107,7 @@ def test_dispatch_policy_of_the_contraction_launcher():
     # the 64-row tile is used: the N >= 2304 linears fill the chip without split-K, the N = 768 ones split 3 ways
     assert _plan(handle, M=800, N=768, K=768, weight=1) == (0, (2, 513, 3, 234))
     assert _plan(handle, M=800, N=2304, K=768, weight=1) == (0, (2, 513, 1, 234))
-    assert _plan(handle, M=800, N=3072, K=768, weight=1) == (0, (2, 513, 1, 312))
+    assert _plan(handle, M=800, N=3072, K=768, weight=1) == (0, (2, 513, 1, 216))  # (round 5) 96-row tiles: one round of workgroups instead of 312 on 64 rows
     assert _plan(handle, M=800, N=768, K=3072, weight=1) == (0, (2, 513, 3, 234))
     assert _plan(handle, M=65536, N=256, K=512, weight=1) == (0, (2, 513, 1, 1024))  # 1x1 skip conv at 256^2
     # activations x activations (no persistent weight) stay on the generic kernel; (round 5) weight GEMMs of 5 .. 256 rows — the 8x8- and
