@@ -109,6 +109,8 @@ struct cgd_ctx {
   int thin_direct = 1;  // 1: the 3-channel INPUT-side conv (UNet stem forward) runs on the direct fp32 kernel of conv_thin.hip (one write pass
                         // over the wide tensor); 2: the 6-channel one (head dgrad) too; 0: the round-1 MFMA route (im2col + GEMM) for both
                         // (A/B knob CGD_THIN)
+  int kconv_tw8 = 1;    // (round 5) kconv_kernel on 8 x 8-pixel tiles (two workgroups per CU) wherever W is a multiple of 8; 0: the 8 x 16 tile
+  int kconv_slots = 0;  // split-K target of kconv in workgroups (0 = one per CU, the rounds 3-4 policy); A/B knobs, 4th / 5th field of CGD_KCONV
   int kconv_mode = 1, kconv_max_m = 1024, kconv_min_chunks = 4;  // weight-streaming variant of the halo conv (kconv.hip, tile code 516): for
                                           // convs of at most kconv_max_m pixels; split-K slices of at least kconv_min_chunks chunks (A/B knob
                                           // CGD_KCONV="<mode>[,<max pixels>[,<min chunks>]]")
@@ -308,7 +310,8 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight-streaming halo conv for the small maps (kconv.hip): K split inside the workgroup, one 32-channel output block per workgroup
 bool cgd_kconv_supported(const cgd_ctx* ctx, const GemmParams& p);
-long cgd_kconv_tiles_m(const GemmParams& p);
+long cgd_kconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p);
+int cgd_kconv_tw(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------

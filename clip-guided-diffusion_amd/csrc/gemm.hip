@@ -523,10 +523,11 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   // (cgd_set_hconv(mode 0) takes the small maps off the halo kernels too: tools that A/B through the setter measure igemm)
   if (kc_forced || (!tile && ctx->kconv_mode && ctx->hconv_mode && p.M <= ctx->kconv_max_m && p.M % (p.H > 0 && p.W > 0 ? p.H * p.W : 1) == 0)) {
     if (cgd_kconv_supported(ctx, p)) {
-      const long tiles = cgd_kconv_tiles_m(p) * (p.N >> 5);
+      const long tiles = cgd_kconv_tiles_m(ctx, p) * (p.N >> 5);
       const int nchunk = p.Cin / 32;
-      if (auto_split && tiles < ctx->num_cu) {
-        long want = std::min<long>(cdiv(ctx->num_cu, tiles), std::max(1, nchunk / ctx->kconv_min_chunks));
+      const long slots = ctx->kconv_slots > 0 ? ctx->kconv_slots : ctx->num_cu;
+      if (auto_split && tiles < slots) {
+        long want = std::min<long>(cdiv(slots, tiles), std::max(1, nchunk / ctx->kconv_min_chunks));
         while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > ctx->ws_bytes) --want;
         if (want >= 2) p.splitk = (int)want;
       }
@@ -752,7 +753,7 @@ extern "C" int cgd_op_plan(int conv, int M, int N, int K, int H, int W, int Cin,
   if (rc != 0) return rc;
   long wg;
   if (kernel == 1) {
-    wg = tile == 516 ? cgd_kconv_tiles_m(p) * (p.N >> 5)
+    wg = tile == 516 ? cgd_kconv_tiles_m(&ctx, p) * (p.N >> 5)
                      : (tile == 515 ? cgd_wconv_tiles_m(&ctx, p) * cdiv(p.N, 128 * cgd_wconv_nc(&ctx, p)) : cgd_hconv_tiles_m(&ctx, p) * cdiv(p.N, 128));
   } else if (kernel == 4) {
     wg = cgd_kgemm_tiles(&ctx, p);

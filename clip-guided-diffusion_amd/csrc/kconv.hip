@@ -33,12 +33,25 @@ typedef float kf32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int KTH = 8;                 // tile rows; the tile is 16 pixels wide
-constexpr int KPW = 18, KHPH = 40, KHRS = 768;  // patch width, pixel pitch, patch-row pitch (bf16 elements): hconv2's layout
-constexpr int KNP = (KTH + 2) * KPW;   // 180 patch rows
-constexpr int KPLANE = (KTH + 2) * KHRS;
-constexpr int KNPASS = 6;              // staging passes: 32 patch rows per pass
+constexpr int KTH = 8;                 // tile rows; the tile is TW = 16 or (round 5) 8 pixels wide
+constexpr int KHPH = 40;               // pixel pitch (bf16 elements): hconv2's layout
 constexpr int KNQ = 5;                 // k-step slots per wavefront and chunk (wavefronts 2 and 3 use 4)
+// Tile geometry.  TW = 16: the 8 x 16-pixel tile of rounds 3-4 (4 pixel blocks of 32 per wavefront, 64 accumulators, ~280 registers: one
+// workgroup per CU).  TW = 8 (round 5): 8 x 8 pixels, 2 pixel blocks per wavefront — half the accumulators and A fragments, ~200 registers and
+// 36 KB of LDS, so TWO workgroups share a CU and one's waits (weight ring, patch staging, barrier) overlap the other's MFMAs; an 8 x 8 map is
+// one full tile instead of a half-empty one; and a map has twice the pixel tiles, so half the split-K slices fill the chip (32 x 32 maps: none).
+// Patch-row pitch: 768 / 448 bf16 elements keep the A-fragment ds_read_b128 conflict-free for 2 x 16 / 4 x 8 pixels per 32 lanes (brute-force
+// check over the instruction's four 16-lane groups).
+template <int TW>
+struct KGeo {
+  static constexpr int PW = TW + 2;                 // patch width
+  static constexpr int HRS = TW == 16 ? 768 : 448;  // patch-row pitch
+  static constexpr int NP = (KTH + 2) * PW;         // patch rows: 180 / 100
+  static constexpr int PLANE = (KTH + 2) * HRS;
+  static constexpr int NPASS = (NP + 31) / 32;      // staging passes of 32 patch rows: 6 / 4
+  static constexpr int NPB = TW * KTH / 32;         // 32-pixel blocks per wavefront: 4 / 2
+  static constexpr int RP = NPB * 4;                // accumulator registers per final part (4 parts, one per wavefront): 16 / 8
+};
 
 struct KConvParams {
   int lda, ldc, ldr;
@@ -58,13 +71,17 @@ __device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) 
   return kf32x4{v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]};
 }
 
-template <int MODE, bool GN>
-__global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
+template <int MODE, bool GN, int TW>
+__global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                     const float* __restrict__ gng, const KConvParams p) {
   constexpr int NPL = MODE == 1 ? 2 : 1;
-  // one array for everything: the patch double buffer, reused for the final cross-wavefront reduction (4 x 3 slabs of 4 KiB = 48 KiB)
-  constexpr int LDS_ELEMS = 2 * NPL * KPLANE > 24576 ? 2 * NPL * KPLANE : 24576;
+  typedef KGeo<TW> G;
+  constexpr int KPW = G::PW, KHRS = G::HRS, KNP = G::NP, KPLANE = G::PLANE, KNPASS = G::NPASS, NPB = G::NPB, RP = G::RP;
+  // one array for everything: the patch double buffer, reused for the final cross-wavefront reduction (4 parts x 3 slabs of RP x 64 floats:
+  // 48 / 24 KiB)
+  constexpr int RED_ELEMS = 4 * 3 * RP * 64 * 2;  // in bf16 elements
+  constexpr int LDS_ELEMS = 2 * NPL * KPLANE > RED_ELEMS ? 2 * NPL * KPLANE : RED_ELEMS;
   __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: k-step offsets and the 5-vs-4 branch are wave-uniform
@@ -79,9 +96,9 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
   // weight-block major within an XCD's run: the pixel tiles that share a 32-channel weight block are neighbours on one XCD
   const int ntm = gridDim.x / nbN;
   const int mt = bid % ntm, nb = bid / ntm;
-  const int tpr = (p.W + 15) >> 4, tpi = (p.H / KTH) * tpr;
+  const int tpr = (p.W + TW - 1) / TW, tpi = (p.H / KTH) * tpr;
   const int img = mt / tpi, trem = mt - img * tpi;
-  const int y0 = (trem / tpr) * KTH, x0 = (trem % tpr) << 4;
+  const int y0 = (trem / tpr) * KTH, x0 = (trem % tpr) * TW;
   const int HW = p.H * p.W;
   const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
   const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
@@ -105,12 +122,12 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
       poff[j] = inb ? (yy * Ws + xx) * p.lda + c4 * 4 : -1;
     }
   }
-  // this lane's pixel in each of the 4 pixel blocks (all wavefronts cover the same 128 pixels)
-  int fro[4];
+  // this lane's pixel in each of the NPB pixel blocks (all wavefronts cover the same 128 / 64 pixels)
+  int fro[NPB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NPB; ++i) {
     const int pix = i * 32 + l31;
-    fro[i] = (pix >> 4) * KHRS + (pix & 15) * KHPH + hh * 8;
+    fro[i] = (pix / TW) * KHRS + (pix % TW) * KHPH + hh * 8;
   }
   // this wavefront's k-steps q = wave + 4 k: LDS offset of (tap, ks) and offset of its fragment pair inside a chunk's weight block
   int aoff[KNQ], boff[KNQ];
@@ -131,9 +148,9 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
   }
   const uint4* __restrict__ Bw0 = Bg + (long)nb * nchunk * (9 * 4 * 64) + lane;
 
-  kf32x16 acc[4];
+  kf32x16 acc[NPB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NPB; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
   }
 #define K_A_LOAD(DST, SRCB, K)                                                                      \
   {                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+    _Pragma("unroll") for (int i = 0; i < NPB; ++i) {                                               \
       DST[i][0] = *(const kbf16x8*)&(SRCB)[fro[i] + aoff[K]];                                       \
       if constexpr (MODE == 1) DST[i][1] = *(const kbf16x8*)&(SRCB)[KPLANE + fro[i] + aoff[K]];    \
     }                                                                                               \
@@ -186,17 +203,17 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
 #define K_MFMA(AQ, BQ)                                                                              \
   {                                                                                                 \
     if constexpr (MODE == 1) {                                                                      \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+      _Pragma("unroll") for (int i = 0; i < NPB; ++i)                                               \
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kbf16x8, BQ[0]), AQ[i][1], acc[i], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+      _Pragma("unroll") for (int i = 0; i < NPB; ++i)                                               \
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kbf16x8, BQ[1]), AQ[i][0], acc[i], 0, 0, 0); \
     }                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+    _Pragma("unroll") for (int i = 0; i < NPB; ++i)                                                 \
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kbf16x8, BQ[0]), AQ[i][0], acc[i], 0, 0, 0); \
   }
     // weight-fragment ring: two sets of KNQ slots; set S holds the chunk being multiplied, the other is filled with the next chunk's
     // fragments meanwhile (one whole chunk of lead: HBM latency under load)
-    kbf16x8 af[2][4][NPL];
+    kbf16x8 af[2][NPB][NPL];
     uint4 bq[2][KNQ][NPL];
     __bf16* const buf0 = lds;
     __bf16* const buf1 = lds + NPL * KPLANE;
@@ -221,8 +238,8 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
       if (k + 1 < KNQ) K_A_LOAD(af[(k + 1) & 1], CUR, k + 1);                                       \
       K_B_LOAD(bq[(S) ^ 1][k], nbp, k);                                                             \
       if (k < 4 || five) K_MFMA(af[k & 1], bq[S][k]);                                               \
-      if (k < 3) K_PATCH_STORE((S) ^ 1, NXT, 2 * k, 2 * k + 2);                                     \
-      _Pragma("unroll") for (int r = 0; r < 12; ++r) {                                              \
+      if (k < KNPASS / 2) K_PATCH_STORE((S) ^ 1, NXT, 2 * k, 2 * k + 2);                            \
+      _Pragma("unroll") for (int r = 0; r < 3 * NPB; ++r) {                                         \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
         if (r % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
         if (r % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                          \
@@ -248,53 +265,58 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
 #undef K_CHUNK
   }
 
-  // ---- cross-wavefront reduction through LDS: wavefront w finishes pixel block w.  Slab (block i, source slot s) = 16 x 64 floats,
-  //      element (r, lane) at r * 64 + lane: conflict-free 4-byte accesses.  The last __syncthreads of the loop (or none, for an empty
-  //      slice) has retired every read of the patch buffers.
+  // ---- cross-wavefront reduction through LDS.  The NPB * 16 accumulator registers of a lane form 4 PARTS of RP registers (16: one pixel block
+  //      each; 8: half a pixel block each = two channel quads); wavefront w finishes part w.  Slab (part, source slot s) = RP x 64 floats, element
+  //      (r, lane) at r * 64 + lane: conflict-free 4-byte accesses.  The last __syncthreads of the loop (or none, for an empty slice) has retired
+  //      every read of the patch buffers.
   float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i != wave) {
-      const int slot = wave - (wave > i ? 1 : 0);
-      float* dst = red + ((i * 3 + slot) * 16) * 64 + lane;
+  for (int pt = 0; pt < 4; ++pt) {
+    if (pt != wave) {
+      const int slot = wave - (wave > pt ? 1 : 0);
+      float* dst = red + ((pt * 3 + slot) * RP) * 64 + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r * 64] = acc[i][r];
+      for (int r = 0; r < RP; ++r) dst[r * 64] = acc[(pt * RP) / 16][(pt * RP) % 16 + r];
     }
   }
   __syncthreads();
-  kf32x16 o;
+  float o[RP];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  for (int r = 0; r < RP; ++r) o[r] = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i == wave) o = acc[i];  // wave-uniform select of this wavefront's own block
+  for (int pt = 0; pt < 4; ++pt)
+    if (pt == wave) {  // wave-uniform select of this wavefront's own part
+#pragma unroll
+      for (int r = 0; r < RP; ++r) o[r] = acc[(pt * RP) / 16][(pt * RP) % 16 + r];
+    }
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    const float* src = red + ((wave * 3 + s) * 16) * 64 + lane;
+    const float* src = red + ((wave * 3 + s) * RP) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] += src[r * 64];
+    for (int r = 0; r < RP; ++r) o[r] += src[r * 64];
   }
 
-  // ---- epilogue for pixel block `wave` (D = W x X^T: column = pixel l31, accumulator quad g = channels 8g + 4hh .. + 3)
-  const int pix = wave * 32 + l31, ty = pix >> 4, tx = pix & 15;
+  // ---- epilogue for part `wave` (D = W x X^T: column = pixel l31 of its pixel block, accumulator quad g = channels 8g + 4hh .. + 3)
+  const int blk = (wave * RP) / 16, g0 = ((wave * RP) % 16) / 4;  // pixel block and first channel quad of the part
+  const int pix = blk * 32 + l31, ty = pix / TW, tx = pix % TW;
   if (x0 + tx >= p.W) return;
   const long mrow = (long)img * HW + (long)(y0 + ty) * p.W + x0 + tx;
   const int cb0 = nb * 32;
   if (p.splitk > 1) {
     float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *(kf32x4*)&ws[mrow * p.N + cb0 + 8 * g + 4 * hh] = kf32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    for (int g = 0; g < RP / 4; ++g)
+      *(kf32x4*)&ws[mrow * p.N + cb0 + 8 * (g0 + g) + 4 * hh] = kf32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
     return;
   }
-  kf32x4 rv[4];
+  kf32x4 rv[RP / 4];
   if (Rg) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) rv[g] = *(const kf32x4*)&Rg[mrow * p.ldr + cb0 + 8 * g + 4 * hh];
+    for (int g = 0; g < RP / 4; ++g) rv[g] = *(const kf32x4*)&Rg[mrow * p.ldr + cb0 + 8 * (g0 + g) + 4 * hh];
   }
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int col = cb0 + 8 * g + 4 * hh;
+  for (int g = 0; g < RP / 4; ++g) {
+    const int col = cb0 + 8 * (g0 + g) + 4 * hh;
     kf32x4 v = kf32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]} * p.alpha;
     if (biasg) v += kf32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
     if (Rg) v += rv[g];
@@ -304,13 +326,17 @@ __global__ __launch_bounds__(256) void kconv_kernel(const float* __restrict__ Ag
 
 }  // namespace
 
-long cgd_kconv_tiles_m(const GemmParams& p) { return (long)(p.M / (p.H * p.W)) * (p.H / KTH) * cdiv(p.W, 16); }
+// tile width of a launch: 8 where the map is a whole number of 8-pixel columns and the variant is on (ctx->kconv_tw8, default), 16 otherwise
+int cgd_kconv_tw(const cgd_ctx* ctx, const GemmParams& p) { return (ctx->kconv_tw8 && !(p.W & 7)) ? 8 : 16; }
+long cgd_kconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p) {
+  return (long)(p.M / (p.H * p.W)) * (p.H / KTH) * cdiv(p.W, cgd_kconv_tw(ctx, p));
+}
 
 // same problems as hconv2 at TH = 8 (cgd_hconv_supported); the caller (cgd_plan_gemm) restricts it to small maps
 bool cgd_kconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
   if (!cgd_hconv_supported(ctx, p)) return false;
   if (p.M % (p.H * p.W)) return false;                                   // whole images only
-  if (cgd_kconv_tiles_m(p) * (p.N >> 5) > (1L << 30)) return false;     // one workgroup per (pixel tile, 32-channel block) in grid.x
+  if (cgd_kconv_tiles_m(ctx, p) * (p.N >> 5) > (1L << 30)) return false;  // one workgroup per (pixel tile, 32-channel block) in grid.x
   return true;
 }
 
@@ -318,14 +344,18 @@ int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   KConvParams p;
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
-  dim3 grid((int)(cgd_kconv_tiles_m(g) * (g.N >> 5)), 1, g.splitk > 1 ? g.splitk : 1);
-#define KC_LAUNCH(M_, GN_) \
-  CGD_LAUNCH((kconv_kernel<M_, GN_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
+  dim3 grid((int)(cgd_kconv_tiles_m(ctx, g) * (g.N >> 5)), 1, g.splitk > 1 ? g.splitk : 1);
+  const int tw = cgd_kconv_tw(ctx, g);
+#define KC_LAUNCH(M_, GN_, TW_) \
+  CGD_LAUNCH((kconv_kernel<M_, GN_, TW_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
+#define KC_TW(M_, GN_) \
+  do { if (tw == 8) KC_LAUNCH(M_, GN_, 8); else KC_LAUNCH(M_, GN_, 16); } while (0)
   if (ctx->precision == CGD_PREC_BF16X3) {
-    if (g.gn_ab) KC_LAUNCH(1, true); else KC_LAUNCH(1, false);
+    if (g.gn_ab) KC_TW(1, true); else KC_TW(1, false);
   } else {
-    if (g.gn_ab) KC_LAUNCH(2, true); else KC_LAUNCH(2, false);
+    if (g.gn_ab) KC_TW(2, true); else KC_TW(2, false);
   }
+#undef KC_TW
 #undef KC_LAUNCH
   return 0;
 }

@@ -99,8 +99,9 @@ def test_dispatch_policy_of_the_contraction_launcher():
     assert conv(256, 256, 512) == (0, (1, 515, 1, 1024))
     assert conv(128, 256, 256) == (0, (1, 515, 1, 256))
     assert conv(64, 512, 512) == (0, (1, 512, 2, 256))
-    assert conv(32, 512, 512) == (0, (1, 516, 2, 256))
-    assert conv(16, 1024, 1024) == (0, (1, 516, 4, 256))
+    # (round 5: 8 x 8-pixel tiles — twice the pixel tiles per map, half the slices: none at 32^2)
+    assert conv(32, 512, 512) == (0, (1, 516, 1, 256))
+    assert conv(16, 1024, 1024) == (0, (1, 516, 2, 256))
     assert conv(8, 1024, 1024) == (0, (1, 516, 8, 256))
     assert conv(256, 256, 256, precision=0) == (0, (0, 1256, 1, 512))  # exact-fp32 mode: the halo kernel is bf16-only
     # weight GEMMs (ViT-B/32 on 16 cutouts = 800 tokens): hgemm with the cached fragment copy; 128-row tiles would leave CUs idle, so
@@ -122,7 +123,8 @@ def test_dispatch_policy_of_the_contraction_launcher():
     # fewer CUs -> fewer slices; argument validation happens before any launch
     assert _plan(handle, conv=1, M=64 * 64, N=512, H=64, W=64, Cin=512, num_cu=256)[1][2] == 2
     assert _plan(handle, conv=1, M=64 * 64, N=512, H=64, W=64, Cin=512, num_cu=64)[1][2] == 1
-    assert _plan(handle, conv=1, M=16 * 16, N=1024, H=16, W=16, Cin=1024, num_cu=64) == (0, (1, 516, 1, 64))
+    assert _plan(handle, conv=1, M=16 * 16, N=1024, H=16, W=16, Cin=1024, num_cu=64) == (0, (1, 516, 1, 128))  # (round 5) 8 x 8-pixel tiles: 4 x 32
+    assert _plan(handle, conv=1, M=32 * 32, N=512, H=32, W=32, Cin=512) == (0, (1, 516, 1, 256))                   # 16 tiles x 16 blocks: no split-K
     assert _plan(handle, M=800, N=768, K=770, weight=1)[0] == -2   # K must be a multiple of 4
     assert _plan(handle, conv=1, M=64 * 64, N=64, H=64, W=64, Cin=48)[0] == -2  # conv Cin must be a multiple of 32
 

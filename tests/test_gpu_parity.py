@@ -59,6 +59,14 @@ def test_conv_weight_streaming_small_map_variant(precision):
         _assert_all(recs)
 
 
+def test_conv_weight_streaming_variant_on_the_8x16_tile(monkeypatch):
+    """CGD_KCONV=1,1024,4,0 keeps kconv_kernel's 8 x 16-pixel tile (rounds 3-4) selectable; the default since round 5 is the 8 x 8 tile
+    (two workgroups per CU), graded by test_conv_weight_streaming_small_map_variant and every UNet test."""
+    monkeypatch.setenv("CGD_KCONV", "1,1024,4,0")
+    _assert_all(pc.check_kconv(1))
+    _assert_all(pc.check_unet("mini", 1))
+
+
 def test_unet_small_maps_on_the_previous_kernels(monkeypatch):
     """CGD_KCONV=0 keeps the round-2 routing (hconv2 / igemm on the <= 32x32 maps) selectable: grade it as well."""
     monkeypatch.setenv("CGD_KCONV", "0")
