@@ -145,8 +145,10 @@ struct cgd_ctx {
   int hgemm_mode = 1, hgemm_min_m = 64, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
                                                                 // igemm's finer tiles win), chunks per split-K slice
   PendingReduce pending;                                       // see SplitSrc
-  int defer_mode = 1;  // deferred split-K reductions: 0 never, 1 when the consumer is a many-workgroup kernel (GroupNorm on > 32x32
-                       // maps), 2 also for the single-launch small-map GroupNorm (32 workgroups: slower, kept for A/B runs)
+  int defer_mode = 2;  // deferred split-K reductions: 0 never, 1 when the consumer is a many-workgroup kernel (GroupNorm on > 32x32
+                       // maps), 2 also for the single-launch small-map GroupNorm (32 workgroups).  Default 2 since round 5: with the slice loads
+                       // of the consumers issued eight at a time and kconv's 8 x 8 tiles halving the slice counts it is 0.04 ms per step ahead of 1
+                       // on two same-box pairs (profiles/r5_ab_kconv_tile_width.txt) and takes 61 reduce launches out of the step (A/B knob CGD_DEFER)
   std::vector<ChanStatsEntry> chanstats;  // see ChanStatsEntry
   std::vector<float*> chanstats_retired;  // record buffers that were outgrown: kept until cgd_chanstats_clear (a kernel in flight may still read them;
                                           // no synchronisation and no hipFree inside a network pass)

@@ -888,8 +888,9 @@ bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p) {
   return ctx->kgemm_mode && p.weight && p.M > 4 && p.M <= ctx->kgemm_max_m && cgd_hgemm_supported(ctx, p) && !p.act_out && !p.act_in && !p.skip_group &&
          p.splitk <= 1 && (long)p.M * p.lda < (1L << 31);
 }
-int cgd_kgemm_ni(const cgd_ctx* ctx, const GemmParams& p) {  // 64-row tiles only where 32-row tiles would exceed two workgroups per CU
-  return (long)cdiv(p.M, 32) * (p.N >> 5) > 2L * ctx->num_cu ? 2 : 1;
+int cgd_kgemm_ni(const cgd_ctx* ctx, const GemmParams& p) {  // 32-row tiles: same-box A/B (profiles/r5_ab_tm96_kgemm.txt) 64-row tiles everywhere
+  (void)p;                                                      // +0.43 ms per step, 32-row tiles everywhere -0.03 against a mixed policy
+  return (ctx->kgemm_var & 1) ? 2 : 1;
 }
 int cgd_kgemm_tiles(const cgd_ctx* ctx, const GemmParams& p) { return cdiv(p.M, 32 * cgd_kgemm_ni(ctx, p)) * (p.N >> 5); }
 
@@ -899,9 +900,8 @@ int cgd_launch_kgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   HGemmParams p = {};
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.K = g.K; p.splitk = 1; p.alpha = g.alpha;
-  int ni = cgd_kgemm_ni(ctx, g);
-  if (ctx->kgemm_var & 1) ni = 2;   // A/B variants (CGD_KGEMM="<mode>,<max rows>,<variant bits>"): bit 0 = 64-row tiles everywhere,
-  if (ctx->kgemm_var & 2) ni = 1;   // bit 1 = 32-row tiles everywhere, bit 2 = deep rings (10 / 6 k-steps instead of 6 / 4)
+  const int ni = cgd_kgemm_ni(ctx, g);  // A/B variants (CGD_KGEMM="<mode>,<max rows>,<variant bits>"): bit 0 = 64-row tiles, bit 2 = deep rings (10 / 6
+                                        // k-steps instead of 6 / 4)
   dim3 grid(cdiv(g.M, 32 * ni) * (g.N >> 5));
   const bool x3 = ctx->precision == CGD_PREC_BF16X3;
   const bool deep = (ctx->kgemm_var & 4) != 0;

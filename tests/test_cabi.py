@@ -114,7 +114,7 @@ def test_dispatch_policy_of_the_contraction_launcher():
     # activations x activations (no persistent weight) stay on the generic kernel; (round 5) weight GEMMs of 5 .. 256 rows — the 8x8- and
     # 16x16-level qkv / proj / skip GEMMs — take the few-row kernel (tile code 518: K split inside the workgroup, ONE slice, no reduce launch)
     assert _plan(handle, M=800, N=768, K=768, weight=0)[1][0] == 0
-    assert _plan(handle, M=256, N=3072, K=1024, weight=1) == (0, (4, 518, 1, 384))   # 8 x 96 32-row tiles would be > 2 per CU: 64-row tiles
+    assert _plan(handle, M=256, N=3072, K=1024, weight=1) == (0, (4, 518, 1, 768))   # 8 row tiles x 96 column blocks
     assert _plan(handle, M=64, N=1024, K=3072, weight=1) == (0, (4, 518, 1, 64))     # was 12 split-K slices + a reduce
     assert _plan(handle, M=257, N=1024, K=1024, weight=1)[1][0] == 2
     assert _plan(handle, M=1, N=1024, K=256, weight=1) == (0, (3, 517, 1, 64))      # M <= 4: the weight-streaming GEMV, no split-K
