@@ -138,6 +138,8 @@ struct cgd_ctx {
                        // and 2 is 0.29 ms SLOWER than 1 — inside a step every launch starts on cold L2s and the longer prologue / hand-over of the
                        // 8-wavefront workgroup costs more than its faster loop gains (A/B knob CGD_HGEMM_KG)
   int kgemm_var = 0;   // A/B variants of kgemm_kernel's launch (cgd_launch_kgemm)
+  int kgemm_big_m = 0, kgemm_big_n = 0;  // kgemm also for GEMMs of up to big_m rows when N <= big_n (the narrow-N linears that hgemm2 splits 2-4 ways);
+                       // 4th / 5th field of CGD_KGEMM
   int kgemm_mode = 1, kgemm_max_m = 256;  // (round 5) weight GEMMs of 5 .. kgemm_max_m rows run on kgemm_kernel (hgemm.hip, tile code 518): K split inside the
                        // workgroup, one slice, no reduce launch (A/B knob CGD_KGEMM="<mode>[,<max rows>]")
   int hgemm_tm96 = 1;  // (round 5) hgemm2 on 96-row tiles where they turn two rounds of 64-row workgroups into one (cgd_hgemm_tile_m; A/B knob CGD_HGEMM_TM96)
