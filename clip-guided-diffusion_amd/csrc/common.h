@@ -110,6 +110,7 @@ struct cgd_ctx {
                         // over the wide tensor); 2: the 6-channel one (head dgrad) too; 0: the round-1 MFMA route (im2col + GEMM) for both
                         // (A/B knob CGD_THIN)
   int kconv_tw8 = 1;    // (round 5) kconv_kernel on 8 x 8-pixel tiles (two workgroups per CU) wherever W is a multiple of 8; 0: the 8 x 16 tile
+  int kconv_ring = 2;   // weight-fragment register sets of kconv_kernel on 8 x 8 tiles: 2 = one chunk ahead, 3 = two chunks ahead (6th field of CGD_KCONV)
   int kconv_slots = 0;  // split-K target of kconv in workgroups (0 = one per CU, the rounds 3-4 policy); A/B knobs, 4th / 5th field of CGD_KCONV
   int kconv_mode = 1, kconv_max_m = 1024, kconv_min_chunks = 4;  // weight-streaming variant of the halo conv (kconv.hip, tile code 516): for
                                           // convs of at most kconv_max_m pixels; split-K slices of at least kconv_min_chunks chunks (A/B knob

@@ -71,7 +71,8 @@ __device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) 
   return kf32x4{v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]};
 }
 
-template <int MODE, bool GN, int TW>
+// WR = weight-fragment register sets: 2 = the next chunk's fragments are fetched while a chunk is multiplied (rounds 3-4), 3 = TWO chunks ahead
+template <int MODE, bool GN, int TW, int WR = 2>
 __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                     const float* __restrict__ gng, const KConvParams p) {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     // weight-fragment ring: two sets of KNQ slots; set S holds the chunk being multiplied, the other is filled with the next chunk's
     // fragments meanwhile (one whole chunk of lead: HBM latency under load)
     kbf16x8 af[2][NPB][NPL];
-    uint4 bq[2][KNQ][NPL];
+    uint4 bq[WR][KNQ][NPL];
     __bf16* const buf0 = lds;
     __bf16* const buf1 = lds + NPL * KPLANE;
     K_PATCH_LOAD(0, c0);
@@ -223,21 +224,27 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
       const uint4* __restrict__ cb = Bw0 + (long)c0 * (9 * 4 * 64);
 #pragma unroll
       for (int k = 0; k < KNQ; ++k) K_B_LOAD(bq[0][k], cb, k);
+      if constexpr (WR == 3) {
+        const uint4* __restrict__ cb1 = Bw0 + (long)(c0 + 1 < c1 ? c0 + 1 : c0) * (9 * 4 * 64);
+#pragma unroll
+        for (int k = 0; k < KNQ; ++k) K_B_LOAD(bq[1][k], cb1, k);
+      }
     }
     K_PATCH_STORE(0, buf0, 0, KNPASS);
     K_PATCH_STORE(1, buf1, 0, KNPASS);
     __syncthreads();
     // chunk C (ring set S, LDS buffer CUR): fetch patch C + 2 into staging set S, write patch C + 1 (staging set S ^ 1, fetched during
     // chunk C - 1; for the first chunk a harmless rewrite of what the prologue stored) into NXT, fetch the fragments of chunk C + 1
-#define K_CHUNK(S, CUR, NXT, C)                                                                     \
+    // (BS = weight set of chunk C = (C - c0) % WR; the fragments of chunk C + WR - 1 go into set (BS + WR - 1) % WR)
+#define K_CHUNK(S, CUR, NXT, C, BS)                                                                 \
   {                                                                                                 \
-    const uint4* __restrict__ nbp = Bw0 + (long)((C) + 1 < c1 ? (C) + 1 : (C)) * (9 * 4 * 64);      \
+    const uint4* __restrict__ nbp = Bw0 + (long)((C) + WR - 1 < c1 ? (C) + WR - 1 : c1 - 1) * (9 * 4 * 64); \
     K_PATCH_LOAD(S, (C) + 2);                                                                       \
     K_A_LOAD(af[0], CUR, 0);                                                                        \
     _Pragma("unroll") for (int k = 0; k < KNQ; ++k) {                                               \
       if (k + 1 < KNQ) K_A_LOAD(af[(k + 1) & 1], CUR, k + 1);                                       \
-      K_B_LOAD(bq[(S) ^ 1][k], nbp, k);                                                             \
-      if (k < 4 || five) K_MFMA(af[k & 1], bq[S][k]);                                               \
+      K_B_LOAD(bq[((BS) + WR - 1) % WR][k], nbp, k);                                                \
+      if (k < 4 || five) K_MFMA(af[k & 1], bq[BS][k]);                                              \
       if (k < KNPASS / 2) K_PATCH_STORE((S) ^ 1, NXT, 2 * k, 2 * k + 2);                            \
       _Pragma("unroll") for (int r = 0; r < 3 * NPB; ++r) {                                         \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
@@ -250,12 +257,16 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     }                                                                                               \
     __syncthreads();                                                                                \
   }
+    // the loop body covers one common period P of the LDS buffer / staging set (2) and the weight set (WR): every index is a compile-time constant
+    constexpr int P = WR == 3 ? 6 : 2;
     int c = c0;
-    for (; c + 1 < c1; c += 2) {
-      K_CHUNK(0, buf0, buf1, c);
-      K_CHUNK(1, buf1, buf0, c + 1);
+    for (; c + P - 1 < c1; c += P) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) K_CHUNK(u & 1, ((u & 1) ? buf1 : buf0), ((u & 1) ? buf0 : buf1), c + u, u % WR);
     }
-    if (c < c1) K_CHUNK(0, buf0, buf1, c);
+#pragma unroll
+    for (int u = 0; u < P - 1; ++u)
+      if (c + u < c1) K_CHUNK(u & 1, ((u & 1) ? buf1 : buf0), ((u & 1) ? buf0 : buf1), c + u, u % WR);
 #undef K_PATCH_LOAD
 #undef K_SILU
 #undef K_PATCH_STORE
@@ -346,11 +357,13 @@ int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   dim3 grid((int)(cgd_kconv_tiles_m(ctx, g) * (g.N >> 5)), 1, g.splitk > 1 ? g.splitk : 1);
   const int tw = cgd_kconv_tw(ctx, g);
-#define KC_LAUNCH(M_, GN_, TW_) \
-  CGD_LAUNCH((kconv_kernel<M_, GN_, TW_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
+#define KC_LAUNCH(M_, GN_, TW_, WR_) \
+  CGD_LAUNCH((kconv_kernel<M_, GN_, TW_, WR_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
 #define KC_TW(M_, GN_) \
-  do { if (tw == 8) KC_LAUNCH(M_, GN_, 8); else KC_LAUNCH(M_, GN_, 16); } while (0)
-  if (ctx->precision == CGD_PREC_BF16X3) {
+  do { if (tw == 8) KC_LAUNCH(M_, GN_, 8, 2); else KC_LAUNCH(M_, GN_, 16, 2); } while (0)
+  if (ctx->precision == CGD_PREC_BF16X3 && tw == 8 && ctx->kconv_ring == 3) {  // weight fragments two chunks ahead (A/B knob, 6th field of CGD_KCONV)
+    if (g.gn_ab) KC_LAUNCH(1, true, 8, 3); else KC_LAUNCH(1, false, 8, 3);
+  } else if (ctx->precision == CGD_PREC_BF16X3) {
     if (g.gn_ab) KC_TW(1, true); else KC_TW(1, false);
   } else {
     if (g.gn_ab) KC_TW(2, true); else KC_TW(2, false);
