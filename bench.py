@@ -28,6 +28,9 @@ Prints ONE JSON line (driver contract) with three extra objects:
   hbm          : GroupNorm(+FiLM+SiLU) forward / backward ops, the HBM-bound kernels north_star names: algorithmic bytes (fwd: read
                  x + write y; bwd: read x, dz [, residual] + write dx) / summed HIP-event duration, against 8 TB/s.
   cpu_baseline : the CPU oracle (plain PyTorch fp32 port of the reference path) timed on the host cores (rank 0, N = 1 only).
+Round 5 adds `precision_modes.f32` (the exact-fp32 MFMA mode of the same workload, a short untimed pass on a second context, so that both
+precision columns are in the driver's record) and `roofline.clock_ghz` / `power_w` (rocm-smi medians over an untimed pass of the step loop:
+the dominant kernel is power-limited, profiles/r5_wconv_power.txt).
 """
 import argparse
 import ctypes as C
@@ -434,7 +437,7 @@ def main():
                     "achieved_gbs": None if kb is None else round(kb / (k_ms / ps * 1e-3) / 1e9, 1),
                     "frac_of_hbm_peak": None if kb is None else round(kb / (k_ms / ps * 1e-3) / 8e12, 4),
                     "kernel_time_share": round(k_ms * 1e-3 / dtp, 4)}
-            roof["other_mfma_kernel"] = {"kernel": "igemm_kernel / hgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / ps,
+            roof["other_mfma_kernel"] = {"kernel": "igemm_kernel / hgemm2_kernel / kgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / ps,
                                          "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
                                          "ms_per_step": round(ig_ms / ps, 3), "kernel_time_share": round(ig_ms * 1e-3 / dtp, 4)}
         else:  # exact-fp32 mode: the halo kernel is bf16-only, every contraction runs in igemm_kernel on v_mfma_f32_32x32x2_f32

@@ -1191,7 +1191,8 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   const bool epi = !src.n && HW > GN_SMALL_HW && !(HW & 127) && (ctx->gn_epi & 1) && cgd_chanstats_find(ctx, x, ldx, (long)B * HW, C, s, &cs);
   ProfRec pr;  // algorithmic HBM bytes of a GroupNorm forward: one read of x, one write of y; statistics only: the read (the
                // figure is the operation's, also when the producer's epilogue has already taken the statistics and the read never happens)
-  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (y ? 8.0 : 4.0) * B * HW * C, s));
+               // a norm that sums split-K slices on the way in also does the work of the reduce launch it replaces: n slice reads + the merged write
+  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, ((y ? 8.0 : 4.0) + (src.n ? 4.0 * src.n : 0.0)) * B * HW * C, s));
   if (epi) {
     ++ctx->gn_record_merges;
     int lg = 0;
@@ -1246,7 +1247,7 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
     src = SplitSrc();
   }
   ProfRec pr;  // algorithmic HBM bytes of a GroupNorm backward: read x and dz (and the residual gradient `add`), write dx
-  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (12.0 + (add ? 4.0 : 0.0) + (add2 ? 4.0 : 0.0)) * B * HW * C, s));
+  CGD_TRY(cgd_prof_begin(ctx, &pr, CGD_PROF_GN, (12.0 + (add ? 4.0 : 0.0) + (add2 ? 4.0 : 0.0) + (src.n ? 4.0 * src.n : 0.0)) * B * HW * C, s));
   if (HW <= GN_SMALL_HW) {
     if (act)
       launch_gn_small_bwd<1>(x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, B, HW, C, stats, coef, s, src);
