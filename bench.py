@@ -352,6 +352,7 @@ def main():
     for _ in range(args.warmup):
         next(steps)
     sync()
+    m0 = int(ctx.lib.cgd_op_gn_record_merges(ctx.h))  # GroupNorm launches that merged conv-epilogue records instead of sweeping their input
     n0 = launch_counts()
     t0, c0 = time.perf_counter(), time.process_time()
     for _ in range(args.steps):
@@ -360,6 +361,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_s = time.process_time() - c0  # CPU seconds (user + sys, all threads of this rank) spent driving the K steps
+    m1 = int(ctx.lib.cgd_op_gn_record_merges(ctx.h))
     n1 = launch_counts()  # kernel launches of the library over the K timed steps (torch's own few elementwise / RNG launches not included)
     finite = bool(th.isfinite(out["sample"]).all().item())
     peak = float(out["sample"].abs().max().item())
@@ -527,6 +529,7 @@ def main():
                                      f"x_t = q_sample(x0*, t={start}) down to t = 0 (init-image prologue, skip_timesteps {N - 1 - start})",
                        "launches_per_step": round((n1[0] - n0[0]) / args.steps, 1),
                        "splitk_reduce_per_step": round((n1[1] - n0[1]) / args.steps, 1),
+                       "groupnorm_record_merges_per_step": round((m1 - m0) / args.steps, 1),
                        "timed_seconds": round(tmax, 3), "last_sample_peak": round(peak, 3),
                        "tflop_per_step": cfg["tflop"], "achieved_tflops_whole_step": round(cfg["tflop"] * args.steps / tmax, 2)},
         }

@@ -281,9 +281,12 @@ struct GemmParams {
 float* cgd_chanstats_register(cgd_ctx* ctx, const float* C, int ldc, int N, long M, hipStream_t s, int kind = 0);
 bool cgd_chanstats_find(cgd_ctx* ctx, const float* x, int ldx, long M, int Cn, hipStream_t s, ChanSrc* out, int kind = 0);
 void cgd_chanstats_clear(cgd_ctx* ctx);
-// a kernel that takes NO records is about to (re)write tensor C: records registered for it in this pass die (a later GroupNorm must
-// never merge sums of a previous content); called by every launcher that writes an activation
-void cgd_chanstats_invalidate(cgd_ctx* ctx, const float* C);
+// a kernel that takes NO records is about to (re)write the tensor C: `rows` rows of `cols` floats at row stride `ld`: every record whose tensor
+// overlaps it dies (a later GroupNorm must never merge sums of a previous content).  Tensors with the same row stride are compared as
+// column rectangles (the two channel halves of a skip-concat buffer do NOT overlap), anything else by its bounding span.  Called by the launchers
+// that write activations: the GEMM / conv family (wconv_kernel re-registers what it takes), pooling / upsampling / copies / activations, the
+// GroupNorm outputs
+void cgd_chanstats_invalidate(cgd_ctx* ctx, const float* C, long rows, int ld, int cols);
 // would the GroupNorm launchers merge epilogue records for a tensor of HW pixels per sample? (the producer registers records only then)
 bool cgd_gn_merges_records(int HW);
 // the one place that maps a CGD_WINO / cgd_set_wino mode to (wino_mode, wino_nc): mode 5 = 8-row tiles with two channel blocks per wavefront

@@ -178,6 +178,7 @@ int cgd_launch_pool2x2(cgd_ctx* ctx, const float* in, int ldi, float* out, int l
                        int Wo, int C, float scale, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (ldi & 3) || (ldo & 3)) CGD_FAIL(ctx, "pool2x2: C and strides must be multiples of 4");
+  cgd_chanstats_invalidate(ctx, out, (long)B * Ho * Wo, ldo, C);
   CGD_LAUNCH(pool2x2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, ldi, out, ldo, add, ldadd, B,
                      Ho, Wo, C, scale);
   CGD_HIP(ctx, hipGetLastError());
@@ -188,6 +189,7 @@ int cgd_launch_upsample2x(cgd_ctx* ctx, const float* in, int ldi, float* out, in
                           int Wo, int C, float scale, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (ldi & 3) || (ldo & 3)) CGD_FAIL(ctx, "upsample2x: C and strides must be multiples of 4");
+  cgd_chanstats_invalidate(ctx, out, (long)B * Ho * Wo, ldo, C);
   CGD_LAUNCH(upsample2x_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, ldi, out, ldo, add, ldadd,
                      B, Ho, Wo, C, scale);
   CGD_HIP(ctx, hipGetLastError());
@@ -198,6 +200,7 @@ int cgd_launch_copy2d(cgd_ctx* ctx, const float* a, int lda, const float* b, int
                       hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((C & 3) || (lda & 3) || (ldo & 3) || (b && (ldb & 3))) CGD_FAIL(ctx, "copy2d: C and strides must be multiples of 4");
+  cgd_chanstats_invalidate(ctx, out, rows, ldo, C);
   CGD_LAUNCH(copy2d_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -207,6 +210,7 @@ int cgd_launch_concat2(cgd_ctx* ctx, const float* a, int lda, int Ca, const floa
                        hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
   if ((Ca & 3) || (Cb & 3) || (lda & 3) || (ldb & 3) || (ldo & 3)) CGD_FAIL(ctx, "concat2: channels and strides must be multiples of 4");
+  cgd_chanstats_invalidate(ctx, out, rows, ldo, Ca + Cb);
   CGD_LAUNCH(concat2_kernel, dim3(grid_for(rows * ((Ca + Cb) / 4))), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, out, ldo, rows);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
@@ -214,12 +218,14 @@ int cgd_launch_concat2(cgd_ctx* ctx, const float* a, int lda, int Ca, const floa
 
 int cgd_launch_act_fwd(cgd_ctx* ctx, const float* x, float* y, long n, int act, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
+  cgd_chanstats_invalidate(ctx, y, 1, (int)(n < (1L << 30) ? n : (1L << 30)), (int)(n < (1L << 30) ? n : (1L << 30)));
   CGD_LAUNCH(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, act);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 int cgd_launch_act_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx, long n, int act, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
+  cgd_chanstats_invalidate(ctx, dx, 1, (int)(n < (1L << 30) ? n : (1L << 30)), (int)(n < (1L << 30) ? n : (1L << 30)));
   CGD_LAUNCH(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, dy, dx, n, act);
   CGD_HIP(ctx, hipGetLastError());
   return 0;

@@ -663,7 +663,7 @@ bool cgd_take_pending(cgd_ctx* ctx, const float* x, long rows, int cols, int ldx
 int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return 0;
   CGD_TRY(cgd_flush_pending(ctx, s));  // a deferred reduction nobody consumed: its slices are about to be overwritten
-  cgd_chanstats_invalidate(ctx, p.C);  // epilogue records of an earlier content of C die here; wconv_kernel re-registers the ones it takes
+  cgd_chanstats_invalidate(ctx, p.C, p.M, p.ldc, p.N);  // epilogue records of an earlier content of C die here; wconv_kernel re-registers the ones it takes
   int tile = 0, kernel = 0;
   CGD_TRY(cgd_plan_gemm(ctx, p, &tile, &kernel));
   const bool use_h = kernel == 1, use_g = kernel == 2;

@@ -1173,6 +1173,7 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
                       const float* beta, const float* film, int ldfilm, int act, float eps, float* scratch, hipStream_t s) {
   if (C % 32 || C > 4096) CGD_FAIL(ctx, "groupnorm: C must be a multiple of 32 and <= 4096");
   if ((ldx & 3) || (y && (ldy & 3))) CGD_FAIL(ctx, "groupnorm: row strides must be multiples of 4");
+  if (y) cgd_chanstats_invalidate(ctx, y, (long)B * HW, ldy, C);
   if (!y) ldy = 4;  // statistics only (y == nullptr): see cgd_gn_ab
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
@@ -1239,6 +1240,7 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
+  cgd_chanstats_invalidate(ctx, dx, (long)B * HW, lddx, C);
   SplitSrc src;  // dz may still lie in split-K slices (the dgrad conv that produced it deferred its reduction)
   if (!((HW > GN_SMALL_HW || ctx->defer_mode >= 2) && cgd_take_pending(ctx, dz, (long)B * HW, C, lddz, s, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
   if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.ws & 15) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15)) && HW > GN_SMALL_HW) {
@@ -1396,9 +1398,23 @@ void cgd_chanstats_clear(cgd_ctx* ctx) {
   ctx->chanstats_retired.clear();
 }
 
-void cgd_chanstats_invalidate(cgd_ctx* ctx, const float* C) {
-  for (ChanStatsEntry& q : ctx->chanstats)
-    if (q.C == C) q.serial = 0;  // serial 0 never matches a pass (stats_serial starts at 1 and only grows)
+void cgd_chanstats_invalidate(cgd_ctx* ctx, const float* C, long rows, int ld, int cols) {
+  if (!C || rows <= 0 || ctx->chanstats.empty()) return;
+  const float* end = C + (rows - 1) * (long)ld + cols;
+  for (ChanStatsEntry& q : ctx->chanstats) {
+    if (q.serial != ctx->stats_serial) continue;  // dead already
+    const float* qend = q.C + (q.M - 1) * (long)q.ldc + q.N;  // the registered tensor: M rows of N floats at stride ldc
+    if (!(q.C < end && C < qend)) continue;  // bounding spans apart
+    if (q.ldc == ld && ld > 0) {
+      // same row stride (a concat buffer and its channel slices): column intervals modulo the stride.  Offset of the record's first column in the
+      // writer's row frame; the bounding spans overlap, so some rows are shared as soon as the column intervals are
+      long d = (q.C - C) % ld;
+      if (d < 0) d += ld;
+      const bool cols_apart = (d >= cols && d + q.N <= ld) ;  // record columns [d, d + N) inside [cols, ld): untouched by the writer
+      if (cols_apart) continue;
+    }
+    q.serial = 0;  // serial 0 never matches a pass (stats_serial starts at 1 and only grows)
+  }
 }
 
 bool cgd_gn_merges_records(int HW) { return HW > GN_SMALL_HW && !(HW & 127); }
