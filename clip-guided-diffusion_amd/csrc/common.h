@@ -138,6 +138,8 @@ struct cgd_ctx {
                        // launch 17.9 -> 16.1 us with warm caches), 2 = wherever K allows.  Step-level A/B (profiles/r4_hgemm_kgroups.txt): 0 is 0.055 ms
                        // and 2 is 0.29 ms SLOWER than 1 — inside a step every launch starts on cold L2s and the longer prologue / hand-over of the
                        // 8-wavefront workgroup costs more than its faster loop gains (A/B knob CGD_HGEMM_KG)
+  int weight_nt = 0;   // bit 0: kconv_kernel on single-tile maps (8x8), bit 1: kgemm_kernel at M <= 64, bit 2: gemv_kernel — weight loads with the nt policy
+                       // (A/B knob CGD_NT)
   int kgemm_var = 0;   // A/B variants of kgemm_kernel's launch (cgd_launch_kgemm)
   int kgemm_big_m = 0, kgemm_big_n = 0;  // kgemm also for GEMMs of up to big_m rows when N <= big_n (the narrow-N linears that hgemm2 splits 2-4 ways);
                        // 4th / 5th field of CGD_KGEMM
@@ -224,6 +226,14 @@ void cgd_prof_push(cgd_ctx* ctx, ProfRec* pr);
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// 16-byte load with the non-temporal ("nt") cache policy: for packed weights that exactly ONE workgroup reads once per pass (the 8x8-level convs, the
+// few-row GEMMs, the embedding GEMV): the line is not kept for a reuse that never comes (MI355X_MICROARCH.md "nt-weights"; A/B knob CGD_NT)
+typedef unsigned cgd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 cgd_load_nt(const uint4* p) {
+  const cgd_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const cgd_u32x4*>(p));
+  return uint4{v.x, v.y, v.z, v.w};
+}
 
 // ---- GEMM / implicit-GEMM conv ---------------------------------------------------------------
 // C[M][N] = alpha * sum_k A[m][k] * B[n][k] (+ bias[n]) (+ R[m][n]);  A and B are K-contiguous fp32.

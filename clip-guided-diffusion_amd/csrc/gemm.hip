@@ -333,7 +333,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 template <int MR>
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                    float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ R,
-                                                   int ldr, int N, int K, float alpha) {
+                                                   int ldr, int N, int K, float alpha, int nt) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [MR][K]
   for (int i = threadIdx.x; i < MR * K; i += 256) xs[i] = A[(long)(i / K) * lda + (i % K)];
   __syncthreads();
@@ -351,7 +351,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ A, 
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         const long n = n0 + r < N ? n0 + r : N - 1;  // clamped: the loads stay unconditional
-        w[r] = *(const float4*)(B + n * ldb + k0);
+        if (nt) {
+          const uint4 u = cgd_load_nt((const uint4*)(B + n * ldb + k0));
+          w[r] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        } else {
+          w[r] = *(const float4*)(B + n * ldb + k0);
+        }
       }
 #pragma unroll
       for (int m = 0; m < MR; ++m) {
@@ -677,7 +682,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (kernel == 3) {
     const int blocks = (int)std::min<long>(std::max<long>(cdiv(p.N, 16), 1), 4L * ctx->num_cu);
     const size_t sh = (size_t)p.M * p.K * sizeof(float);
-#define GV_LAUNCH(MR_) CGD_LAUNCH((gemv_kernel<MR_>), dim3(blocks), dim3(256), sh, s, p.A, p.lda, p.B, p.ldb, p.C, p.ldc, p.bias, p.R, p.ldr, p.N, p.K, p.alpha)
+#define GV_LAUNCH(MR_) CGD_LAUNCH((gemv_kernel<MR_>), dim3(blocks), dim3(256), sh, s, p.A, p.lda, p.B, p.ldb, p.C, p.ldc, p.bias, p.R, p.ldr, p.N, p.K, p.alpha, (ctx->weight_nt & 4) ? 1 : 0)
     switch (p.M) {
       case 1: GV_LAUNCH(1); break;
       case 2: GV_LAUNCH(2); break;

@@ -69,6 +69,7 @@ struct HGemmParams {
   int ld_act, act;
   int lep;         // hgemm2, bf16x3: 1 = output block through LDS, whole-line stores / operand reads (ctx->hgemm_epi)
   int skip_group;  // hgemm2, one slice: drop the first row of every group of this many rows, write the rest compactly (GemmParams)
+  int nt;      // kgemm_kernel: weight-fragment loads with the non-temporal policy
   int nmajor;  // tile order within the XCD-contiguous runs: 0 = M-tile major (an XCD owns row panels and streams all weights),
                // 1 = N-tile major (an XCD owns weight column panels, read from HBM once and kept in its 4 MB L2; the small
                // activation matrix is what every XCD re-reads): chosen when the weights are the larger operand (N >= M)
@@ -744,8 +745,8 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const float* __restrict__ Ag
   {                                                                                               \
     const int t_ = (T) < mine ? (T) : mine - 1; /* clamped: the loads stay unconditional */       \
     const int kq_ = w + 4 * t_;                                                                   \
-    bq[SLOT][0] = Bw[(long)kq_ * 128];                                                            \
-    if constexpr (MODE == 1) bq[SLOT][1] = Bw[(long)kq_ * 128 + 64];                              \
+    bq[SLOT][0] = p.nt ? cgd_load_nt(Bw + (long)kq_ * 128) : Bw[(long)kq_ * 128];                 \
+    if constexpr (MODE == 1) bq[SLOT][1] = p.nt ? cgd_load_nt(Bw + (long)kq_ * 128 + 64) : Bw[(long)kq_ * 128 + 64]; \
     _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
       aq[SLOT][i][0] = *(const f32x4*)(Ag + arow[i] + 16 * kq_);                                  \
       aq[SLOT][i][1] = *(const f32x4*)(Ag + arow[i] + 16 * kq_ + 4);                              \
@@ -901,6 +902,7 @@ int cgd_launch_kgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   HGemmParams p = {};
   p.lda = g.lda; p.ldc = g.ldc; p.ldr = g.ldr;
   p.M = g.M; p.N = g.N; p.K = g.K; p.splitk = 1; p.alpha = g.alpha;
+  p.nt = ((ctx->weight_nt & 2) && g.M <= 64) ? 1 : 0;
   const int ni = cgd_kgemm_ni(ctx, g);  // A/B variants (CGD_KGEMM="<mode>,<max rows>,<variant bits>"): bit 0 = 64-row tiles, bit 2 = deep rings (10 / 6
                                         // k-steps instead of 6 / 4)
   dim3 grid(cdiv(g.M, 32 * ni) * (g.N >> 5));

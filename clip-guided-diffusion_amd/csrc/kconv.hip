@@ -72,7 +72,8 @@ __device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) 
 }
 
 // WR = weight-fragment register sets: 2 = the next chunk's fragments are fetched while a chunk is multiplied (rounds 3-4), 3 = TWO chunks ahead
-template <int MODE, bool GN, int TW, int WR = 2>
+// NT = weight-fragment loads with the non-temporal policy (single-tile maps: every fragment is read by exactly one workgroup)
+template <int MODE, bool GN, int TW, int WR = 2, bool NT = false>
 __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                     const float* __restrict__ gng, const KConvParams p) {
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
 #define K_B_LOAD(DST, BASE, K)                                                                      \
   {                                                                                                 \
     const uint4* bp_ = (BASE) + boff[K];                                                            \
-    DST[0] = bp_[0];                                                                                \
-    if constexpr (MODE == 1) DST[1] = bp_[64];                                                      \
+    DST[0] = NT ? cgd_load_nt(bp_) : bp_[0];                                                        \
+    if constexpr (MODE == 1) DST[1] = NT ? cgd_load_nt(bp_ + 64) : bp_[64];                         \
   }
 #define K_MFMA(AQ, BQ)                                                                              \
   {                                                                                                 \
@@ -361,7 +362,10 @@ int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   CGD_LAUNCH((kconv_kernel<M_, GN_, TW_, WR_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
 #define KC_TW(M_, GN_) \
   do { if (tw == 8) KC_LAUNCH(M_, GN_, 8, 2); else KC_LAUNCH(M_, GN_, 16, 2); } while (0)
-  if (ctx->precision == CGD_PREC_BF16X3 && tw == 8 && ctx->kconv_ring == 3) {  // weight fragments two chunks ahead (A/B knob, 6th field of CGD_KCONV)
+  if (ctx->precision == CGD_PREC_BF16X3 && tw == 8 && (ctx->weight_nt & 1) && cgd_kconv_tiles_m(ctx, g) == 1) {
+    if (g.gn_ab) CGD_LAUNCH((kconv_kernel<1, true, 8, 2, true>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p);
+    else CGD_LAUNCH((kconv_kernel<1, false, 8, 2, true>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p);
+  } else if (ctx->precision == CGD_PREC_BF16X3 && tw == 8 && ctx->kconv_ring == 3) {  // weight fragments two chunks ahead (A/B knob, 6th field of CGD_KCONV)
     if (g.gn_ab) KC_LAUNCH(1, true, 8, 3); else KC_LAUNCH(1, false, 8, 3);
   } else if (ctx->precision == CGD_PREC_BF16X3) {
     if (g.gn_ab) KC_TW(1, true); else KC_TW(1, false);
