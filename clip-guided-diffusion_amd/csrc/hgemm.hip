@@ -887,6 +887,7 @@ int cgd_hgemm_chunks(const GemmParams& p) { return p.K / GK; }
 // kgemm_kernel takes persistent-weight GEMMs of 5 .. kgemm_max_m rows in one slice, without the epilogue options only hgemm2 has
 bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p) {
   const bool rows_ok = p.M <= ctx->kgemm_max_m || (p.M <= ctx->kgemm_big_m && p.N <= ctx->kgemm_big_n);
+  if ((uintptr_t)p.bias & 15) return false;  // the epilogue reads the bias 16 bytes at a time
   return ctx->kgemm_mode && p.weight && p.M > 4 && rows_ok && cgd_hgemm_supported(ctx, p) && !p.act_out && !p.act_in && !p.skip_group &&
          p.splitk <= 1 && (long)p.M * p.lda < (1L << 31);
 }
