@@ -888,6 +888,7 @@ int cgd_hgemm_chunks(const GemmParams& p) { return p.K / GK; }
 bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p) {
   const bool rows_ok = p.M <= ctx->kgemm_max_m || (p.M <= ctx->kgemm_big_m && p.N <= ctx->kgemm_big_n);
   if ((uintptr_t)p.bias & 15) return false;  // the epilogue reads the bias 16 bytes at a time
+  if (ctx->kgemm_mode == 2 && p.defer && ctx->defer_mode >= 2) return false;  // mode 2: a GEMM whose split-K slices its consumer would sum anyway stays on hgemm2
   return ctx->kgemm_mode && p.weight && p.M > 4 && rows_ok && cgd_hgemm_supported(ctx, p) && !p.act_out && !p.act_in && !p.skip_group &&
          p.splitk <= 1 && (long)p.M * p.lda < (1L << 31);
 }
