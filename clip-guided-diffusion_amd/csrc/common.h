@@ -143,8 +143,11 @@ struct cgd_ctx {
   int kgemm_var = 0;   // A/B variants of kgemm_kernel's launch (cgd_launch_kgemm)
   int kgemm_big_m = 0, kgemm_big_n = 0;  // kgemm also for GEMMs of up to big_m rows when N <= big_n (the narrow-N linears that hgemm2 splits 2-4 ways);
                        // 4th / 5th field of CGD_KGEMM
-  int kgemm_mode = 1, kgemm_max_m = 256;  // (round 5) weight GEMMs of 5 .. kgemm_max_m rows run on kgemm_kernel (hgemm.hip, tile code 518): K split inside the
-                       // workgroup, one slice, no reduce launch (A/B knob CGD_KGEMM="<mode>[,<max rows>]")
+  int kgemm_mode = 2, kgemm_max_m = 256;  // (round 5) weight GEMMs of 5 .. kgemm_max_m rows run on kgemm_kernel (hgemm.hip, tile code 518): K split inside the
+                       // workgroup, one slice, no reduce launch.  Mode 2 (default): only the GEMMs whose split-K slices no consumer would sum anyway
+                       // (qkv forward, proj_out backward, 1x1 skips; with CGD_DEFER=2 the others cost no reduce launch on hgemm2 and are faster there:
+                       // -0.04 ms per step, profiles/r5_ab_kgemm_modes_with_defer2.txt); 1: every eligible GEMM; 0: off
+                       // (A/B knob CGD_KGEMM="<mode>[,<max rows>[,<variant bits>[,<big rows>,<big N>]]]")
   int hgemm_tm96 = 1;  // (round 5) hgemm2 on 96-row tiles where they turn two rounds of 64-row workgroups into one (cgd_hgemm_tile_m; A/B knob CGD_HGEMM_TM96)
   int hgemm_var = 1;   // weight GEMM kernel variant (hgemm.hip cgd_hgemm_tile_m): 0 hgemm_kernel, 1 hgemm2 auto tile, 2 / 3 hgemm2 128 / 64 rows
   int hgemm_mode = 1, hgemm_min_m = 64, hgemm_min_chunks = 4;  // weight GEMM kernel (hgemm.hip): on/off, smallest M (below it
