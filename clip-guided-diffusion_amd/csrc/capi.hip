@@ -39,7 +39,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_HGEMM_VAR")) ctx->hgemm_var = atoi(e);
   if (const char* e = getenv("CGD_HGEMM_EPI")) ctx->hgemm_epi = atoi(e);
   if (const char* e = getenv("CGD_TILE_ORDER")) ctx->tile_order = atoi(e);
-  if (const char* e = getenv("CGD_FUSE_GN")) sscanf(e, "%d,%d,%d", &ctx->fuse_gn, &ctx->fuse_gn_max_m, &ctx->fuse_gn_min_m);
+  if (const char* e = getenv("CGD_FUSE_GN")) sscanf(e, "%d,%d,%d,%d", &ctx->fuse_gn, &ctx->fuse_gn_max_m, &ctx->fuse_gn_min_m, &ctx->fuse_gn_skip_m);
   if (const char* e = getenv("CGD_FUSE_ACT")) ctx->fuse_act = atoi(e);
   if (const char* e = getenv("CGD_HCONV_W8")) ctx->hconv_w8 = atoi(e);
   if (const char* e = getenv("CGD_ATTN_X3")) ctx->attn_x3 = atoi(e);

@@ -127,6 +127,7 @@ struct cgd_ctx {
   int attn_flash = 1;  // 1 (round 5): d = 64, T > 64 attention in bf16x3 contexts runs on the kernels of attn_flash.hip (online softmax, no materialised
                        // P / dS, backward recomputes P from the saved row statistics); 0 = attn_mid_* of attn.hip (A/B knob CGD_ATTN_FLASH)
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
+  int fuse_gn_skip_m = 0;  // A/B: convs of exactly this many pixels read a materialised normalised tensor instead (4th field of CGD_FUSE_GN)
   int fuse_gn_max_m = 1 << 30, fuse_gn_min_m = 0;  // ... only for convs of at most / at least this many pixels (A/B knob,
                                                    // CGD_FUSE_GN="1,<max pixels>,<min pixels>")
   int fuse_gn = 1;     // 1: ResBlock convs on the halo kernel apply their GroupNorm + FiLM + SiLU while staging (A/B knob)

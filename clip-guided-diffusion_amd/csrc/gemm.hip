@@ -621,7 +621,7 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out);
 bool cgd_conv_uses_hconv(cgd_ctx* ctx, GemmParams p) {
   int tile = 0, kernel = 0;
   const std::string keep = ctx->err;
-  const bool ok = p.conv && ctx->fuse_gn && p.M <= ctx->fuse_gn_max_m && p.M >= ctx->fuse_gn_min_m && cgd_plan_gemm(ctx, p, &tile, &kernel) == 0 && kernel == 1;
+  const bool ok = p.conv && ctx->fuse_gn && p.M <= ctx->fuse_gn_max_m && p.M >= ctx->fuse_gn_min_m && (ctx->fuse_gn_skip_m <= 0 || p.M != ctx->fuse_gn_skip_m) && cgd_plan_gemm(ctx, p, &tile, &kernel) == 0 && kernel == 1;
   ctx->err = keep;
   return ok;
 }
