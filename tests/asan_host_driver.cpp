@@ -103,6 +103,7 @@ int main() {
               const int rc = cgd_op_plan(1, s * s, co, 0, s, s, ci, 1, prec, cu, out4);
               EXPECT(rc == 0 && out4[2] >= 1 && out4[3] >= 1);
               if (prec == 1 && s <= 32) EXPECT(out4[1] == 516);  // weight-streaming kernel on the small maps
+              if (prec == 1 && s == 32 && cu <= 256 && co >= 512) EXPECT(out4[2] == 1);  // (round 5) 8 x 8-pixel tiles: 16 x Cout / 32 >= 256 workgroups, no split-K
             }
     for (int M : {1, 50, 64, 256, 800, 4096, 65536})
       for (int N : {32, 768, 2304, 3072})
@@ -110,6 +111,8 @@ int main() {
           EXPECT(cgd_op_plan(0, M, N, K, 0, 0, 0, 1, 1, 256, out4) == 0);
           EXPECT(cgd_op_plan(0, M, N, K, 0, 0, 0, 0, 0, 256, out4) == 0);
         }
+    EXPECT(cgd_op_plan(0, 64, 1024, 3072, 0, 0, 0, 1, 1, 256, out4) == 0 && out4[0] == 4 && out4[1] == 518 && out4[2] == 1);  // (round 5) few-row weight GEMM: one slice
+    EXPECT(cgd_op_plan(0, 800, 3072, 768, 0, 0, 0, 1, 1, 256, out4) == 0 && out4[3] == 216);                                 // 96-row hgemm2 tiles: 9 x 24
     EXPECT(cgd_op_plan(0, 800, 768, 770, 0, 0, 0, 1, 1, 256, out4) == -2);   // K not a multiple of 4
     EXPECT(cgd_op_plan(1, 4096, 64, 0, 64, 64, 48, 1, 1, 256, out4) == -2);  // conv Cin not a multiple of 32
     EXPECT(cgd_op_plan(0, 800, 768, 768, 0, 0, 0, 1, 1, 256, nullptr) == -3);
@@ -125,6 +128,10 @@ int main() {
     EXPECT(cgd_ctx_create(nullptr, 0) == -3);
     cgd_ctx_destroy(nullptr);
     EXPECT(cgd_set_precision(nullptr, 1) == -3);
+    EXPECT(cgd_op_new_pass(nullptr) == -3);  // round-5 test-support entry points
+    EXPECT(cgd_op_gn_record_merges(nullptr) == -3);
+    EXPECT(cgd_op_gn_stats_offset(2, 4096, 192) == 2 * 256 * 64);
+    EXPECT(cgd_op_conv3x3_wino_ex(nullptr, nullptr, 32, nullptr, nullptr, 32, nullptr, nullptr, 0, nullptr, 1, 16, 16, 32, 32, 0, 1, nullptr, 0, nullptr, nullptr) == -3);
     EXPECT(cgd_profile(nullptr, 1) == -3);
     double buf[18];  // 3 * cgd_profile_kinds()
     EXPECT(cgd_profile_read(nullptr, buf) == -3);

@@ -57,6 +57,12 @@ def test_null_handles_are_rejected_not_dereferenced():
     assert handle.cgd_set_wino(None, 1, 0) == -3
     assert handle.cgd_op_pack_conv3x3_wino(None, None, None, 32, 32, 0, None) == -3
     assert handle.cgd_op_conv3x3_wino(None, None, 32, None, None, 32, None, None, 0, None, 1, 16, 16, 32, 32, 0, None) == -3
+    # round-5 test-support entry points (conv-epilogue GroupNorm records)
+    assert handle.cgd_op_conv3x3_wino_ex(None, None, 32, None, None, 32, None, None, 0, None, 1, 16, 16, 32, 32, 0, 1, None, 0, None, None) == -3
+    assert handle.cgd_op_new_pass(None) == -3
+    assert handle.cgd_op_gn_record_merges(None) == -3
+    # host-only layout query: {mean, rstd} pairs sit behind the per-chunk partials of the scratch (B * ceil(HW / chunk) * 64 floats)
+    assert handle.cgd_op_gn_stats_offset(2, 4096, 192) == 2 * 256 * 64 and handle.cgd_op_gn_stats_offset(1, 64, 1024) == 8 * 64
     assert handle.cgd_last_error(None) == b"null context"
     for net in ("unet", "vit", "rn", "lpips"):
         assert getattr(handle, f"cgd_{net}_num_params")(None) == -3
