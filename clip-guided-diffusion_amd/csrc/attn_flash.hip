@@ -468,6 +468,170 @@ __global__ __launch_bounds__(256) void attn_flash_bwd_dkv_kernel(const float* __
   }
 }
 
+// ---- T <= 64 (CLIP ViT-B/32: 50 tokens; the UNet's 8x8 level): the whole backward of a (sequence, head) in ONE workgroup (CGD_ATTN_FLASH=3) ----------
+// Wavefront (qi, kj) owns the 32-query block qi against the 32-key block kj.  All eight 32-row blocks (Q, K, V, dO x 2) are staged once (two per
+// wavefront, natural and / or transposed hi / lo planes), then each wavefront computes BOTH orientations of its score tile from LDS: S^T (query in the
+// lane: P^T / dS^T registers feed dQ^T += K^T dS^T) and S (key in the lane: P / dS registers feed dV^T += dO^T P and dK^T += Q^T dS) — 84 MFMAs, no
+// barrier in between; the partial dQ (over kj) and dK / dV (over qi) meet in LDS.  Needs the forward's LSE (attn_flash_fwd_kernel) and writes D itself.
+constexpr int FA_SM_Q = 0;                                        // [2 blocks][natural | transposed]
+constexpr int FA_SM_BLK = 2 * FA_NPLANE + 2 * FA_TPLANE;          // natural + transposed images of one block
+constexpr int FA_SM_K = FA_SM_Q + 2 * FA_SM_BLK;
+constexpr int FA_SM_G = FA_SM_K + 2 * FA_SM_BLK;
+constexpr int FA_SM_V = FA_SM_G + 2 * FA_SM_BLK;                  // natural only
+constexpr int FA_SM_ELEMS = FA_SM_V + 2 * (2 * FA_NPLANE);
+static_assert(FA_SM_ELEMS * 2 >= 4 * 3 * 32 * FA_OP * 4, "small-T merge slabs must fit the staging area");
+
+__global__ __launch_bounds__(256) void attn_flash_bwd_small_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dout, int lddo,
+                                                                   const float* __restrict__ Ocopy, const float* __restrict__ lse,
+                                                                   float* __restrict__ Dbuf, float* __restrict__ dqkv, int lddq, int T, int Tq,
+                                                                   int H, long qo, long ko, long vo, long step, float alpha) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[FA_SM_ELEMS];
+  __shared__ __attribute__((aligned(16))) float Dsh[64], Lsh[64];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x, n = blockIdx.y;
+  const float* __restrict__ base = qkv + (long)n * T * ldq + h * step;
+  const float* __restrict__ dob = dout + (long)n * T * lddo + h * 64;
+  {  // D = rowsum(dO * O) and the forward's LSE of the 64 (padded) queries
+    const int q = tid >> 2, seg = tid & 3;
+    const bool rok = q < T;
+    const long t = (long)n * T + (rok ? q : 0);
+    const float* o = Ocopy + t * ((long)H * 64) + h * 64 + seg * 16;
+    const float* g = dob + (long)(rok ? q : 0) * lddo + seg * 16;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const fa_f32x4 ov = *(const fa_f32x4*)(o + 4 * i), gv = *(const fa_f32x4*)(g + 4 * i);
+      a += ov[0] * gv[0] + ov[1] * gv[1] + ov[2] * gv[2] + ov[3] * gv[3];
+    }
+    if (!rok) a = 0.f;
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (seg == 0) {  // (the statistics rows of a (sequence, head) are Tq = 32 or 64 long)
+      Dsh[q] = a;
+      if (q < Tq) Dbuf[((long)n * H + h) * Tq + q] = a;
+      Lsh[q] = q < Tq ? lse[((long)n * H + h) * Tq + q] : INFINITY;  // +inf for rows >= T
+    }
+  }
+  {  // staging: wavefront 0: Q0, V0; 1: Q1, V1; 2: K0, dO0; 3: K1, dO1
+    const int blk = w & 1;
+    fa_f32x4 ra[8], rb[8];
+    const float* pa = (w < 2 ? base + qo : base + ko) + (long)blk * 32 * ldq;
+    const float* pb = w < 2 ? base + vo + (long)blk * 32 * ldq : dob + (long)blk * 32 * lddo;
+    if (T - blk * 32 > 0) {
+      fa_gload(ra, pa, ldq, T - blk * 32, lane);
+      fa_gload(rb, pb, w < 2 ? ldq : lddo, T - blk * 32, lane);
+    } else {  // T <= 32: the second row block does not exist (its base address lies beyond the sequence): zeros
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ra[i] = rb[i] = fa_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __bf16* ia = lds + (w < 2 ? FA_SM_Q : FA_SM_K) + blk * FA_SM_BLK;
+    const float sa = w < 2 ? alpha : 1.f;  // Q is staged pre-scaled: S = (alpha Q) K^T, dK = dS^T (alpha Q)
+    fa_store_nat(ia, ia + FA_NPLANE, ra, sa, lane);
+    fa_store_tr(ia + 2 * FA_NPLANE, ia + 2 * FA_NPLANE + FA_TPLANE, ra, sa, lane);
+    if (w < 2) {
+      __bf16* iv = lds + FA_SM_V + blk * (2 * FA_NPLANE);
+      fa_store_nat(iv, iv + FA_NPLANE, rb, 1.f, lane);
+    } else {
+      __bf16* ig = lds + FA_SM_G + blk * FA_SM_BLK;
+      fa_store_nat(ig, ig + FA_NPLANE, rb, 1.f, lane);
+      fa_store_tr(ig + 2 * FA_NPLANE, ig + 2 * FA_NPLANE + FA_TPLANE, rb, 1.f, lane);
+    }
+  }
+  __syncthreads();
+  const int qi = w >> 1, kj = w & 1;
+  const __bf16* Qn = lds + FA_SM_Q + qi * FA_SM_BLK;
+  const __bf16* Qt = Qn + 2 * FA_NPLANE;
+  const __bf16* Kn = lds + FA_SM_K + kj * FA_SM_BLK;
+  const __bf16* Kt = Kn + 2 * FA_NPLANE;
+  const __bf16* Gn = lds + FA_SM_G + qi * FA_SM_BLK;
+  const __bf16* Gt = Gn + 2 * FA_NPLANE;
+  const __bf16* Vn = lds + FA_SM_V + kj * (2 * FA_NPLANE);
+  fa_f32x16 dq[2], dv[2], dk[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[t][e] = dv[t][e] = dk[t][e] = 0.f;
+  {  // query in the lane: dQ^T += K^T dS^T
+    fa_f32x16 st, dpt;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = dpt[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fa_mma3(st, fa_frag_nat(Kn, l31, hh, s), fa_frag_nat(Kn + FA_NPLANE, l31, hh, s), fa_frag_nat(Qn, l31, hh, s), fa_frag_nat(Qn + FA_NPLANE, l31, hh, s));
+      fa_mma3(dpt, fa_frag_nat(Vn, l31, hh, s), fa_frag_nat(Vn + FA_NPLANE, l31, hh, s), fa_frag_nat(Gn, l31, hh, s), fa_frag_nat(Gn + FA_NPLANE, l31, hh, s));
+    }
+    const float lq = Lsh[qi * 32 + l31], Dq = Dsh[qi * 32 + l31];
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kj * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float p = key < T ? __expf(st[r] - lq) : 0.f;
+      ds[r] = p * (dpt[r] - Dq);
+    }
+    fa_bf16x8 dh[2], dl[2];
+    fa_split_acc(ds, dh, dl);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fa_mma3(dq[t], fa_frag_tr(Kt, l31, hh, t, j), fa_frag_tr(Kt + FA_TPLANE, l31, hh, t, j), dh[j], dl[j]);
+  }
+  {  // key in the lane: dV^T += dO^T P, dK^T += Q^T dS
+    fa_f32x16 sa, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sa[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fa_mma3(sa, fa_frag_nat(Qn, l31, hh, s), fa_frag_nat(Qn + FA_NPLANE, l31, hh, s), fa_frag_nat(Kn, l31, hh, s), fa_frag_nat(Kn + FA_NPLANE, l31, hh, s));
+      fa_mma3(dp, fa_frag_nat(Gn, l31, hh, s), fa_frag_nat(Gn + FA_NPLANE, l31, hh, s), fa_frag_nat(Vn, l31, hh, s), fa_frag_nat(Vn + FA_NPLANE, l31, hh, s));
+    }
+    float p[16], ds[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const fa_f32x4 lr = *(const fa_f32x4*)&Lsh[qi * 32 + 8 * g + 4 * hh], dr = *(const fa_f32x4*)&Dsh[qi * 32 + 8 * g + 4 * hh];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p[4 * g + e] = __expf(sa[4 * g + e] - lr[e]);  // query rows >= T: exp(-inf) = 0
+        ds[4 * g + e] = p[4 * g + e] * (dp[4 * g + e] - dr[e]);
+      }
+    }
+    fa_bf16x8 ph[2], pl[2], dh[2], dl[2];
+    fa_split_acc(p, ph, pl);
+    fa_split_acc(ds, dh, dl);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        fa_mma3(dv[t], fa_frag_tr(Gt, l31, hh, t, j), fa_frag_tr(Gt + FA_TPLANE, l31, hh, t, j), ph[j], pl[j]);
+        fa_mma3(dk[t], fa_frag_tr(Qt, l31, hh, t, j), fa_frag_tr(Qt + FA_TPLANE, l31, hh, t, j), dh[j], dl[j]);
+      }
+  }
+  __syncthreads();  // every wavefront has read its last fragments: the staging area becomes the merge slabs
+  float* const slab = reinterpret_cast<float*>(lds) + w * (3 * 32 * FA_OP);
+  fa_park(slab, dq, l31, hh);
+  fa_park(slab + 32 * FA_OP, dv, l31, hh);
+  fa_park(slab + 2 * 32 * FA_OP, dk, l31, hh);
+  __syncthreads();
+  const int row = tid >> 2, dc = (tid & 3) * 16, b = row >> 5, r = row & 31;
+  if (row >= T) return;
+  const float* sl = reinterpret_cast<const float*>(lds);
+  float* dst = dqkv + ((long)n * T + row) * lddq + h * step;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = dc + 4 * i;
+    // dQ of query block b: wavefronts (b, 0) and (b, 1); dV / dK of key block b: wavefronts (0, b) and (1, b)
+    const fa_f32x4 q0 = *(const fa_f32x4*)&sl[(2 * b + 0) * (3 * 32 * FA_OP) + r * FA_OP + c];
+    const fa_f32x4 q1 = *(const fa_f32x4*)&sl[(2 * b + 1) * (3 * 32 * FA_OP) + r * FA_OP + c];
+    const fa_f32x4 v0 = *(const fa_f32x4*)&sl[(0 + b) * (3 * 32 * FA_OP) + 32 * FA_OP + r * FA_OP + c];
+    const fa_f32x4 v1 = *(const fa_f32x4*)&sl[(2 + b) * (3 * 32 * FA_OP) + 32 * FA_OP + r * FA_OP + c];
+    const fa_f32x4 k0 = *(const fa_f32x4*)&sl[(0 + b) * (3 * 32 * FA_OP) + 2 * 32 * FA_OP + r * FA_OP + c];
+    const fa_f32x4 k1 = *(const fa_f32x4*)&sl[(2 + b) * (3 * 32 * FA_OP) + 2 * 32 * FA_OP + r * FA_OP + c];
+    *(fa_f32x4*)(dst + qo + c) = (q0 + q1) * alpha;
+    *(fa_f32x4*)(dst + vo + c) = v0 + v1;
+    *(fa_f32x4*)(dst + ko + c) = k0 + k1;
+  }
+}
+
 }  // namespace
 
 // statistics buffers inside AttnBufs::P (the probabilities are never materialised on this path): lse | D, [nb * H][Tq] each
@@ -486,6 +650,12 @@ int cgd_attn_flash_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int 
   const float alpha = 1.f / sqrtf((float)sh.d);
   float* lse = bufs.P;
   float* Dbuf = bufs.P + (long)sh.nb * H * Tq;
+  if (T <= 64 && ctx->attn_flash >= 3) {  // one workgroup per (sequence, head) does the whole backward (Tq = 64)
+    CGD_LAUNCH(attn_flash_bwd_small_kernel, dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, lse, Dbuf, dqkv, lddq, T, Tq, H, qo, ko, vo, step,
+               alpha);
+    CGD_HIP(ctx, hipGetLastError());
+    return 0;
+  }
   CGD_LAUNCH(attn_flash_bwd_dq_kernel, dim3(Tq / 32, H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, lse, Dbuf, dqkv, lddq, T, Tq, H,
              qo, ko, vo, step, alpha);
   CGD_LAUNCH(attn_flash_bwd_dkv_kernel, dim3(Tq / 32, H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, lse, Dbuf, dqkv, lddq, T, Tq, H, qo, ko, vo,

@@ -271,3 +271,77 @@ def test_flash_attention_lane_maps_reproduce_softmax_attention_and_its_gradients
         dk, dv = emu_dkv(qp, kp, vp, dop, lse_pad, D_pad, T, kb, alpha)
         np.testing.assert_allclose(dk[:n], dk_ref[kb * 32:kb * 32 + n], rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(dv[:n], dv_ref[kb * 32:kb * 32 + n], rtol=1e-9, atol=1e-11)
+
+
+def emu_bwd_small(q, k, v, do, lse_pad, D_pad, T, alpha):
+    """attn_flash_bwd_small_kernel: wavefront (qi, kj) computes both orientations of its score tile; dQ partials over kj, dK / dV over qi."""
+    dq_tot, dk_tot, dv_tot = np.zeros((64, 64)), np.zeros((64, 64)), np.zeros((64, 64))
+    img = {}
+    for blk in range(2):
+        nv = T - blk * 32
+        z = np.zeros((64, 8, 4))
+        qr = gload(q[blk * 32:], nv) if nv > 0 else z
+        kr = gload(k[blk * 32:], nv) if nv > 0 else z
+        vr = gload(v[blk * 32:], nv) if nv > 0 else z
+        gr = gload(do[blk * 32:], nv) if nv > 0 else z
+        img[blk] = dict(Qn=store_nat(qr, alpha), Qt=store_tr(qr, alpha), Kn=store_nat(kr, 1.0), Kt=store_tr(kr, 1.0), Vn=store_nat(vr, 1.0),
+                        Gn=store_nat(gr, 1.0), Gt=store_tr(gr, 1.0))
+    for w in range(4):
+        qi, kj = w >> 1, w & 1
+        A, Bk = img[qi], img[kj]
+        st, dpt = np.zeros((64, 16)), np.zeros((64, 16))
+        for s_ in range(4):
+            mma(st, frag_nat(Bk["Kn"], s_), frag_nat(A["Qn"], s_))
+            mma(dpt, frag_nat(Bk["Vn"], s_), frag_nat(A["Gn"], s_))
+        ds = np.zeros((64, 16))
+        for lane in range(64):
+            l31, hh = lane & 31, lane >> 5
+            for r in range(16):
+                key = kj * 32 + reg_row(r, hh)
+                p = np.exp(st[lane, r] - lse_pad[qi * 32 + l31]) if key < T else 0.0
+                ds[lane, r] = p * (dpt[lane, r] - D_pad[qi * 32 + l31])
+        dq = [np.zeros((64, 16)), np.zeros((64, 16))]
+        df = split_acc(ds)
+        for t in range(2):
+            for j in range(2):
+                mma(dq[t], frag_tr(Bk["Kt"], t, j), df[j])
+        sa, dp = np.zeros((64, 16)), np.zeros((64, 16))
+        for s_ in range(4):
+            mma(sa, frag_nat(A["Qn"], s_), frag_nat(Bk["Kn"], s_))
+            mma(dp, frag_nat(A["Gn"], s_), frag_nat(Bk["Vn"], s_))
+        p2, ds2 = np.zeros((64, 16)), np.zeros((64, 16))
+        for lane in range(64):
+            hh = lane >> 5
+            for r in range(16):
+                row = qi * 32 + reg_row(r, hh)
+                p2[lane, r] = np.exp(sa[lane, r] - lse_pad[row])
+                ds2[lane, r] = p2[lane, r] * (dp[lane, r] - D_pad[row])
+        dv = [np.zeros((64, 16)), np.zeros((64, 16))]
+        dk = [np.zeros((64, 16)), np.zeros((64, 16))]
+        pf, df2 = split_acc(p2), split_acc(ds2)
+        for t in range(2):
+            for j in range(2):
+                mma(dv[t], frag_tr(A["Gt"], t, j), pf[j])
+                mma(dk[t], frag_tr(A["Qt"], t, j), df2[j])
+        dq_tot[qi * 32:qi * 32 + 32] += park(dq)
+        dv_tot[kj * 32:kj * 32 + 32] += park(dv)
+        dk_tot[kj * 32:kj * 32 + 32] += park(dk)
+    return dq_tot * alpha, dk_tot, dv_tot
+
+
+@pytest.mark.parametrize("T", [20, 50, 64])
+def test_fused_small_T_backward_lane_maps(T):
+    rng = np.random.default_rng(100 + T)
+    q, k, v, do = (rng.standard_normal((T, 64)) for _ in range(4))
+    alpha = 0.125
+    o_ref, dq_ref, dk_ref, dv_ref, D_ref = reference(q, k, v, do, alpha)
+    s = alpha * q @ k.T
+    lse_pad = np.full(64, np.inf)
+    lse_pad[:T] = np.log(np.exp(s - s.max(1, keepdims=True)).sum(1)) + s.max(1)
+    D_pad = np.zeros(64)
+    D_pad[:T] = D_ref
+    pad = lambda a: np.concatenate([a, np.full((96 - T, 64), 1e30)])  # noqa: E731  (poison: must never be used)
+    dq, dk, dv = emu_bwd_small(pad(q), pad(k), pad(v), pad(do), lse_pad, D_pad, T, alpha)
+    np.testing.assert_allclose(dq[:T], dq_ref, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(dk[:T], dk_ref, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(dv[:T], dv_ref, rtol=1e-9, atol=1e-11)
