@@ -124,8 +124,10 @@ struct cgd_ctx {
   int attn_x3 = 1;     // 1 (default since round 3): the fused attention kernels contract on bf16x3 MFMA products when the context precision
                        // is bf16x3 (attn.hip); 0 = exact-fp32 MFMA (CGD_ATTN_X3=0).  GPU-validated: strict parity, -0.2 ms/step
                        // (profiles/r3_staged_ab.txt)
-  int attn_flash = 1;  // 1 (round 5): d = 64, T > 64 attention in bf16x3 contexts runs on the kernels of attn_flash.hip (online softmax, no materialised
-                       // P / dS, backward recomputes P from the saved row statistics); 0 = attn_mid_* of attn.hip (A/B knob CGD_ATTN_FLASH)
+  int attn_flash = 3;  // (round 5) d = 64 attention in bf16x3 contexts on the kernels of attn_flash.hip (online softmax, no materialised P / dS, backward
+                       // recomputes P from the saved row statistics): 1 = T > 64 only (attn_s64_* keep T <= 64), 2 = every T, 3 (default) = every T
+                       // with the whole T <= 64 backward in ONE workgroup per (sequence, head) (attn_flash_bwd_small_kernel: -0.20 ms per step,
+                       // profiles/r5_ab_attention_small_T_fused_bwd.txt); 0 = attn_mid_* / attn_s64_* of attn.hip (A/B knob CGD_ATTN_FLASH)
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
   int fuse_gn_skip_m = 0;  // A/B: convs of exactly this many pixels read a materialised normalised tensor instead (4th field of CGD_FUSE_GN)
   int fuse_gn_max_m = 1 << 30, fuse_gn_min_m = 0;  // ... only for convs of at most / at least this many pixels (A/B knob,

@@ -117,9 +117,12 @@ def test_attention(precision):
     _assert_all(pc.check_attn(precision))
 
 
-def test_attention_materialised_kernels_in_bf16x3_context(monkeypatch):
-    """CGD_ATTN_FLASH=0 keeps attn_mid_*<true> (P / dS written to global memory, rounds 2-4) selectable: grade that path too."""
-    monkeypatch.setenv("CGD_ATTN_FLASH", "0")
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_attention_other_kernel_selections_in_bf16x3_context(mode, monkeypatch):
+    """CGD_ATTN_FLASH=0 keeps attn_mid_*<true> / attn_s64_*<true> (P / dS written to global memory, rounds 2-4) selectable; 1 = flash kernels for
+    T > 64 only; 2 = flash forward + the two-kernel flash backward for every T (the default, 3, runs the T <= 64 backward in one workgroup): grade
+    those paths too, so that no instantiation in the library is unrun."""
+    monkeypatch.setenv("CGD_ATTN_FLASH", mode)
     _assert_all(pc.check_attn(1))
 
 
