@@ -680,8 +680,10 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;  // bf16x3 products in the fused kernels (CGD_ATTN_X3=0: exact)
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
   const HeadOff ho = head_off(sh);
-  // CGD_ATTN_FLASH=2 (A/B): T <= 64 through the flash kernels too (two 32-key blocks: two of the four wavefronts of a workgroup work)
-  if (T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3) && x3 && ctx->attn_flash >= 2)
+  // CGD_ATTN_FLASH >= 2: 32 < T <= 64 through the flash kernels too (two 32-key blocks; the backward of mode 3 is one workgroup per (sequence,
+  // head)).  T <= 32 stays on attn_s64_*: no workload of the path has it, and the row statistics (2 x 32 floats per head) would not fit the
+  // T x T scratch a caller sized for the probabilities below T = 8.
+  if (T > 32 && T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3) && x3 && ctx->attn_flash >= 2)
     return cgd_attn_flash_fwd(ctx, sh, qkv, ldq, out, ldo, bufs, ho.q, ho.k, ho.v, ho.step, s);
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3)) {
     if (x3) {
@@ -746,7 +748,7 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   const float alpha = 1.f / sqrtf((float)d);
   const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;
   const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
-  if (T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3) && x3 && ctx->attn_flash >= 2)
+  if (T > 32 && T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3) && x3 && ctx->attn_flash >= 2)
     return cgd_attn_flash_bwd(ctx, sh, qkv, ldq, dout, lddo, dqkv, lddq, bufs, ho.q, ho.k, ho.v, ho.step, s);
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3)) {
     if (x3) {
