@@ -660,6 +660,16 @@ __global__ __launch_bounds__(256) void attn_s64_bwd_kernel(const float* __restri
 // the fused MFMA path: d = 64, any T > 64 (keys / queries beyond T are masked), 16-byte aligned rows
 bool attn_mid_ok(const AttnShape& sh, int ldq, int ldo) { return sh.d == 64 && sh.T > AS_T && !(ldq & 3) && !(ldo & 3); }
 
+// Round 5: which calls run on attn_flash.hip (no materialised P; bufs.P holds the row statistics LSE | D, bufs.qkvT a copy of O).  ONE predicate
+// for forward and backward (ldo = the row stride of out / dout), because a backward on the other kernels would read statistics as probabilities.
+// CGD_ATTN_FLASH >= 1: T > 64; >= 2: 32 < T <= 64 too (two 32-key blocks; the backward of mode 3 is one workgroup per (sequence, head)).  T <= 32
+// stays on attn_s64_*: no workload of the path has it, and below T = 8 the statistics (2 x 32 floats per head) would not fit the T x T scratch a
+// caller sized for the probabilities.
+bool attn_flash_selected(const cgd_ctx* ctx, const AttnShape& sh, int ldq, int ldo, bool x3) {
+  if (!x3 || sh.d != AS_D || (ldq & 3) || (ldo & 3)) return false;
+  return sh.T > AS_T ? ctx->attn_flash >= 1 : (sh.T > 32 && ctx->attn_flash >= 2);
+}
+
 }  // namespace
 
 int cgd_launch_softmax_rows(cgd_ctx* ctx, float* S, long rows, int T, int ld, hipStream_t s) {
@@ -680,11 +690,7 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;  // bf16x3 products in the fused kernels (CGD_ATTN_X3=0: exact)
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
   const HeadOff ho = head_off(sh);
-  // CGD_ATTN_FLASH >= 2: 32 < T <= 64 through the flash kernels too (two 32-key blocks; the backward of mode 3 is one workgroup per (sequence,
-  // head)).  T <= 32 stays on attn_s64_*: no workload of the path has it, and the row statistics (2 x 32 floats per head) would not fit the
-  // T x T scratch a caller sized for the probabilities below T = 8.
-  if (T > 32 && T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3) && x3 && ctx->attn_flash >= 2)
-    return cgd_attn_flash_fwd(ctx, sh, qkv, ldq, out, ldo, bufs, ho.q, ho.k, ho.v, ho.step, s);
+  if (attn_flash_selected(ctx, sh, ldq, ldo, x3)) return cgd_attn_flash_fwd(ctx, sh, qkv, ldq, out, ldo, bufs, ho.q, ho.k, ho.v, ho.step, s);
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3)) {
     if (x3) {
       CGD_LAUNCH((attn_s64_fwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
@@ -695,10 +701,6 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
     }
     CGD_HIP(ctx, hipGetLastError());
     return 0;
-  }
-  if (attn_mid_ok(sh, ldq, ldo) && x3 && ctx->attn_flash) {
-    // round 5: no materialised P; row statistics (LSE) kept in bufs.P for the recomputing backward kernels (attn_flash.hip)
-    return cgd_attn_flash_fwd(ctx, sh, qkv, ldq, out, ldo, bufs, ho.q, ho.k, ho.v, ho.step, s);
   }
   if (attn_mid_ok(sh, ldq, ldo)) {
     if (x3) {
@@ -748,8 +750,10 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   const float alpha = 1.f / sqrtf((float)d);
   const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;
   const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
-  if (T > 32 && T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3) && x3 && ctx->attn_flash >= 2)
+  if (attn_flash_selected(ctx, sh, ldq, lddo, x3)) {
+    if (lddq & 3) CGD_FAIL(ctx, "attention backward: the forward of this shape kept row statistics only; dqkv rows must be 16-byte aligned");
     return cgd_attn_flash_bwd(ctx, sh, qkv, ldq, dout, lddo, dqkv, lddq, bufs, ho.q, ho.k, ho.v, ho.step, s);
+  }
   if (T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3)) {
     if (x3) {
       CGD_LAUNCH((attn_s64_bwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
@@ -760,9 +764,6 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
     }
     CGD_HIP(ctx, hipGetLastError());
     return 0;
-  }
-  if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3) && x3 && ctx->attn_flash) {
-    return cgd_attn_flash_bwd(ctx, sh, qkv, ldq, dout, lddo, dqkv, lddq, bufs, ho.q, ho.k, ho.v, ho.step, s);
   }
   if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3)) {
     if (x3) {
