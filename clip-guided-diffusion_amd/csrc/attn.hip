@@ -670,6 +670,15 @@ bool attn_flash_selected(const cgd_ctx* ctx, const AttnShape& sh, int ldq, int l
   return sh.T > AS_T ? ctx->attn_flash >= 1 : (sh.T > 32 && ctx->attn_flash >= 2);
 }
 
+// The kernel family of one attention call: pure host logic, shared by the two launchers below and by cgd_op_attn_plan (CPU tests)
+enum AttnPath { ATTN_GENERIC = 0, ATTN_S64 = 1, ATTN_MID = 2, ATTN_FLASH = 3 };
+AttnPath attn_select(const cgd_ctx* ctx, const AttnShape& sh, int ldq, int ldo, bool x3) {
+  if (attn_flash_selected(ctx, sh, ldq, ldo, x3)) return ATTN_FLASH;
+  if (sh.T <= AS_T && sh.d == AS_D && !(ldq & 3) && !(ldo & 3)) return ATTN_S64;
+  if (attn_mid_ok(sh, ldq, ldo)) return ATTN_MID;
+  return ATTN_GENERIC;  // batched GEMMs + row softmax, probabilities materialised (any head dim)
+}
+
 }  // namespace
 
 int cgd_launch_softmax_rows(cgd_ctx* ctx, float* S, long rows, int T, int ld, hipStream_t s) {
@@ -690,8 +699,9 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;  // bf16x3 products in the fused kernels (CGD_ATTN_X3=0: exact)
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
   const HeadOff ho = head_off(sh);
-  if (attn_flash_selected(ctx, sh, ldq, ldo, x3)) return cgd_attn_flash_fwd(ctx, sh, qkv, ldq, out, ldo, bufs, ho.q, ho.k, ho.v, ho.step, s);
-  if (T <= AS_T && d == AS_D && !(ldq & 3) && !(ldo & 3)) {
+  const AttnPath path = attn_select(ctx, sh, ldq, ldo, x3);
+  if (path == ATTN_FLASH) return cgd_attn_flash_fwd(ctx, sh, qkv, ldq, out, ldo, bufs, ho.q, ho.k, ho.v, ho.step, s);
+  if (path == ATTN_S64) {
     if (x3) {
       CGD_LAUNCH((attn_s64_fwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.P, T, Tp, H, ho.q, ho.k, ho.v, ho.step,
                        1.f / sqrtf((float)d));
@@ -702,7 +712,7 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
-  if (attn_mid_ok(sh, ldq, ldo)) {
+  if (path == ATTN_MID) {
     if (x3) {
       CGD_LAUNCH((attn_mid_fwd_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, out, ldo, bufs.qkvT, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, 1.f / sqrtf((float)d));
@@ -750,11 +760,11 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   const float alpha = 1.f / sqrtf((float)d);
   const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;
   const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
-  if (attn_flash_selected(ctx, sh, ldq, lddo, x3)) {
-    if (lddq & 3) CGD_FAIL(ctx, "attention backward: the forward of this shape kept row statistics only; dqkv rows must be 16-byte aligned");
-    return cgd_attn_flash_bwd(ctx, sh, qkv, ldq, dout, lddo, dqkv, lddq, bufs, ho.q, ho.k, ho.v, ho.step, s);
-  }
-  if (T <= AS_T && d == AS_D && !(ldq & 3) && !(lddo & 3) && !(lddq & 3)) {
+  const AttnPath path = attn_select(ctx, sh, ldq, lddo, x3);  // the forward's choice (out and dout share a row stride)
+  // the fused forwards leave what their own backward needs (row statistics, or P without the transposed q / k / v of the GEMM path): no fallback
+  if (path != ATTN_GENERIC && (lddq & 3)) CGD_FAIL(ctx, "attention backward: dqkv rows must be 16-byte aligned for the fused kernels of this shape");
+  if (path == ATTN_FLASH) return cgd_attn_flash_bwd(ctx, sh, qkv, ldq, dout, lddo, dqkv, lddq, bufs, ho.q, ho.k, ho.v, ho.step, s);
+  if (path == ATTN_S64) {
     if (x3) {
       CGD_LAUNCH((attn_s64_bwd_kernel<true>), dim3(H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, dqkv, lddq, bufs.P, T, Tp, H, ho.q, ho.k,
                        ho.v, ho.step, alpha);
@@ -765,7 +775,7 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
     CGD_HIP(ctx, hipGetLastError());
     return 0;
   }
-  if (attn_mid_ok(sh, ldq, lddo) && !(lddq & 3)) {
+  if (path == ATTN_MID) {
     if (x3) {
       CGD_LAUNCH((attn_mid_bwd_dq_kernel<true>), dim3(cdiv(T, 32), H, sh.nb), dim3(256), 0, s, qkv, ldq, dout, lddo, bufs.qkvT, bufs.P, bufs.dP,
                        dqkv, lddq, T, Tp, H, ho.q, ho.k, ho.v, ho.step, alpha);
@@ -834,5 +844,21 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   k.sB1 = 3L * C * Tp; k.sB2 = ho.step * Tp;
   k.sC1 = (long)T * lddq; k.sC2 = ho.step;
   CGD_TRY(cgd_launch_gemm(ctx, k, s));
+  return 0;
+}
+
+// Host-only view of attn_select (no GPU, no context; defaults of a fresh context except the two knobs passed in): out2 = {kernel family of the
+// forward and of the backward: 0 batched GEMMs + row softmax, 1 attn_s64_*, 2 attn_mid_*, 3 attn_flash_*; kernel launches of the backward when
+// the family is fused (0 for the GEMM path, whose launch count depends on the GEMM planner)}.  attn_flash < 0 = the default.
+extern "C" int cgd_op_attn_plan(int T, int d, int ldq, int ldo, int precision, int attn_flash, int* out2) {
+  if (!out2 || T <= 0 || d <= 0) return -3;
+  cgd_ctx ctx;  // plain host object: defaults of cgd_ctx_create, nothing allocated
+  ctx.precision = precision;
+  if (attn_flash >= 0) ctx.attn_flash = attn_flash;
+  AttnShape sh{1, 1, T, d, d, 0};
+  const bool x3 = ctx.attn_x3 && precision == CGD_PREC_BF16X3;
+  const AttnPath path = attn_select(&ctx, sh, ldq, ldo, x3);
+  out2[0] = (int)path;
+  out2[1] = path == ATTN_S64 ? 1 : path == ATTN_MID ? 2 : path == ATTN_FLASH ? ((T <= AS_T && ctx.attn_flash >= 3) ? 1 : 2) : 0;
   return 0;
 }

@@ -133,6 +133,7 @@ _SIGS = {
     "cgd_op_attn_buf_floats": (i64, [i32, i32, i32, i32, i32]),
     "cgd_op_attn_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(vp), vp]),
     "cgd_op_attn_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(vp), vp]),
+    "cgd_op_attn_plan": (i32, [i32, i32, i32, i32, i32, i32, C.POINTER(i32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -275,6 +275,12 @@ int cgd_op_attn_fwd(cgd_ctx* ctx, const float* qkv, float* out, int nb, int head
                     void* stream);
 int cgd_op_attn_bwd(cgd_ctx* ctx, const float* qkv, const float* dout, float* dqkv, int nb, int heads, int T, int d, int legacy,
                     float* bufs[5], void* stream);
+/* host-only (no GPU, no context): the kernel family cgd_op_attn_fwd / _bwd (and the UNet / ViT towers) pick for one attention shape.  ldq / ldo =
+ * row strides of qkv and of out / dout in floats; precision as in cgd_ctx_create; attn_flash = the CGD_ATTN_FLASH knob (0..3), < 0 = its default.
+ * out2 = {family: 0 batched GEMMs + row softmax (any head dim), 1 attn_s64_* (d = 64, T <= 64), 2 attn_mid_* (d = 64, T > 64, probabilities
+ * materialised), 3 attn_flash_* (row statistics only); kernel launches of the backward of a fused family (0 for family 0)}.  The forward and the
+ * backward of a call use the same family: the backward fails (-2, cgd_last_error) rather than fall back when dqkv's rows are not 16-byte aligned. */
+int cgd_op_attn_plan(int T, int d, int ldq, int ldo, int precision, int attn_flash, int* out2);
 
 #ifdef __cplusplus
 }

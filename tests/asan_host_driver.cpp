@@ -113,6 +113,18 @@ int main() {
         }
     EXPECT(cgd_op_plan(0, 64, 1024, 3072, 0, 0, 0, 1, 1, 256, out4) == 0 && out4[0] == 4 && out4[1] == 518 && out4[2] == 1);  // (round 5) few-row weight GEMM: one slice
     EXPECT(cgd_op_plan(0, 800, 3072, 768, 0, 0, 0, 1, 1, 256, out4) == 0 && out4[3] == 216);                                 // 96-row hgemm2 tiles: 9 x 24
+    {  // (round 5) attention family per shape and CGD_ATTN_FLASH setting: host-only
+      int out2[2] = {-1, -1};
+      for (int flash = -1; flash <= 3; ++flash)
+        for (int T : {1, 7, 32, 33, 50, 64, 65, 197, 256, 257, 1024, 4096})
+          for (int d : {32, 64, 128, 192, 256})
+            for (int prec : {0, 1}) {
+              EXPECT(cgd_op_attn_plan(T, d, 3 * 4 * d, 4 * d, prec, flash, out2) == 0);
+              EXPECT(out2[0] >= 0 && out2[0] <= 3 && out2[1] >= 0 && out2[1] <= 2);
+              EXPECT((out2[0] == 3) == (prec == 1 && d == 64 && ((T > 64 && flash != 0) || (T > 32 && T <= 64 && (flash < 0 || flash >= 2)))));
+            }
+      EXPECT(cgd_op_attn_plan(50, 64, 192, 64, 1, -1, nullptr) == -3 && cgd_op_attn_plan(0, 64, 192, 64, 1, -1, out2) == -3);
+    }
     EXPECT(cgd_op_plan(0, 800, 768, 770, 0, 0, 0, 1, 1, 256, out4) == -2);   // K not a multiple of 4
     EXPECT(cgd_op_plan(1, 4096, 64, 0, 64, 64, 48, 1, 1, 256, out4) == -2);  // conv Cin not a multiple of 32
     EXPECT(cgd_op_plan(0, 800, 768, 768, 0, 0, 0, 1, 1, 256, nullptr) == -3);

@@ -135,6 +135,36 @@ def test_dispatch_policy_of_the_contraction_launcher():
     assert _plan(handle, conv=1, M=64 * 64, N=64, H=64, W=64, Cin=48)[0] == -2  # conv Cin must be a multiple of 32
 
 
+def test_dispatch_policy_of_the_attention_launchers():
+    """Host logic of cgd_attn_fwd / cgd_attn_bwd (csrc/attn.hip: attn_select), evaluated without a GPU through cgd_op_attn_plan: the kernel
+    family per attention shape of the path and per CGD_ATTN_FLASH setting; forward and backward of a call always agree on it."""
+    import ctypes as C
+    handle = lib.load()
+
+    def plan(T, d, heads=1, precision=1, flash=-1, ldq=None, ldo=None):
+        out = (C.c_int * 2)()
+        rc = handle.cgd_op_attn_plan(T, d, 3 * heads * d if ldq is None else ldq, heads * d if ldo is None else ldo, precision, flash, out)
+        return rc, tuple(out)
+
+    GENERIC, S64, MID, FLASH = 0, 1, 2, 3
+    # defaults (CGD_ATTN_FLASH=3) in a bf16x3 context: every d = 64 shape of BASELINE config 2 keeps row statistics only — UNet 32^2 / 16^2 / 8^2
+    # levels (T = 1024 / 256 / 64), ViT-B/32 (T = 50), ViT-B/16 (197), ViT-L/14 (257); T <= 64 backward = one launch, longer = dq + dkv
+    for T, heads, bwd in [(1024, 8, 2), (256, 16, 2), (64, 16, 1), (50, 12, 1), (197, 12, 2), (257, 16, 2), (33, 2, 1), (65, 2, 2)]:
+        assert plan(T, 64, heads) == (0, (FLASH, bwd)), T
+    # T <= 32: the short-sequence kernel (its probabilities fit the scratch at any T); other head dims (cfg128: 128 / 192 / 256): GEMM path
+    assert plan(32, 64)[1] == (S64, 1) and plan(7, 64)[1] == (S64, 1)
+    assert plan(64, 128)[1] == (GENERIC, 0) and plan(1024, 192)[1] == (GENERIC, 0)
+    # the knob: 0 = materialising kernels everywhere, 1 = flash for T > 64 only, 2 = flash everywhere with the two-kernel backward
+    assert plan(50, 64, 12, flash=0)[1] == (S64, 1) and plan(1024, 64, 8, flash=0)[1] == (MID, 2)
+    assert plan(50, 64, 12, flash=1)[1] == (S64, 1) and plan(1024, 64, 8, flash=1)[1] == (FLASH, 2)
+    assert plan(50, 64, 12, flash=2)[1] == (FLASH, 2) and plan(64, 64, 16, flash=2)[1] == (FLASH, 2)
+    # exact-fp32 contexts never take the flash kernels (bf16x3 only)
+    assert plan(1024, 64, 8, precision=0)[1] == (MID, 2) and plan(50, 64, 12, precision=0)[1] == (S64, 1)
+    # rows that are not 16-byte aligned: GEMM path
+    assert plan(50, 64, ldq=3 * 64 + 2)[1] == (GENERIC, 0) and plan(1024, 64, ldo=64 + 1)[1] == (GENERIC, 0)
+    assert plan(0, 64)[0] == -3 and handle.cgd_op_attn_plan(50, 64, 192, 64, 1, -1, None) == -3
+
+
 def test_parameter_manifests_of_every_supported_network_match_the_oracle():
     """Checkpoint ingestion without a GPU: the library's host-only manifests — the names and element counts
     `set_param` expects — against the oracle networks' state dicts (which carry the upstream key scheme), for all six published
