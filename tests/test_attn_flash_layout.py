@@ -329,7 +329,7 @@ def emu_bwd_small(q, k, v, do, lse_pad, D_pad, T, alpha):
     return dq_tot * alpha, dk_tot, dv_tot
 
 
-@pytest.mark.parametrize("T", [20, 50, 64])
+@pytest.mark.parametrize("T", [20, 33, 50, 64])
 def test_fused_small_T_backward_lane_maps(T):
     rng = np.random.default_rng(100 + T)
     q, k, v, do = (rng.standard_normal((T, 64)) for _ in range(4))
