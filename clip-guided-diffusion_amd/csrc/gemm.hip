@@ -546,7 +546,15 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
     }
     if (kc_forced) CGD_FAIL(ctx, "cgd_launch_gemm: weight-streaming conv kernel does not support this problem");
   }
-  if (use_h && !wino_forced) {
+  // Winograd F(2,3) variant (wconv.hip, tile code 515): the large maps, ONE slice, transformed weights packed.  Decided before hconv2's split-K
+  // policy (round 6): with a lowered wino_min_m (CGD_WINO="1,4096": the 64 x 64 level) the split that hconv2 would want for its 128 tiles used to
+  // disqualify wconv_kernel silently, so rounds 4-5 never measured it there
+  const bool wino_auto = use_h && !wino_forced && !p.force_tile && ctx->wino_mode && p.M >= ctx->wino_min_m && p.splitk == 1 && cgd_wconv_supported(ctx, p);
+  if (wino_auto) {
+    if (p.M % (p.H * p.W)) CGD_FAIL(ctx, "cgd_launch_gemm: conv M must be a whole number of H x W images");
+    tile = 515;
+    auto_split = false;
+  } else if (use_h && !wino_forced) {
     tile = 512;
     if (p.M % (p.H * p.W)) CGD_FAIL(ctx, "cgd_launch_gemm: conv M must be a whole number of H x W images");
     const long tiles = cgd_hconv_tiles_m(ctx, p) * cdiv(p.N, 128);
@@ -565,8 +573,6 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
       if (want >= 2) p.splitk = (int)want;
     }
     auto_split = false;
-    // Winograd F(2,3) variant (wconv.hip, tile code 515): the large maps, one slice, transformed weights packed
-    if (!p.force_tile && ctx->wino_mode && p.M >= ctx->wino_min_m && cgd_wconv_supported(ctx, p)) tile = 515;
   }
   // weight GEMM kernel (hgemm.hip): tile code 513; automatic for persistent weights with M >= hgemm_min_m
   bool use_g = false;

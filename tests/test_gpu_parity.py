@@ -32,6 +32,30 @@ def test_hgemm2_epilogues_are_bit_identical():
     _assert_all(pc.check_hgemm_epilogues())
 
 
+@pytest.mark.parametrize("shape", ["800 2304 768 1 64 2", "800 768 768 3 64 1", "800 3072 768 1 96 2", "200 160 256 1 32 2", "1000 1024 512 2 128 1"])
+def test_lgemm_experiment_matches_hgemm2(shape, tmp_path):
+    """lgemm_kernel (csrc/lgemm.hip: LDS-DMA loader wavefronts + pre-split bf16 planes; a measured no-go that is NOT linked into the library)
+    computes the same bf16x3 products in the same order as hgemm2_kernel: the micro-benchmark's self-check must report bit-identical outputs /
+    split-K slabs, ragged last row tiles and clamped column blocks included, and agreement with float64 on its samples."""
+    import os, re, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    exe = os.path.join(root, "benchmarks", "ubench", "lgemm_bench")
+    if not os.path.exists(exe):
+        exe = str(tmp_path / "lgemm_bench")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"),
+                            os.path.join(root, "benchmarks", "ubench", "lgemm_bench.hip"), "-o", exe], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, *shape.split(), "3", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+    m = re.search(r"check .*: (\d+) of (\d+) words differ from hgemm2 .*fp64 on 64 samples ([0-9.e+-]+)", r.stdout)
+    assert m, r.stdout[-1000:]
+    assert int(m.group(1)) == 0 and int(m.group(2)) > 0, r.stdout[-1000:] + r.stderr[-1000:]
+    assert float(m.group(3)) <= 1e-4, r.stdout[-1000:]
+
+
 def test_clip_vit_b32_on_the_per_lane_gemm_epilogue(monkeypatch):
     """CGD_HGEMM_EPI=0 keeps hgemm2's per-lane epilogue selectable (fused QuickGELU outputs / derivative operands, the patch-embedding
     dgrad's dropped class rows go through it): grade that path too, so no instantiation in the library is unrun."""

@@ -13,7 +13,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src,extra", [("wconv_stamps.hip", []), ("hgemm_stamps.hip", []), ("hgemm_stamps.hip", ["-DCGD_HGEMM_STAMPS=2"])])
+@pytest.mark.parametrize("src,extra", [("wconv_stamps.hip", []), ("hgemm_stamps.hip", []), ("hgemm_stamps.hip", ["-DCGD_HGEMM_STAMPS=2"]),
+                                       ("lgemm_bench.hip", []), ("lgemm_bench.hip", ["-DCGD_LGEMM_EXP=5"])])
 def test_timeline_microbenchmarks_compile_for_gfx950(tmp_path, src, extra):
     out = tmp_path / "a.out"
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), *extra,
