@@ -283,6 +283,7 @@ int cgd_op_conv3x3_wino(cgd_ctx* ctx, const float* x, int ldx, const float* w_wi
   CGD_NEED_CTX(ctx);
   GemmParams p;
   p.Bwk = w_wino;
+  p.bwk_prec = ctx->precision;  // op-level contract: packed (cgd_op_pack_conv3x3_wino) and run under the same precision mode
   p.A = x; p.lda = ldx; p.B = x /* unused: the kernel reads only the transformed weights */; p.ldb = 9 * Cin; p.C = y; p.ldc = ldy;
   p.bias = bias; p.R = R; p.ldr = ldr; p.gn_ab = gn_ab;
   p.M = Bn * H * W; p.N = Cout; p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.ups = ups; p.force_tile = 515;
@@ -294,6 +295,7 @@ int cgd_op_conv3x3_wino_ex(cgd_ctx* ctx, const float* x, int ldx, const float* w
   CGD_NEED_CTX(ctx);
   GemmParams p;
   p.Bwk = w_wino;
+  p.bwk_prec = ctx->precision;
   p.A = x; p.lda = ldx; p.B = x /* unused */; p.ldb = 9 * Cin; p.C = y; p.ldc = ldy;
   p.bias = bias; p.R = R; p.ldr = ldr; p.gn_ab = gn_ab;
   p.M = Bn * H * W; p.N = Cout; p.conv = 1; p.H = H; p.W = W; p.Cin = Cin; p.ups = ups; p.force_tile = 515;

@@ -267,6 +267,7 @@ struct GemmParams {
   int weight = 0;      // 1: B is a persistent weight (same pointer every step): hgemm.hip may cache a fragment-order copy of it
   const void* Bpk = nullptr;  // conv only: weights pre-packed in MFMA fragment order (cgd_pack_conv3x3_frag) for hconv.hip
   const void* Bwk = nullptr;  // conv only: Winograd F(2,3)-transformed weights in fragment order (cgd_pack_conv3x3_wino) for wconv.hip
+  int bwk_prec = CGD_PREC_BF16X3;  // ... and the precision mode that copy was packed for (fp32 values for mode 0, bf16 hi / lo planes for mode 1)
   // weight GEMM on hgemm2 without split-K only (cgd_gemm_fuses_act): activation fused into the epilogue.
   //   act_out: second output C2[m][n] = act(C[m][n]) (C keeps the pre-activation, the backward pass needs it);
   //   act_in : C[m][n] = (alpha * acc + bias + R) * act'(U[m][n]) (backward through the activation whose input was U)

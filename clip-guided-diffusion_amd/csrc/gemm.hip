@@ -549,9 +549,12 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   // Winograd F(2,3) variant (wconv.hip, tile code 515): the large maps, ONE slice, transformed weights packed.  Decided before hconv2's split-K
   // policy (round 6): with a lowered wino_min_m (CGD_WINO="1,4096": the 64 x 64 level) the split that hconv2 would want for its 128 tiles used to
   // disqualify wconv_kernel silently, so rounds 4-5 never measured it there
-  const bool wino_auto = use_h && !wino_forced && !p.force_tile && ctx->wino_mode && p.M >= ctx->wino_min_m && p.splitk == 1 && cgd_wconv_supported(ctx, p);
+  // ... and for exact-fp32 contexts, which have no other halo kernel: wconv_kernel<..., F32> instead of the implicit GEMM (2/3 of the products)
+  const bool wino_auto = (use_h || (ctx->precision == CGD_PREC_F32 && ctx->hconv_mode && p.conv)) && !wino_forced && !p.force_tile && ctx->wino_mode &&
+                         p.M >= ctx->wino_min_m && p.splitk == 1 && cgd_wconv_supported(ctx, p);
   if (wino_auto) {
     if (p.M % (p.H * p.W)) CGD_FAIL(ctx, "cgd_launch_gemm: conv M must be a whole number of H x W images");
+    use_h = true;
     tile = 515;
     auto_split = false;
   } else if (use_h && !wino_forced) {

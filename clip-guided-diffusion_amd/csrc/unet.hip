@@ -66,6 +66,7 @@ struct ResBlock : Module {
         *skb = 0;
   float *cw1fp = 0, *cw1dp = 0, *cw2fp = 0, *cw2dp = 0;  // MFMA-fragment-order bf16 hi/lo copies for the halo conv kernel
   float *cw1wp = 0, *cw1wd = 0, *cw2wp = 0, *cw2wd = 0;  // Winograd F(2,3)-transformed copies (wconv.hip): packed lazily, the first time
+  int wino_prec = CGD_PREC_BF16X3;                         //   precision mode the Winograd copies were packed for
   bool wino_ready = false;                                //   the block runs at >= ctx->wino_min_m pixels (UNet::ensure_wino)
   // runtime
   int B = 0, H = 0, W = 0, Ho = 0, Wo = 0;
@@ -125,7 +126,11 @@ struct UNet : NetBase {
 // 8x8 .. 64x64 levels of the supported resolutions.  Both passes use the same copies; the backward pass runs after a
 // forward pass of the same shape, so the forward hook is enough.
 int UNet::ensure_wino(ResBlock* rb, long pixels, hipStream_t s) {
+  // (round 6) the copies are packed for the context's precision mode (fp32 values or bf16 hi / lo planes, same size): a block that last ran under the
+  // other mode is repacked
+  if (rb->wino_ready && rb->wino_prec != ctx->precision) rb->wino_ready = false;
   if (!ctx->wino_mode || pixels < ctx->wino_min_m || rb->wino_ready) return 0;
+  if (ctx->precision != CGD_PREC_BF16X3 && ctx->precision != CGD_PREC_F32) return 0;
   const std::string& p = rb->pre;
   // each buffer on its own: an allocation that fails half-way is retried on the next call instead of leaving null pointers behind a
   // non-null first one
@@ -138,6 +143,7 @@ int UNet::ensure_wino(ResBlock* rb, long pixels, hipStream_t s) {
   CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wp, rb->cout, rb->cout, 0, s));
   CGD_TRY(cgd_pack_conv3x3_wino(ctx, P(p + ".out_layers.3.weight"), rb->cw2wd, rb->cout, rb->cout, 1, s));
   rb->wino_ready = true;
+  rb->wino_prec = ctx->precision;
   return 0;
 }
 
@@ -158,7 +164,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   CGD_TRY(u.ensure_wino(this, npo, s));
   // conv1 (the nearest-2x upsample of an `up` block is folded into the conv's gather)
   GemmParams c1;
-  c1.B = cw1f; c1.Bpk = cw1fp; c1.Bwk = wino_ready ? cw1wp : nullptr; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
+  c1.B = cw1f; c1.Bpk = cw1fp; c1.Bwk = wino_ready ? cw1wp : nullptr; c1.bwk_prec = wino_prec; c1.ldb = 9 * cin; c1.C = h2.p; c1.ldc = cout; c1.bias = cb1;
   c1.M = (int)npo; c1.N = cout; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cin; c1.ups = up ? 1 : 0;
   c1.defer = 1;  // a split-K launch leaves its slices for the GroupNorm right below (SplitSrc)
   c1.stats = 1;  // ... and a wconv_kernel launch takes the statistics that GroupNorm needs in its epilogue (ChanStatsEntry)
@@ -194,7 +200,7 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   CGD_TRY(cgd_launch_gemm(ctx, c1, s));
   // out_layers: GN * (1+scale) + shift -> SiLU -> conv2 (+ skip); same on-the-fly application when conv2 runs on the halo kernel
   GemmParams c2;
-  c2.A = h2.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.Bwk = wino_ready ? cw2wp : nullptr; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2;
+  c2.A = h2.p; c2.lda = cout; c2.B = cw2f; c2.Bpk = cw2fp; c2.Bwk = wino_ready ? cw2wp : nullptr; c2.bwk_prec = wino_prec; c2.ldb = 9 * cout; c2.C = outp; c2.ldc = ldo; c2.bias = cb2;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   c2.defer = 1;  // the next module starts with a GroupNorm of this tensor (or the launcher flushes: concat inputs, the head)
   c2.stats = 1;  // (both halves of a skip concat carry their own records: the GroupNorm of the concat merges the two sources)
@@ -236,7 +242,7 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   CGD_TRY(u.ensure(dx, npi * cin));
   // conv2 dgrad (a split-K launch leaves its slices for the GroupNorm backward right below)
   GemmParams c2;
-  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.Bwk = wino_ready ? cw2wd : nullptr; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
+  c2.A = dout.p; c2.lda = dout.ld; c2.B = cw2d; c2.Bpk = cw2dp; c2.Bwk = wino_ready ? cw2wd : nullptr; c2.bwk_prec = wino_prec; c2.ldb = 9 * cout; c2.C = d3.p; c2.ldc = cout;
   c2.M = (int)npo; c2.N = cout; c2.conv = 1; c2.H = Ho; c2.W = Wo; c2.Cin = cout;
   c2.defer = 1;
   // a wconv_kernel launch takes the backward sums of GN2 (input h2, upstream gradient d3 = this conv's output) in its epilogue
@@ -267,7 +273,7 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   }
   // conv1 dgrad (at the conv's own resolution)
   GemmParams c1;
-  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.Bwk = wino_ready ? cw1wd : nullptr; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
+  c1.A = d2.p; c1.lda = cout; c1.B = cw1d; c1.Bpk = cw1dp; c1.Bwk = wino_ready ? cw1wd : nullptr; c1.bwk_prec = wino_prec; c1.ldb = 9 * cout; c1.C = d1.p; c1.ldc = cin;
   c1.M = (int)npo; c1.N = cin; c1.conv = 1; c1.H = Ho; c1.W = Wo; c1.Cin = cout;
   c1.defer = (up || down) ? 0 : 1;  // plain blocks: GN1's backward below consumes the slices; resampling blocks read d1 first
   if (!up && !down) {  // ... and GN1's backward sums come from this conv's epilogue (its output d1 is GN1's upstream gradient at the same pixels)

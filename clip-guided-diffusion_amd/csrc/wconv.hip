@@ -138,7 +138,15 @@ __device__ __forceinline__ float w_silu(float x, float a, float b) {
 // overlaps a wavefront's vector-memory / staging instructions with MFMA issue (profiles/r4_wconv_ablation.txt).  The 8-row tile's two patch buffers
 // are exactly half of the CU's 160 KB of LDS and its 128 accumulators leave 128 registers per wavefront: the weight ring shrinks to 4 steps
 // (the other workgroup's MFMAs cover the shorter prefetch distance).
-template <bool GN, int NB, int NC = 1, int OCC = 1>
+// F32 (round 6): the same kernel on EXACT fp32 products (v_mfma_f32_32x32x2_f32) for precision-0 contexts — the reference's own arithmetic
+// (/root/reference/cgd/cgd.py:61 runs the diffusion model in fp32 on the CPU path).  An fp32 value is as wide as a bf16 hi / lo pair, so nothing about
+// the data movement changes: the LDS image keeps its two planes and every address, a lane's 16 bytes of "plane P" of logical unit u now hold the four
+// fp32 values of channels 8 u + 4 P .. + 3 (where the split build keeps 8 bf16 hi or lo values of channels 8 u .. 8 u + 7), the weight fragments are
+// packed the same way (pack_wino_kernel<true>), and a 16-channel k-step becomes 8 MFMAs of depth 2: MFMA e of plane P contracts channels
+// 4 P + e (lanes 0-31) and 8 + 4 P + e (lanes 32-63) of the k-step — any assignment works as long as both operands use the same one.  Staging writes
+// one 16-byte fp32 quad where it wrote two 8-byte bf16 quads; accumulators, output transform, epilogue and the GroupNorm records are shared code.
+// Per step 8 NB NC MFMAs of 64 cycles (512-2048 cycles): every load is hidden without a hand-written schedule.
+template <bool GN, int NB, int NC = 1, int OCC = 1, bool F32 = false>
 __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg,
                                                     const float* __restrict__ gng, const WConvParams p) {
@@ -177,7 +185,8 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     if (row >= TR + 2) row -= 2;  // task slots beyond the patch repeat its last two rows (identical values, identical addresses)
     const int y = y0 + row - 1;
     rowoff[j] = (unsigned)y < (unsigned)p.H ? (p.ups ? y >> 1 : y) * Ws * p.lda : -1;
-    wbase[j] = row * WROW + sp * 32 + (((c4 >> 1) + row) & 3) * 8 + (c4 & 1) * 4;
+    wbase[j] = F32 ? (c4 & 1) * WPLANE + row * WROW + sp * 32 + (((c4 >> 1) + row) & 3) * 8  // fp32 quad = the whole 16-byte unit of plane (c4 & 1)
+                   : row * WROW + sp * 32 + (((c4 >> 1) + row) & 3) * 8 + (c4 & 1) * 4;
   }
   int colo[4];
 #pragma unroll
@@ -237,9 +246,13 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
 #define W_TASK_PUT(DSTB, J, XI, V)                                                                   \
   {                                                                                                  \
     const wf32x4 t_ = (V);                                                                           \
-    const wbf16x4 hi_ = w_bf16x4(t_);                                                                \
-    *(wbf16x4*)&(DSTB)[wbase[J] + (XI) * 256] = hi_;                                                 \
-    *(wbf16x4*)&(DSTB)[WPLANE + wbase[J] + (XI) * 256] = w_bf16x4(w_residual4(t_, hi_));             \
+    if constexpr (F32) {                                                                             \
+      *(wf32x4*)&(DSTB)[wbase[J] + (XI) * 256] = t_;                                                 \
+    } else {                                                                                         \
+      const wbf16x4 hi_ = w_bf16x4(t_);                                                              \
+      *(wbf16x4*)&(DSTB)[wbase[J] + (XI) * 256] = hi_;                                               \
+      *(wbf16x4*)&(DSTB)[WPLANE + wbase[J] + (XI) * 256] = w_bf16x4(w_residual4(t_, hi_));           \
+    }                                                                                                \
   }
   // a task is transformed in three pieces of similar VALU weight (one per step)
 #define W_TASK_P1(DSTB, ARR, J)                                                                      \
@@ -279,7 +292,12 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     }                                                                                                \
   }
 #define W_MFMA12(XI, AQ, BQ)                                                                         \
-  {                                                                                                  \
+  if constexpr (F32) {                                                                               \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) _Pragma("unroll") for (int e = 0; e < 4; ++e)   \
+    _Pragma("unroll") for (int c = 0; c < NC; ++c) _Pragma("unroll") for (int b = 0; b < NB; ++b)    \
+        acc[XI][b][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(wf32x4, BQ[c][pl])[e], __builtin_bit_cast(wf32x4, AQ[b][pl])[e], \
+                                                             acc[XI][b][c], 0, 0, 0);                \
+  } else {                                                                                           \
     _Pragma("unroll") for (int c = 0; c < NC; ++c) _Pragma("unroll") for (int b = 0; b < NB; ++b)    \
         acc[XI][b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, BQ[c][0]), AQ[b][1], acc[XI][b][c], 0, 0, 0); \
     _Pragma("unroll") for (int c = 0; c < NC; ++c) _Pragma("unroll") for (int b = 0; b < NB; ++b)    \
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
         if (k2 >= 0) W_TASK_P2(nxt, pr[k2 & PM], (k2 < 0 ? 0 : k2));
         if (k3 >= 0) W_TASK_P3(nxt, pr[k3 & PM], (k3 < 0 ? 0 : k3));
       }
-      if constexpr (!(CGD_WCONV_EXP & 16)) {
+      if constexpr (!(CGD_WCONV_EXP & 16) && !F32) {
         const bool loads = w_load_task<NB, OCC>(q) >= 0;
         const bool puts = w_proc_task<NB, OCC>(q, 0) >= 0 || w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 2) >= 0;
         constexpr int NM = 3 * NB * NC;  // MFMAs per step: 12 (16-row tile, or 8-row tile x 2 channel blocks) or 6
@@ -545,7 +563,9 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
 }
 
 // w: torch conv weight [Co][Ci][3][3].  dgrad = 0: g[kx] = w[n][k][ky][kx]; dgrad = 1: g[kx] = w[k][n][2-ky][2-kx].
-// U = (g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2), computed in double, stored as bf16 hi / lo in fragment order (header).
+// U = (g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2), computed in double, stored in fragment order (header): as bf16 hi / lo planes, or (F32) as the
+// fp32 value itself with the four values of channels 8 u + 4 P .. + 3 in the lane's 16 bytes of plane P (see wconv_kernel)
+template <bool F32>
 __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Co, int Ci, int dgrad) {
   const int N = dgrad ? Ci : Co, K = dgrad ? Co : Ci;
   const int nchunk = K >> 5;
@@ -566,11 +586,16 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
       g[kx] = dgrad ? (double)w[(((long)k * Ci + n) * 3 + (2 - ky)) * 3 + (2 - kx)] : (double)w[(((long)n * Ci + k) * 3 + ky) * 3 + kx];
     const double uv = xi == 0 ? g[0] : xi == 1 ? 0.5 * (g[0] + g[1] + g[2]) : xi == 2 ? 0.5 * (g[0] - g[1] + g[2]) : g[2];
     const float v = (float)uv;
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
     const long blk = (((long)nb * nchunk + chunk) * WSTEPS + q) * 2;  // + plane
-    out[(blk + 0) * 512 + lane * 8 + e] = hi;
-    out[(blk + 1) * 512 + lane * 8 + e] = lo;
+    if constexpr (F32) {
+      // channel e of the lane's 8: plane e >> 2, float e & 3 of its 16 bytes
+      ((float*)out)[((blk + (e >> 2)) * 64 + lane) * 4 + (e & 3)] = v;
+    } else {
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      out[(blk + 0) * 512 + lane * 8 + e] = hi;
+      out[(blk + 1) * 512 + lane * 8 + e] = lo;
+    }
   }
 }
 
@@ -590,7 +615,11 @@ size_t cgd_wconv_packed_floats(int Co, int Ci) { return (size_t)Co * Ci * 12; } 
 int cgd_pack_conv3x3_wino(cgd_ctx* ctx, const float* w, float* out, int Co, int Ci, int dgrad, hipStream_t s) {
   if ((Co & 31) || (Ci & 31)) CGD_FAIL(ctx, "pack_conv3x3_wino: channels must be multiples of 32");
   const long total = (long)Co * Ci * 12;
-  CGD_LAUNCH(pack_wino_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
+  // packed for the context's CURRENT precision: fp32 values for precision 0, bf16 hi / lo planes otherwise (GemmParams::bwk_prec tells the launcher)
+  if (ctx->precision == CGD_PREC_F32)
+    CGD_LAUNCH(pack_wino_kernel<true>, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
+  else
+    CGD_LAUNCH(pack_wino_kernel<false>, dim3((int)std::min<long>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, (__bf16*)out, Co, Ci, dgrad);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
@@ -609,13 +638,21 @@ int cgd_wconv_nc(const cgd_ctx* ctx, const GemmParams& p) {
   if (ctx->wino_nc == 3) return (p.N % 256 == 0) ? 2 : 1;  // everywhere it fits (A/B)
   return (wconv_nb_plain(ctx, p) == 4 && p.N % 256 == 0) ? 2 : 1;
 }
-int cgd_wconv_nb(const cgd_ctx* ctx, const GemmParams& p) { return cgd_wconv_nc(ctx, p) == 2 ? 2 : wconv_nb_plain(ctx, p); }
+int cgd_wconv_nb(const cgd_ctx* ctx, const GemmParams& p) {
+  if (cgd_wconv_nc(ctx, p) == 2) return 2;
+  // exact-fp32 contexts never take the 16-row x 128-channel tile (its fp32 instantiation would spill two registers; with 64-cycle MFMAs the 8-row
+  // tile's shorter steps hide their loads just as well)
+  if (ctx->precision == CGD_PREC_F32 && (ctx->wino_mode & 3) != 2) return 2;
+  return wconv_nb_plain(ctx, p);
+}
 
 bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
-  if (!p.conv || !p.Bwk || ctx->precision != CGD_PREC_BF16X3 || p.nbatch != 1 || p.splitk > 1) return false;
+  if (!p.conv || !p.Bwk || (ctx->precision != CGD_PREC_BF16X3 && ctx->precision != CGD_PREC_F32) || p.nbatch != 1 || p.splitk > 1) return false;
+  if (p.bwk_prec != ctx->precision) return false;  // the transformed copy was packed for the other product type
   if ((p.Cin & 31) || (p.N & 31) || (p.lda & 3)) return false;
   if (p.H <= 0 || p.W <= 0 || (p.H & 7) || (p.W & 15) || p.M % (p.H * p.W)) return false;
   if ((p.H & 15) && (ctx->wino_mode & 3) == 2) return false;
+  if (ctx->precision == CGD_PREC_F32 && (ctx->wino_mode & 3) == 2) return false;  // forced 16-row tiles: bf16x3 only
   if (p.ups && ((p.H | p.W) & 1)) return false;
   if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
   if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
@@ -642,12 +679,18 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   ctx->last_wconv_bstat = p.bstat != nullptr;
   const int nb = cgd_wconv_nb(ctx, g), nc = cgd_wconv_nc(ctx, g);
   dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128 * nc));
-#define WC_LAUNCH(GN_, NB_, NC_) \
-  CGD_LAUNCH((wconv_kernel<GN_, NB_, NC_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
-  if (g.gn_ab) {
-    if (nc == 2) WC_LAUNCH(true, 2, 2); else if (nb == 4) WC_LAUNCH(true, 4, 1); else WC_LAUNCH(true, 2, 1);
+#define WC_LAUNCH(GN_, NB_, NC_, F32_) \
+  CGD_LAUNCH((wconv_kernel<GN_, NB_, NC_, 1, F32_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bwk, g.C, g.bias, g.R, g.gn_ab, p)
+  if (ctx->precision == CGD_PREC_F32) {
+    if (g.gn_ab) {
+      if (nc == 2) WC_LAUNCH(true, 2, 2, true); else if (nb == 4) CGD_FAIL(ctx, "wconv: no 16-row tile on fp32 products"); else WC_LAUNCH(true, 2, 1, true);
+    } else {
+      if (nc == 2) WC_LAUNCH(false, 2, 2, true); else if (nb == 4) CGD_FAIL(ctx, "wconv: no 16-row tile on fp32 products"); else WC_LAUNCH(false, 2, 1, true);
+    }
+  } else if (g.gn_ab) {
+    if (nc == 2) WC_LAUNCH(true, 2, 2, false); else if (nb == 4) WC_LAUNCH(true, 4, 1, false); else WC_LAUNCH(true, 2, 1, false);
   } else {
-    if (nc == 2) WC_LAUNCH(false, 2, 2); else if (nb == 4) WC_LAUNCH(false, 4, 1); else WC_LAUNCH(false, 2, 1);
+    if (nc == 2) WC_LAUNCH(false, 2, 2, false); else if (nb == 4) WC_LAUNCH(false, 4, 1, false); else WC_LAUNCH(false, 2, 1, false);
   }
 #undef WC_LAUNCH
   return 0;

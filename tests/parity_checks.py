@@ -295,15 +295,16 @@ def check_kconv(precision=1):
     return out
 
 
-def check_wconv():
-    """Winograd F(2,3) halo conv kernel (csrc/wconv.hip, bf16x3 only) against a float64 convolution: plain, bias + residual, batch,
-    nearest-upsampled input, the fused GroupNorm+SiLU input (gn_ab), multi-tile maps with several weight panels, and dgrad."""
+def check_wconv(precision=1):
+    """Winograd F(2,3) halo conv kernel (csrc/wconv.hip; bf16x3 products, or — round 6 — exact fp32 products in precision-0 contexts) against a
+    float64 convolution: plain, bias + residual, batch, nearest-upsampled input, the fused GroupNorm+SiLU input (gn_ab), multi-tile maps with
+    several weight panels, and dgrad."""
     from cgd_amd import ops
-    ctx = _ctx(1)
+    ctx = _ctx(precision)
     out = []
-    # 2: 16x16-pixel tiles (4 pixel blocks per wavefront), 3: 8x16-pixel tiles (2 blocks), 5 (round 4): 8x16 pixels x 256 channels (2 pixel
-    # blocks x 2 channel blocks per wavefront) wherever N is a multiple of 256
-    for mode in (2, 3, 5):
+    # 2: 16x16-pixel tiles (4 pixel blocks per wavefront; bf16x3 only), 3: 8x16-pixel tiles (2 blocks), 5 (round 4): 8x16 pixels x 256 channels
+    # (2 pixel blocks x 2 channel blocks per wavefront) wherever N is a multiple of 256
+    for mode in ((2, 3, 5) if precision == 1 else (3, 5)):
         ctx.check(ctx.lib.cgd_set_wino(ctx.h, mode, 0))
         cases = [(1, 16, 16, 32, 32, 0, 0), (1, 32, 48, 64, 160, 0, 0), (2, 16, 32, 96, 128, 0, 1), (1, 64, 64, 64, 96, 1, 0),
                  (1, 32, 32, 128, 256, 1, 1), (1, 128, 128, 32, 64, 0, 1), (1, 256, 256, 32, 32, 0, 0), (2, 24, 32, 64, 64, 0, 1)]
@@ -328,7 +329,7 @@ def check_wconv():
             ww = ops.pack_conv3x3_wino(ctx, w.to(DEV), dgrad=False)
             got = ops.conv3x3_wino(ctx, x.permute(0, 2, 3, 1).contiguous().to(DEV), ww, Co, b.to(DEV), R=r.to(DEV), upsample_input=bool(ups),
                                    gn_ab=None if ab is None else ab.to(DEV))
-            out.append(rec(f"wconv m{mode} B{Bn} {H}x{W} {Ci}->{Co} ups{ups} gn{gn}", got.permute(0, 3, 1, 2), ref))
+            out.append(rec(f"wconv[p{precision}] m{mode} B{Bn} {H}x{W} {Ci}->{Co} ups{ups} gn{gn}", got.permute(0, 3, 1, 2), ref))
             if not ups and not gn:
                 dy = th.randn(Bn, Co, H, W, generator=g(8))
                 xr = x.double().requires_grad_()
@@ -336,7 +337,7 @@ def check_wconv():
                 sd = unit_seed(xr.grad)
                 wwd = ops.pack_conv3x3_wino(ctx, w.to(DEV), dgrad=True)
                 got = ops.conv3x3_wino(ctx, (dy * sd).permute(0, 2, 3, 1).contiguous().to(DEV), wwd, Ci)
-                out.append(rec(f"wconv m{mode} dgrad {H}x{W} {Ci}<-{Co}", got.permute(0, 3, 1, 2), (xr.grad * sd).float()))
+                out.append(rec(f"wconv[p{precision}] m{mode} dgrad {H}x{W} {Ci}<-{Co}", got.permute(0, 3, 1, 2), (xr.grad * sd).float()))
     ctx.check(ctx.lib.cgd_set_wino(ctx.h, 1, 0))  # back to the default (automatic tile height)
     return out
 

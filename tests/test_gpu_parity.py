@@ -108,8 +108,10 @@ def test_thin_input_side_convs(route, monkeypatch):
     _assert_all(pc.check_thin_in(0))
 
 
-def test_conv_winograd_variant():
-    _assert_all(pc.check_wconv())
+@pytest.mark.parametrize("precision", [1, 0])
+def test_conv_winograd_variant(precision):
+    """precision 0 (round 6): wconv_kernel<..., F32> on v_mfma_f32_32x32x2_f32 — same staging, LDS image, epilogue; fp32 fragments"""
+    _assert_all(pc.check_wconv(precision))
 
 
 def test_groupnorm_layernorm():
@@ -173,6 +175,12 @@ def test_unet_batch2_on_the_winograd_kernel_with_epilogue_records():
     """Round 4: batch 2 at 128x128 puts the first level's convs (2 x 16384 pixels) on wconv_kernel, whose epilogues take the GroupNorm forward
     statistics and backward sums per (sample, half tile, channel): the per-sample indexing of the records and of the folded coefficients."""
     _assert_all(pc.check_unet("mini", 1, B=2, hw=(128, 128)))
+
+
+def test_unet_exact_fp32_on_the_winograd_kernel_with_epilogue_records():
+    """Round 6: in precision-0 contexts the >= 128 x 128-pixel convs run on wconv_kernel<..., F32> (v_mfma_f32_32x32x2_f32) instead of the implicit
+    GEMM; batch 2 at 128 x 128 also exercises the GroupNorm records its shared epilogue takes, per sample."""
+    _assert_all(pc.check_unet("mini", 0, B=2, hw=(128, 128)))
 
 
 def test_unet_dgrad_survives_a_knob_change_between_the_passes():

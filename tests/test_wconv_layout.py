@@ -24,6 +24,9 @@ def test_layouts_emulated_end_to_end_match_a_direct_convolution_and_are_bank_con
     for nb in (4, 2):
         err, worst = emulate_wconv.emulate(nb, CIN=32)
         assert err < 1e-9 and worst == 1, (nb, err, worst)
+        # round 6: the exact-fp32 instantiation (fp32 quads in the two planes, 8 MFMAs of depth 2 per k-step, pack_wino_kernel<true>)
+        err, worst = emulate_wconv.emulate(nb, CIN=32, f32=True)
+        assert err < 1e-9 and worst == 1, ("f32", nb, err, worst)
 
 
 def test_lds_transposed_epilogues_round_trip_and_are_bank_conflict_free():
