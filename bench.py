@@ -31,6 +31,9 @@ Prints ONE JSON line (driver contract) with three extra objects:
 Round 5 adds `precision_modes.f32` (the exact-fp32 MFMA mode of the same workload, a short untimed pass on a second context, so that both
 precision columns are in the driver's record) and `roofline.clock_ghz` / `power_w` (rocm-smi medians over an untimed pass of the step loop:
 the dominant kernel is power-limited, profiles/r5_wconv_power.txt).
+Round 6 adds `box_calibration` (untimed region): the sustained MFMA rate of a register-resident loop and the time of one canonical `wconv_kernel`
+layer on random and on zero inputs — fixed work that lets two driver records taken on different boxes of the pool be normalised (the boxes
+differ by up to 13 % on one build).
 """
 import argparse
 import ctypes as C
@@ -215,6 +218,50 @@ def sample_power_clock(step_fn, th, seconds=2.5):
             "power_clock_source": f"rocm-smi median over {len(samples)} samples during an untimed pass of {n} steps"}
 
 
+def box_calibration(ctx, th, dev):
+    """Fixed-work references of THIS box taken in the untimed region: the pool's boxes differ by up to 13 % on one build
+    (clock / power state), more than a round's gain, so a driver-to-driver delta can only be read after normalising by these:
+      mfma_tflops           sustained v_mfma_f32_32x32x16_bf16 rate of a register-resident loop on every SIMD (no memory traffic): the matrix
+                            pipes' rate at the clock this box grants;
+      wconv_ref_us_random / _zero   one canonical layer of the dominant kernel — 3x3 conv 256 -> 256 channels at 256 x 256, the 8-row x 256-channel
+                            Winograd tile — on N(0,1) and on all-zero inputs (zero operands do not toggle the datapath: the gap between the
+                            two is the power-cap share of the kernel's time)."""
+    import ctypes as C
+    import math
+    from cgd_amd import ops
+    lib, s = ctx.lib, ctx.stream()
+
+    def timed(fn, n):
+        fn()
+        th.cuda.synchronize()
+        a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) / n  # ms per call
+
+    flop = C.c_double()
+    iters = 60000  # ~35 ms
+    ms = timed(lambda: ctx.check(lib.cgd_op_mfma_peak(ctx.h, iters, C.byref(flop), s)), 3)
+    out = {"mfma_tflops": round(flop.value / (ms * 1e-3) / 1e12, 1), "mfma_loop_ms": round(ms, 3)}
+    g = th.Generator().manual_seed(7)
+    w = (th.randn(256, 256, 3, 3, generator=g) / math.sqrt(9 * 256)).to(dev)
+    ww = ops.pack_conv3x3_wino(ctx, w)
+    x = th.randn(1, 256, 256, 256, generator=g).to(dev)
+    y = th.empty(1, 256, 256, 256, device=dev)
+
+    def conv(xx):
+        ctx.check(lib.cgd_op_conv3x3_wino(ctx.h, xx.data_ptr(), 256, ww.data_ptr(), y.data_ptr(), 256, None, None, 0, None, 1, 256, 256, 256, 256, 0, s))
+
+    out["wconv_ref_us_random"] = round(timed(lambda: conv(x), 40) * 1e3, 2)
+    z = th.zeros_like(x)
+    out["wconv_ref_us_zero"] = round(timed(lambda: conv(z), 40) * 1e3, 2)
+    out["wconv_ref_layer"] = "conv3x3 256 -> 256 @ 256x256, wconv_kernel<false, 2, 2>, 40 launches back to back after 1 warm-up"
+    return out
+
+
 def build_device(ctx, cfg, dev):
     import torch as th
     from cgd_amd import diffusion as dd
@@ -395,15 +442,17 @@ def main():
         ps = args.profile_steps
         nprod = {"f32": 1, "bf16x3": 3, "bf16": 1}[args.precision]
 
+        peak_tf = 157.3 if args.precision == "f32" else 2500.0  # dense MFMA peak of the product type (fp32-input MFMA = the fp32 vector rate)
+
         def conv_leg(name, ms, flop, n, products, algo_bytes, pmc_name):
             ach = flop / (ms * 1e-3) / 1e12
-            return {"kernel": name, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            return {"kernel": name, "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4),
                     "traffic": pmc_traffic(pmc_name) if args.config == 2 else None,
                     "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass of this command; a constant in this line)",
                     "algorithmic_bytes_per_launch": algo_bytes if args.config == 2 else None,
                     "launches_per_step": n / ps, "avg_launch_us": round(ms * 1e3 / n, 2), "flop_per_launch": flop / n,
                     "kernel_time_share": round(ms * 1e-3 / dtp, 4), "mfma_products_per_flop": products,
-                    "mfma_issue_frac": round(products * ach / 2500.0, 4)}
+                    "mfma_issue_frac": round(products * ach / peak_tf, 4)}
 
         legs = []
         if w_n > 0:  # Winograd F(2,3): 4 transformed products per 6 algorithmic ones, each on `nprod` MFMAs
@@ -422,9 +471,9 @@ def main():
                 pb = wb_flop / (wb_ms * 1e-3) / 1e12
                 roof["launch_classes"] = {
                     "plain": {"launches_per_step": (w_n - wb_n) / ps, "avg_launch_us": round((w_ms - wb_ms) * 1e3 / (w_n - wb_n), 2),
-                              "achieved": round(pa, 2), "frac": round(pa / 2500.0, 4)},
+                              "achieved": round(pa, 2), "frac": round(pa / peak_tf, 4)},
                     "with_groupnorm_backward_epilogue": {"launches_per_step": wb_n / ps, "avg_launch_us": round(wb_ms * 1e3 / wb_n, 2),
-                                                         "achieved": round(pb, 2), "frac": round(pb / 2500.0, 4)}}
+                                                         "achieved": round(pb, 2), "frac": round(pb / peak_tf, 4)}}
             roof["measured_in"] = f"untimed pass of {ps} steps after the timed region"
             if len(legs) > 1:
                 roof["other_conv_kernel"] = legs[1]
@@ -442,7 +491,7 @@ def main():
             roof["other_mfma_kernel"] = {"kernel": "igemm_kernel / hgemm2_kernel / kgemm_kernel (+ split-K reduce)", "launches_per_step": ig_n / ps,
                                          "achieved": round(ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12, 2),
                                          "ms_per_step": round(ig_ms / ps, 3), "kernel_time_share": round(ig_ms * 1e-3 / dtp, 4)}
-        else:  # exact-fp32 mode: the halo kernel is bf16-only, every contraction runs in igemm_kernel on v_mfma_f32_32x32x2_f32
+        else:  # no halo-kernel launches at all (CGD_WINO=0 in exact-fp32 mode): every contraction runs in igemm_kernel on v_mfma_f32_32x32x2_f32
             ach = ig_flop / max(ig_ms * 1e-3, 1e-9) / 1e12
             roof = {"bound": "mfma", "kernel": "igemm_kernel<f32> (implicit GEMM, gemm.hip)", "achieved": round(ach, 2), "peak": 157.3,
                     "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None, "launches_per_step": ig_n / ps,
@@ -475,11 +524,18 @@ def main():
             th.cuda.synchronize()
             d32 = (time.perf_counter() - tq) / 12
             precision_modes = {"f32": {"steps_per_sec": round(1.0 / d32, 3), "ms_per_step": round(d32 * 1e3, 3), "steps": 12,
-                                       "note": "exact fp32 MFMA products (v_mfma_f32_32x32x2_f32), same workload, untimed-region pass on a "
-                                               "second context; `value` above is the bf16x3 mode"}}
+                                       "note": "exact fp32 MFMA products (v_mfma_f32_32x32x2_f32; round 6: the >= 128x128-pixel convs on "
+                                               "wconv_kernel<..., F32>, Winograd F(2,3) on fp32 products), same workload, untimed-region pass "
+                                               "on a second context; `value` above is the bf16x3 mode"}}
             del st32, unet32, guid32, smp32, ctx32
         except Exception as e:  # never lose the headline number to the side column
             precision_modes = {"f32": {"error": f"{type(e).__name__}: {e}"}}
+    box = None
+    if rank == 0 and world == 1 and args.precision == "bf16x3" and not args.no_profile:
+        try:
+            box = box_calibration(ctx, th, dev)
+        except Exception as e:  # never lose the headline number to the side column
+            box = {"error": f"{type(e).__name__}: {e}"}
     assert finite, "non-finite sample"
     tdev = dev if os.environ.get("CGD_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
     tmax = th.tensor([dt], device=tdev, dtype=th.float64)
@@ -535,6 +591,8 @@ def main():
         }
         if precision_modes:
             res["precision_modes"] = precision_modes
+        if box:
+            res["box_calibration"] = box
         if roof:
             res["roofline"] = roof
         if hbm:

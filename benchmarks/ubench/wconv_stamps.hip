@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dbias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dab, hab.data(), hab.size() * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(pack_wino_kernel, dim3(4096), dim3(256), 0, 0, dW, (__bf16*)dB, N, Cin, 0);
+  hipLaunchKernelGGL(pack_wino_kernel<false>, dim3(4096), dim3(256), 0, 0, dW, (__bf16*)dB, N, Cin, 0);
   CK(hipDeviceSynchronize());
 
   WConvParams p = {};

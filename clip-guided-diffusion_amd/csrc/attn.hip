@@ -679,7 +679,39 @@ AttnPath attn_select(const cgd_ctx* ctx, const AttnShape& sh, int ldq, int ldo, 
   return ATTN_GENERIC;  // batched GEMMs + row softmax, probabilities materialised (any head dim)
 }
 
+// the forward's kernel family per statistics / probabilities buffer: the fused families leave in bufs.P what only their OWN backward can
+// read (row statistics vs probabilities), so the backward refuses to run another family than the forward that last wrote the buffer
+void attn_note_path(cgd_ctx* ctx, const float* P, AttnPath path) {
+  for (auto& e : ctx->attn_fwd_path)
+    if (e.first == P) {
+      e.second = (int)path;
+      return;
+    }
+  if (ctx->attn_fwd_path.size() >= 4096) ctx->attn_fwd_path.clear();  // op-level callers with ever-new buffers: forget, never grow without bound
+  ctx->attn_fwd_path.emplace_back(P, (int)path);
+}
+int attn_noted_path(const cgd_ctx* ctx, const float* P) {
+  for (const auto& e : ctx->attn_fwd_path)
+    if (e.first == P) return e.second;
+  return -1;
+}
+
 }  // namespace
+
+// floats of AttnBufs member `which` (0 qkvT, 1 P, 2 Pt, 3 dP, 4 dAt) that an attention call of this shape needs on the kernel family the context
+// would run it on NOW (the flash family keeps 2 x Tq statistics per (sequence, head) and a copy of O, not T x T probabilities — 33.5 MB
+// per T = 1024 block that the callers used to allocate three times over for nothing)
+size_t cgd_attn_buf_floats(const cgd_ctx* ctx, const AttnShape& sh, int ldq, int ldo, int which) {
+  const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;
+  const size_t T = sh.T, Tp = attn_tp(sh.T), C = sh.C, H = sh.heads, nb = sh.nb;
+  const size_t probs = nb * H * T * Tp;
+  switch (attn_select(ctx, sh, ldq, ldo, x3)) {
+    case ATTN_FLASH: return which == 0 ? nb * T * C : which == 1 ? 2 * nb * H * (size_t)(cdiv(sh.T, 32) * 32) : 0;
+    case ATTN_S64: return which == 1 ? probs : 0;
+    case ATTN_MID: return which == 0 ? nb * 3 * C * Tp : (which == 1 || which == 3) ? probs : 0;
+    default: return which == 0 ? nb * 3 * C * Tp : which == 4 ? nb * C * Tp : probs;
+  }
+}
 
 int cgd_launch_softmax_rows(cgd_ctx* ctx, float* S, long rows, int T, int ld, hipStream_t s) {
   CGD_LAUNCH(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, S, rows, T, ld);
@@ -700,6 +732,7 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
   if (d % 4) CGD_FAIL(ctx, "attention: head dim must be a multiple of 4");
   const HeadOff ho = head_off(sh);
   const AttnPath path = attn_select(ctx, sh, ldq, ldo, x3);
+  attn_note_path(ctx, bufs.P, path);
   if (path == ATTN_FLASH) return cgd_attn_flash_fwd(ctx, sh, qkv, ldq, out, ldo, bufs, ho.q, ho.k, ho.v, ho.step, s);
   if (path == ATTN_S64) {
     if (x3) {
@@ -760,7 +793,13 @@ int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, c
   const float alpha = 1.f / sqrtf((float)d);
   const bool x3 = ctx->attn_x3 && ctx->precision == CGD_PREC_BF16X3;
   const long sP1 = (long)H * T * Tp, sP2 = (long)T * Tp;
-  const AttnPath path = attn_select(ctx, sh, ldq, lddo, x3);  // the forward's choice (out and dout share a row stride)
+  const AttnPath path = attn_select(ctx, sh, ldq, lddo, x3);  // the forward's choice when out and dout share a row stride and no knob changed
+  // ... and when they do not (a dout stride that is not a multiple of 4 floats, a precision / knob change between the passes): fail loudly instead of
+  // reading row statistics as probabilities
+  const int noted = attn_noted_path(ctx, bufs.P);
+  if (noted >= 0 && noted != (int)path)
+    CGD_FAIL(ctx, "attention backward: the forward that filled these buffers ran kernel family " + std::to_string(noted) + ", the backward would run " +
+                      std::to_string((int)path) + " (row stride of dout, precision or CGD_ATTN_* changed between the passes)");
   // the fused forwards leave what their own backward needs (row statistics, or P without the transposed q / k / v of the GEMM path): no fallback
   if (path != ATTN_GENERIC && (lddq & 3)) CGD_FAIL(ctx, "attention backward: dqkv rows must be 16-byte aligned for the fused kernels of this shape");
   if (path == ATTN_FLASH) return cgd_attn_flash_bwd(ctx, sh, qkv, ldq, dout, lddo, dqkv, lddq, bufs, ho.q, ho.k, ho.v, ho.step, s);

@@ -1,4 +1,5 @@
-// Fused QKV attention WITHOUT materialised probabilities for d = 64, T > 64 (round 5): the UNet's 16x16 / 32x32 AttentionBlocks
+// Fused QKV attention WITHOUT materialised probabilities for d = 64, T > 32 (round 5; T > 64 only with CGD_ATTN_FLASH=1, the default 3 also routes
+// 32 < T <= 64 here with the whole backward of a (sequence, head) in one workgroup): the UNet's 8x8 / 16x16 / 32x32 AttentionBlocks
 // ([3P] guided_diffusion QKVAttentionLegacy / QKVAttention, reached through /root/reference/cgd/script_util.py:316) and the CLIP
 // ViT-B/16 / L/14 towers (197 / 257 tokens).  Replaces attn_mid_* of attn.hip in bf16x3 contexts: those wrote P (33.5 MB per
 // T = 1024 call) and dS to global memory and re-split the fp32 K / V tiles from LDS on every use.

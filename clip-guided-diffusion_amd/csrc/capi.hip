@@ -253,7 +253,8 @@ int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, 
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.force_tile = force_tile; p.splitk = splitk;
   if (force_tile == 518) {  // few-row weight GEMM kernel (kgemm_kernel): it reads the fragment copy cached by B's pointer; tests hand over a fresh B
-    cgd_frag_cache_clear(ctx);  // per call, possibly at a recycled address, so the cache is emptied first (hipFree waits for kernels in flight)
+    cgd_frag_cache_evict(ctx, B);  // per call, possibly at a recycled address: only THIS pointer's copy goes (the packed weights of
+                                   // networks living on the same context stay)
     p.weight = 1;
   }
   if (force_tile == 519) {  // micro-benchmarks: kgemm_kernel with the fragment copy cached by B's pointer (B must persist)
@@ -304,6 +305,42 @@ int cgd_op_conv3x3_wino_ex(cgd_ctx* ctx, const float* x, int ldx, const float* w
     p.gnb_x = gnb_x; p.gnb_ldx = gnb_ldx; p.gnb_coef = cgd_gn_coef(gnb_scratch, Bn, H * W, Cout); p.gnb_act = 1;
   }
   return cgd_launch_gemm(ctx, p, S(stream));
+}
+}  // extern "C" (the calibration kernel below is C++)
+namespace {
+typedef __bf16 cal_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float cal_f32x16 __attribute__((ext_vector_type(16)));
+// the loop of benchmarks/ubench/mfma_peak.hip with 4 independent accumulators: 12 MFMAs per iteration, operands in registers
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  cal_f32x16 acc[4];
+  for (int a = 0; a < 4; ++a)
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+  cal_bf16x8 x, y;
+  for (int e = 0; e < 8; ++e) {
+    x[e] = (__bf16)(float)((threadIdx.x * 7 + e) % 13 - 6);
+    y[e] = (__bf16)(0.001f * (float)((threadIdx.x * 3 + e) % 11 - 5));
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[a], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int a = 0; a < 4; ++a)
+    for (int e = 0; e < 16; ++e) s += acc[a][e];
+  if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;  // keeps the loop alive, never stores
+}
+}  // namespace
+extern "C" {
+int cgd_op_mfma_peak(cgd_ctx* ctx, int iters, double* flop_out, void* stream) {
+  CGD_NEED_CTX(ctx);
+  if (iters <= 0) CGD_FAIL(ctx, "cgd_op_mfma_peak: iters must be positive");
+  const int blocks = ctx->num_cu;  // 256 threads = one wavefront per SIMD
+  if (flop_out) *flop_out = 2.0 * 32 * 32 * 16 * 12.0 * iters * blocks * 4;
+  CGD_LAUNCH(mfma_peak_kernel, dim3(blocks), dim3(256), 0, S(stream), ctx->ws, iters);
+  CGD_HIP(ctx, hipGetLastError());
+  return 0;
 }
 int cgd_op_new_pass(cgd_ctx* ctx) {
   CGD_NEED_CTX(ctx);

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <atomic>
 #include <string>
+#include <utility>
 #include <vector>
 
 // process-wide launch counters (measurement: bench.py reports launches and split-K reduce launches per step): every kernel launch of
@@ -111,7 +112,8 @@ struct cgd_ctx {
                         // (A/B knob CGD_THIN)
   int kconv_tw8 = 1;    // (round 5) kconv_kernel on 8 x 8-pixel tiles (two workgroups per CU) wherever W is a multiple of 8; 0: the 8 x 16 tile
   int kconv_ring = 2;   // weight-fragment register sets of kconv_kernel on 8 x 8 tiles: 2 = one chunk ahead, 3 = two chunks ahead (6th field of CGD_KCONV)
-  int kconv_slots = 0;  // split-K target of kconv in workgroups (0 = one per CU, the rounds 3-4 policy); A/B knobs, 4th / 5th field of CGD_KCONV
+  int kconv_slots = 0;  // split-K target of kconv in workgroups (0 = one per CU, the rounds 3-4 policy).  CGD_KCONV="<mode>,<max pixels>,<min chunks>,
+                        // <8x8 tiles>,<slots>,<ring>": kconv_tw8 is the 4th field, kconv_slots the 5th, kconv_ring the 6th
   int kconv_mode = 1, kconv_max_m = 1024, kconv_min_chunks = 4;  // weight-streaming variant of the halo conv (kconv.hip, tile code 516): for
                                           // convs of at most kconv_max_m pixels; split-K slices of at least kconv_min_chunks chunks (A/B knob
                                           // CGD_KCONV="<mode>[,<max pixels>[,<min chunks>]]")
@@ -168,6 +170,7 @@ struct cgd_ctx {
   bool last_wconv_bstat = false;          // did the last cgd_launch_wconv take a GroupNorm's backward sums in its epilogue? (profiling: kind 5)
   int gn_epi = 3;      // bit 0: GroupNorm forward statistics of conv-produced tensors come from the conv epilogue; bit 1: the backward sums of a
                        // GroupNorm whose upstream gradient a dgrad conv produces come from that conv's epilogue (A/B knob CGD_GN_EPI)
+  std::vector<std::pair<const float*, int>> attn_fwd_path;     // kernel family of the last attention forward per AttnBufs::P buffer (attn.hip)
   std::vector<FragEntry> frag_cache;                           // packed weights, keyed by pointer; cleared by finalize / set_param / destroy
   void* frag_tmp = nullptr;                                    // packed copy of a non-persistent B operand (forced hgemm, tests)
   size_t frag_tmp_bytes = 0;
@@ -346,7 +349,9 @@ int cgd_hgemm_tiles(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_hgemm_chunks(const GemmParams& p);
 int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 void cgd_frag_cache_clear(cgd_ctx* ctx);
-bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p);
+bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p);  // policy + capability (automatic selection)
+bool cgd_kgemm_capable(const cgd_ctx* ctx, const GemmParams& p);    // capability only (forced tile codes)
+void cgd_frag_cache_evict(cgd_ctx* ctx, const float* w);
 int cgd_kgemm_tiles(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_kgemm(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 

@@ -216,16 +216,23 @@ int cgd_launch_concat2(cgd_ctx* ctx, const float* a, int lda, int Ca, const floa
   return 0;
 }
 
+// records of every tensor overlapping the flat span [p, p + n) die: whole rows of 2^20 floats + the remainder (no clamp of n: ADVICE r5)
+static void flat_invalidate(cgd_ctx* ctx, const float* p, long n) {
+  const long full = n >> 20, rest = n & ((1L << 20) - 1);
+  if (full > 0) cgd_chanstats_invalidate(ctx, p, full, 1 << 20, 1 << 20);
+  if (rest > 0) cgd_chanstats_invalidate(ctx, p + (full << 20), 1, (int)rest, (int)rest);
+}
+
 int cgd_launch_act_fwd(cgd_ctx* ctx, const float* x, float* y, long n, int act, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
-  cgd_chanstats_invalidate(ctx, y, 1, (int)(n < (1L << 30) ? n : (1L << 30)), (int)(n < (1L << 30) ? n : (1L << 30)));
+  flat_invalidate(ctx, y, n);
   CGD_LAUNCH(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, act);
   CGD_HIP(ctx, hipGetLastError());
   return 0;
 }
 int cgd_launch_act_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx, long n, int act, hipStream_t s) {
   CGD_TRY(cgd_sync_pending(ctx, s));  // reads activations: a deferred split-K reduction must have landed
-  cgd_chanstats_invalidate(ctx, dx, 1, (int)(n < (1L << 30) ? n : (1L << 30)), (int)(n < (1L << 30) ? n : (1L << 30)));
+  flat_invalidate(ctx, dx, n);
   CGD_LAUNCH(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, dy, dx, n, act);
   CGD_HIP(ctx, hipGetLastError());
   return 0;

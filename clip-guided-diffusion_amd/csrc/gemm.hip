@@ -498,7 +498,7 @@ int cgd_plan_gemm(cgd_ctx* ctx, GemmParams& p, int* tile_out, int* kernel_out) {
   }
   if (p.force_tile == 517) CGD_FAIL(ctx, "cgd_launch_gemm: the GEMV kernel takes M <= 4, one batch, K and ldb multiples of 4");
   // few-row weight GEMM (tile code 518, kernel 4): K split inside the workgroup, always one slice
-  if ((p.force_tile == 518 || !p.force_tile) && !p.conv && cgd_kgemm_supported(ctx, p)) {
+  if (!p.conv && (p.force_tile == 518 ? cgd_kgemm_capable(ctx, p) : (!p.force_tile && cgd_kgemm_supported(ctx, p)))) {
     p.splitk = 1;
     *tile_out = 518;
     *kernel_out = 4;

@@ -884,13 +884,28 @@ int cgd_hgemm_tile_m(const cgd_ctx* ctx, const GemmParams& p) {
 int cgd_hgemm_tiles(const cgd_ctx* ctx, const GemmParams& p) { return cdiv(p.M, cgd_hgemm_tile_m(ctx, p)) * cdiv(p.N, GN); }
 int cgd_hgemm_chunks(const GemmParams& p) { return p.K / GK; }
 
-// kgemm_kernel takes persistent-weight GEMMs of 5 .. kgemm_max_m rows in one slice, without the epilogue options only hgemm2 has
+// kgemm_kernel takes persistent-weight GEMMs of 5 .. kgemm_max_m rows in one slice, without the epilogue options only hgemm2 has.
+// Capability (what the kernel can run: the forced tile codes 518 / 519 ask only this) apart from policy (what the automatic selection gives it;
+// a forced launch used to fail with "does not support this problem" when a policy knob said no)
+bool cgd_kgemm_capable(const cgd_ctx* ctx, const GemmParams& p) {
+  if ((uintptr_t)p.bias & 15) return false;  // the epilogue reads the bias 16 bytes at a time
+  return p.weight && p.M > 4 && cgd_hgemm_supported(ctx, p) && !p.act_out && !p.act_in && !p.skip_group && p.splitk <= 1 && (long)p.M * p.lda < (1L << 31);
+}
 bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p) {
   const bool rows_ok = p.M <= ctx->kgemm_max_m || (p.M <= ctx->kgemm_big_m && p.N <= ctx->kgemm_big_n);
-  if ((uintptr_t)p.bias & 15) return false;  // the epilogue reads the bias 16 bytes at a time
   if (ctx->kgemm_mode == 2 && p.defer && ctx->defer_mode >= 2) return false;  // mode 2: a GEMM whose split-K slices its consumer would sum anyway stays on hgemm2
-  return ctx->kgemm_mode && p.weight && p.M > 4 && rows_ok && cgd_hgemm_supported(ctx, p) && !p.act_out && !p.act_in && !p.skip_group &&
-         p.splitk <= 1 && (long)p.M * p.lda < (1L << 31);
+  return ctx->kgemm_mode && rows_ok && cgd_kgemm_capable(ctx, p);
+}
+// drops the cached fragment copy of ONE weight (tests hand over a fresh B per call, possibly at a recycled address)
+void cgd_frag_cache_evict(cgd_ctx* ctx, const float* w) {
+  for (size_t i = 0; i < ctx->frag_cache.size();) {
+    if (ctx->frag_cache[i].w == w) {
+      (void)hipFree(ctx->frag_cache[i].packed);  // waits for kernels in flight
+      ctx->frag_cache.erase(ctx->frag_cache.begin() + i);
+    } else {
+      ++i;
+    }
+  }
 }
 int cgd_kgemm_ni(const cgd_ctx* ctx, const GemmParams& p) {  // 32-row tiles: same-box A/B (profiles/r5_ab_tm96_kgemm.txt) 64-row tiles everywhere
   (void)p;                                                      // +0.43 ms per step, 32-row tiles everywhere -0.03 against a mixed policy

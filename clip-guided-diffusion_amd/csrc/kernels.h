@@ -80,6 +80,8 @@ struct AttnBufs {     // all owned by the caller, sized by cgd_attn_buf_floats
   float* dAt;         // [nb][C][Tp]
 };
 static inline int attn_tp(int T) { return (T + 3) & ~3; }
+// floats of AttnBufs member `which` (0 qkvT, 1 P, 2 Pt, 3 dP, 4 dAt) for the kernel family the context runs this shape on (0 = not touched)
+size_t cgd_attn_buf_floats(const cgd_ctx* ctx, const AttnShape& sh, int ldq, int ldo, int which);
 // qkv: [nb*T][3C] token-major (row stride ldq);  out: [nb*T][C] (row stride ldo)
 int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, float* out, int ldo, const AttnBufs& bufs,
                  hipStream_t s);
@@ -87,7 +89,7 @@ int cgd_attn_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, f
 int cgd_attn_bwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, const float* dout, int lddo, float* dqkv, int lddq,
                  const AttnBufs& bufs, hipStream_t s);
 
-// attn_flash.hip (round 5): d = 64, T > 64 in bf16x3 contexts; P is never materialised, bufs.P holds the row statistics (LSE | D),
+// attn_flash.hip (round 5): d = 64, T > 32 in bf16x3 contexts (T > 64 only at CGD_ATTN_FLASH=1); P is never materialised, bufs.P holds the row statistics (LSE | D),
 // bufs.qkvT a copy of O for the backward's D = rowsum(dO * O).  qo / ko / vo / step: column offsets of head 0 and the per-head step
 int cgd_attn_flash_fwd(cgd_ctx* ctx, const AttnShape& sh, const float* qkv, int ldq, float* out, int ldo, const AttnBufs& bufs, long qo,
                        long ko, long vo, long step, hipStream_t s);

@@ -57,7 +57,7 @@ struct NetBase {
     return 0;
   }
   int ensure(DevBuf& b, size_t n) {
-    if (b.n >= n && b.p) return 0;
+    if (n == 0 || (b.n >= n && b.p)) return 0;
     // grow-only; the old block stays registered and is released with the handle
     CGD_TRY(alloc(&b.p, n));
     b.n = n;

@@ -1173,7 +1173,8 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
                       const float* beta, const float* film, int ldfilm, int act, float eps, float* scratch, hipStream_t s) {
   if (C % 32 || C > 4096) CGD_FAIL(ctx, "groupnorm: C must be a multiple of 32 and <= 4096");
   if ((ldx & 3) || (y && (ldy & 3))) CGD_FAIL(ctx, "groupnorm: row strides must be multiples of 4");
-  if (y) cgd_chanstats_invalidate(ctx, y, (long)B * HW, ldy, C);
+  float* const y_written = y;
+  const int ldy_written = ldy;
   if (!y) ldy = 4;  // statistics only (y == nullptr): see cgd_gn_ab
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
@@ -1190,6 +1191,8 @@ int cgd_launch_gn_fwd(cgd_ctx* ctx, const float* x, int ldx, float* y, int ldy, 
   // statistics a conv epilogue already took for exactly this tensor in this pass (ChanStatsEntry): merge the records, no sweep over x
   ChanSrc cs;
   const bool epi = !src.n && HW > GN_SMALL_HW && !(HW & 127) && (ctx->gn_epi & 1) && cgd_chanstats_find(ctx, x, ldx, (long)B * HW, C, s, &cs);
+  // the output's records die AFTER the lookup: an in-place call (y == x) consumes the records of x first, then kills them
+  if (y_written) cgd_chanstats_invalidate(ctx, y_written, (long)B * HW, ldy_written, C);
   ProfRec pr;  // algorithmic HBM bytes of a GroupNorm forward: one read of x, one write of y; statistics only: the read (the
                // figure is the operation's, also when the producer's epilogue has already taken the statistics and the read never happens)
                // a norm that sums split-K slices on the way in also does the work of the reduce launch it replaces: n slice reads + the merged write
@@ -1240,7 +1243,6 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
   int chunk, nchunk;
   float *part, *stats, *coef, *bcoef;
   gn_layout(scratch, B, HW, C, &chunk, &nchunk, &part, &stats, &coef, &bcoef);
-  cgd_chanstats_invalidate(ctx, dx, (long)B * HW, lddx, C);
   SplitSrc src;  // dz may still lie in split-K slices (the dgrad conv that produced it deferred its reduction)
   if (!((HW > GN_SMALL_HW || ctx->defer_mode >= 2) && cgd_take_pending(ctx, dz, (long)B * HW, C, lddz, s, &src))) CGD_TRY(cgd_flush_pending(ctx, s));
   if (src.n && (((src.N | src.ldr) & 3) || ((uintptr_t)src.ws & 15) || ((uintptr_t)src.R & 15) || ((uintptr_t)src.bias & 15)) && HW > GN_SMALL_HW) {
@@ -1258,11 +1260,15 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
     CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
     cgd_prof_push(ctx, &pr);
     CGD_HIP(ctx, hipGetLastError());
+    cgd_chanstats_invalidate(ctx, dx, (long)B * HW, lddx, C);
     return 0;
   }
   // the dgrad conv that produced dz may already have taken this norm's backward sums in its epilogue (ChanStatsEntry kind 1): merge its records
   ChanSrc cs;
-  if (!src.n && !(HW & 127) && (ctx->gn_epi & 2) && cgd_chanstats_find(ctx, dz, lddz, (long)B * HW, C, s, &cs, 1) && cs.n0 == C) {
+  const bool merged = !src.n && !(HW & 127) && (ctx->gn_epi & 2) && cgd_chanstats_find(ctx, dz, lddz, (long)B * HW, C, s, &cs, 1) && cs.n0 == C;
+  // dx's records die AFTER the lookup: an in-place call (dx == dz) consumes the records of dz first
+  cgd_chanstats_invalidate(ctx, dx, (long)B * HW, lddx, C);
+  if (merged) {
     ++ctx->gn_record_merges;
     int lg = 0;
     while ((1 << lg) < C / 32) ++lg;

@@ -301,7 +301,6 @@ int AttnBlock::fwd(UNet& u, TV xin, int Bn, int& H, int& W, TV* o, hipStream_t s
   B = Bn; T = H * W;
   x = xin;
   const long rows = (long)B * T;
-  const int Tp = attn_tp(T);
   CGD_TRY(u.ensure(sc, cgd_gn_scratch_floats(B, T, C)));
   CGD_TRY(u.ensure(n, rows * C));
   CGD_TRY(u.ensure(qkv, rows * 3 * C));
@@ -309,8 +308,11 @@ int AttnBlock::fwd(UNet& u, TV xin, int Bn, int& H, int& W, TV* o, hipStream_t s
   if (!dst.p) CGD_TRY(u.ensure(out, rows * C));
   float* const outp = dst.p ? dst.p : out.p;
   const int ldo = dst.p ? dst.ld : C;
-  CGD_TRY(u.ensure(qkvT, (size_t)B * 3 * C * Tp));
-  CGD_TRY(u.ensure(P, (size_t)B * heads * T * Tp));
+  {  // scratch of the kernel family this shape runs on (flash: row statistics + a copy of O instead of T x T probabilities)
+    const AttnShape shb{B, heads, T, d, C, legacy};
+    CGD_TRY(u.ensure(qkvT, cgd_attn_buf_floats(ctx, shb, 3 * C, C, 0)));
+    CGD_TRY(u.ensure(P, cgd_attn_buf_floats(ctx, shb, 3 * C, C, 1)));
+  }
   CGD_TRY(cgd_launch_gn_fwd(ctx, x.p, x.ld, n.p, C, B, T, C, g, b, nullptr, 0, 0, 1e-5f, sc.p, s));
   GemmParams q;
   q.A = n.p; q.lda = C; q.B = qkvw; q.ldb = C; q.C = qkv.p; q.ldc = 3 * C; q.bias = qkvb; q.M = (int)rows; q.N = 3 * C; q.K = C;
@@ -332,14 +334,16 @@ int AttnBlock::fwd(UNet& u, TV xin, int Bn, int& H, int& W, TV* o, hipStream_t s
 int AttnBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   cgd_ctx* ctx = u.ctx;
   const long rows = (long)B * T;
-  const int Tp = attn_tp(T);
   CGD_TRY(u.ensure(da, rows * C));
   CGD_TRY(u.ensure(dqkv, rows * 3 * C));
   CGD_TRY(u.ensure(dn, rows * C));
   CGD_TRY(u.ensure(dx, rows * C));
-  CGD_TRY(u.ensure(Pt, (size_t)B * heads * T * Tp));
-  CGD_TRY(u.ensure(dP, (size_t)B * heads * T * Tp));
-  CGD_TRY(u.ensure(dAt, (size_t)B * C * Tp));
+  {
+    const AttnShape shb{B, heads, T, d, C, legacy};
+    CGD_TRY(u.ensure(Pt, cgd_attn_buf_floats(ctx, shb, 3 * C, C, 2)));
+    CGD_TRY(u.ensure(dP, cgd_attn_buf_floats(ctx, shb, 3 * C, C, 3)));
+    CGD_TRY(u.ensure(dAt, cgd_attn_buf_floats(ctx, shb, 3 * C, C, 4)));
+  }
   GemmParams p;
   p.A = dout.p; p.lda = dout.ld; p.B = pwT; p.ldb = C; p.C = da.p; p.ldc = C; p.M = (int)rows; p.N = C; p.K = C;
   p.weight = 1;

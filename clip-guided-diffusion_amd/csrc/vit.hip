@@ -115,7 +115,7 @@ int ViT::forward(const float* img, int lay, int Nn, float* emb, hipStream_t s) {
   if (!finalized) CGD_FAIL(ctx, "vit: finalize() has not been called after the last set_param");
   N = Nn; layout = lay; have_fwd = false;
   const long rows = (long)N * L;
-  const int H = cfg.heads, d = W / H, Tp = attn_tp(L);
+  const int H = cfg.heads, d = W / H;
   const float* colp = img;
   if (layout == 0) {
     CGD_TRY(ensure(cols, (size_t)N * g * g * PP));
@@ -135,7 +135,10 @@ int ViT::forward(const float* img, int lay, int Nn, float* emb, hipStream_t s) {
     CGD_TRY(ensure(l.y, rows * W)); CGD_TRY(ensure(l.qkv, rows * 3 * W)); CGD_TRY(ensure(l.a, rows * W));
     CGD_TRY(ensure(l.x1, rows * W)); CGD_TRY(ensure(l.y2, rows * W)); CGD_TRY(ensure(l.u, rows * 4 * W));
     CGD_TRY(ensure(l.ga, rows * 4 * W)); CGD_TRY(ensure(l.xo, rows * W));
-    CGD_TRY(ensure(l.qkvT, (size_t)N * 3 * W * Tp)); CGD_TRY(ensure(l.P, (size_t)N * H * L * Tp));
+    {  // scratch of the kernel family this shape runs on (flash: row statistics + a copy of O instead of L x L probabilities)
+      const AttnShape shb{N, H, L, d, W, 0};
+      CGD_TRY(ensure(l.qkvT, cgd_attn_buf_floats(ctx, shb, 3 * W, W, 0))); CGD_TRY(ensure(l.P, cgd_attn_buf_floats(ctx, shb, 3 * W, W, 1)));
+    }
     CGD_TRY(cgd_launch_ln_fwd(ctx, x, W, l.y.p, W, (int)rows, W, l.ln1g, l.ln1b, 1e-5f, l.st1.p, s));
     CGD_TRY(cgd_launch_gemm(ctx, lin(l.y.p, W, l.inw, W, l.qkv.p, 3 * W, l.inb, nullptr, 0, rows, 3 * W), s));
     AttnShape sh{N, H, L, d, W, 0};
@@ -169,7 +172,7 @@ int ViT::forward(const float* img, int lay, int Nn, float* emb, hipStream_t s) {
 int ViT::dgrad(const float* demb, float* dimg, hipStream_t s) {
   if (!have_fwd) CGD_FAIL(ctx, "vit: dgrad() needs a preceding forward()");
   const long rows = (long)N * L;
-  const int H = cfg.heads, d = W / H, Tp = attn_tp(L);
+  const int H = cfg.heads, d = W / H;
   CGD_TRY(ensure(dclsn, (size_t)N * W));
   CGD_TRY(ensure(dxl, rows * W));
   // emb = clsn @ proj  ->  d clsn = demb @ proj^T : B = proj [W][out] is already [N=W][K=out]
@@ -184,8 +187,11 @@ int ViT::dgrad(const float* demb, float* dimg, hipStream_t s) {
     CGD_TRY(ensure(l.dga, rows * 4 * W)); CGD_TRY(ensure(l.du, rows * 4 * W)); CGD_TRY(ensure(l.dy2, rows * W));
     CGD_TRY(ensure(l.dx1, rows * W)); CGD_TRY(ensure(l.da, rows * W)); CGD_TRY(ensure(l.dqkv, rows * 3 * W));
     CGD_TRY(ensure(l.dy, rows * W)); CGD_TRY(ensure(l.dx, rows * W));
-    CGD_TRY(ensure(l.Pt, (size_t)N * H * L * Tp)); CGD_TRY(ensure(l.dP, (size_t)N * H * L * Tp));
-    CGD_TRY(ensure(l.dAt, (size_t)N * W * Tp));
+    {
+      const AttnShape shb{N, H, L, d, W, 0};
+      CGD_TRY(ensure(l.Pt, cgd_attn_buf_floats(ctx, shb, 3 * W, W, 2))); CGD_TRY(ensure(l.dP, cgd_attn_buf_floats(ctx, shb, 3 * W, W, 3)));
+      CGD_TRY(ensure(l.dAt, cgd_attn_buf_floats(ctx, shb, 3 * W, W, 4)));
+    }
     // MLP
     {
       // d(c_proj) and the backward of QuickGELU: du = (dcur @ W_proj) * gelu'(u), fused like the forward

@@ -120,6 +120,7 @@ _SIGS = {
     "cgd_op_gn_record_merges": (i64, [vp]),
     "cgd_op_gn_stats_offset": (i64, [i32, i32, i32]),
     "cgd_op_wconv_schedule": (i32, [i32, i32, C.POINTER(i32)]),
+    "cgd_op_mfma_peak": (i32, [vp, i32, C.POINTER(C.c_double), vp]),
     "cgd_op_conv_in": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cgd_op_conv_thin_out": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cgd_op_gn_scratch_floats": (i64, [i32, i32, i32]),

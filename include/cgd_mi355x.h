@@ -203,9 +203,10 @@ int cgd_sample_update(cgd_ctx* ctx, const float* x, const float* pred_xstart, co
 /* ---- single ops, exported for parity tests and for user-supplied cond_fn plumbing ---- */
 /* C[M][N] = alpha * A[M][K] B[N][K]^T (+bias[N]) (+R[M][N]); conv3x3: A is NHWC (Bn,H,W,Cin), B = [N][9*Cin].
  * force_tile: 0 auto, 64 / 128 / 256 / 257 (+1000: two-deep prefetch) igemm tiles, 513 weight GEMM kernel (B re-packed per call),
- * 514 the same with the packed copy cached by B's pointer (B must persist; micro-benchmarks), 518 the few-row weight GEMM kernel (M <= 256, K split
- * inside the workgroup, one slice; the packed-weight cache is emptied first).  splitk: >= 1 slices (1 = automatic), -1 = one
- * slice, never split automatically. */
+ * 514 the same with the packed copy cached by B's pointer (B must persist; micro-benchmarks), 518 the few-row weight GEMM kernel (5 <= M rows, K
+ * split inside the workgroup, one slice; the cached fragment copy of THIS B pointer is dropped first, other weights of the context stay), 519 the
+ * same with the copy cached by B's pointer (B must persist; micro-benchmarks).  A forced 518 / 519 asks only what the kernel can run, not the
+ * CGD_KGEMM policy knobs.  splitk: >= 1 slices (1 = automatic), -1 = one slice, never split automatically. */
 int cgd_op_gemm(cgd_ctx* ctx, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, const float* R,
                 int ldr, int M, int N, int K, float alpha, int force_tile, int splitk, void* stream);
 /* w_packed: [Cout][9*Cin] fp32 (generic kernel); w_frag (optional): the same weights in MFMA-fragment order, bf16 hi/lo planes,
@@ -223,8 +224,10 @@ int cgd_set_hconv(cgd_ctx* ctx, int mode, int min_m);
 int cgd_op_conv3x3(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w_packed, const float* w_frag, float* y_nhwc, int ldy,
                    const float* bias, const float* R, int ldr, int Bn, int H, int W, int Cin, int Cout, int upsample_input, int force_tile,
                    int splitk, void* stream);
-/* Winograd F(2,3)-along-W variant of the halo conv (wconv.hip; H, W multiples of 16, bf16x3 only): w_wino = the torch weights
- * transformed and packed by cgd_op_pack_conv3x3_wino (Co*Ci*12 floats of storage).  gn_ab (optional): per-(sample, channel) pairs
+/* Winograd F(2,3)-along-W variant of the halo conv (wconv.hip; H a multiple of 8, W of 16; bf16x3 products, or — round 6 — exact fp32 products
+ * in precision-0 contexts: wconv_kernel<..., F32> on v_mfma_f32_32x32x2_f32): w_wino = the torch weights transformed and packed by
+ * cgd_op_pack_conv3x3_wino (Co*Ci*12 floats of storage) FOR THE CONTEXT'S CURRENT PRECISION MODE (fp32 values or bf16 hi / lo planes: pack and
+ * run under the same mode; the UNet repacks its copies when the mode changes).  gn_ab (optional): per-(sample, channel) pairs
  * {a, b} [Bn][Cin][2]; the kernel then convolves SiLU(x * a + b) (the fused GroupNorm of the UNet's ResBlocks).
  * cgd_set_wino: mode 1 (default) = the UNet's 3x3 convs of >= min_m (default 16384) pixels run on this kernel, 0 = off, 2 / 3 = 16- / 8-row
  * tiles everywhere; set BEFORE cgd_unet_finalize, which packs the transformed weights (environment CGD_WINO="<mode>[,min_m]"). */
@@ -254,6 +257,10 @@ int64_t cgd_op_gn_stats_offset(int B, int HW, int C);
  * tiles) or 2 (8-row tiles): out4 = {task whose 4 pixel loads are issued at step q, tasks whose transform piece 1 / 2 / 3 runs at step
  * q}, -1 = none; task k lives in register slot k & 1.  CPU tests check that no slot is reloaded while its task is still live. */
 int cgd_op_wconv_schedule(int nb, int q, int* out4);
+/* box calibration (bench.py `box_calibration`): a register-resident v_mfma_f32_32x32x16_bf16 loop, one wavefront per SIMD
+ * on every CU, `iters` x 12 MFMAs per wavefront: no memory traffic, so its rate is what the box's clock / power state gives the matrix pipes.
+ * flop_out (optional, host): the FLOP of the launch; time it with events on `stream`. */
+int cgd_op_mfma_peak(cgd_ctx* ctx, int iters, double* flop_out, void* stream);
 int cgd_op_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w, const float* bias, float* y_nhwc, int Bn, int H, int W, int Cin,
                    int Cout, void* stream);
 int cgd_op_conv_thin_out(cgd_ctx* ctx, const float* x_nhwc, int ldx, const float* w, const float* bias, float* y_nchw, int Bn, int H,
@@ -270,6 +277,7 @@ int cgd_op_ln_bwd(cgd_ctx* ctx, const float* x, const float* dy, float* dx, int 
 int cgd_op_pool2x2(cgd_ctx* ctx, const float* in, float* out, int B, int Ho, int Wo, int C, float scale, void* stream);
 int cgd_op_upsample2x(cgd_ctx* ctx, const float* in, float* out, int B, int Ho, int Wo, int C, float scale, void* stream);
 int cgd_op_act(cgd_ctx* ctx, const float* x, const float* dy, float* out, int64_t n, int act, void* stream);
+/* upper bound over all kernel families (the GEMM path's T x T probabilities); the networks size their own scratch per family (flash: row statistics) */
 int64_t cgd_op_attn_buf_floats(int nb, int heads, int T, int d, int which);
 int cgd_op_attn_fwd(cgd_ctx* ctx, const float* qkv, float* out, int nb, int heads, int T, int d, int legacy, float* bufs[5],
                     void* stream);
@@ -279,7 +287,9 @@ int cgd_op_attn_bwd(cgd_ctx* ctx, const float* qkv, const float* dout, float* dq
  * row strides of qkv and of out / dout in floats; precision as in cgd_ctx_create; attn_flash = the CGD_ATTN_FLASH knob (0..3), < 0 = its default.
  * out2 = {family: 0 batched GEMMs + row softmax (any head dim), 1 attn_s64_* (d = 64, T <= 64), 2 attn_mid_* (d = 64, T > 64, probabilities
  * materialised), 3 attn_flash_* (row statistics only); kernel launches of the backward of a fused family (0 for family 0)}.  The forward and the
- * backward of a call use the same family: the backward fails (-2, cgd_last_error) rather than fall back when dqkv's rows are not 16-byte aligned. */
+ * backward of a call use the same family: the backward fails (-2, cgd_last_error) rather than fall back when dqkv's rows are not 16-byte aligned,
+ * or when the forward that filled the buffers ran another family (a different dout stride, a precision change between the passes).
+ * The plan is that of a FRESH context: CGD_ATTN_X3 / CGD_ATTN_FLASH of the environment are not read (pass attn_flash explicitly). */
 int cgd_op_attn_plan(int T, int d, int ldq, int ldo, int precision, int attn_flash, int* out2);
 
 #ifdef __cplusplus

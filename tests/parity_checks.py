@@ -543,7 +543,10 @@ def check_attn(precision):
     ctx = _ctx(precision)
     out = []
     for (nb, heads, T, d, legacy) in [(2, 2, 64, 64, 1), (1, 4, 256, 64, 1), (3, 12, 50, 64, 0), (1, 3, 100, 64, 0), (1, 4, 64, 128, 1),
-                                      (2, 3, 256, 64, 0), (1, 2, 1024, 64, 1), (1, 2, 192, 64, 1), (2, 12, 197, 64, 0), (1, 4, 257, 64, 0)]:
+                                      (2, 3, 256, 64, 0), (1, 2, 1024, 64, 1), (1, 2, 192, 64, 1), (2, 12, 197, 64, 0), (1, 4, 257, 64, 0),
+                                      # the UNet's 8x8 shape (16 heads, two sequences) on the one-workgroup backward, and the
+                                      # 256x288 model's token counts (72 / 288 / 1152: ragged 32-row blocks) at the op level
+                                      (2, 16, 64, 64, 1), (1, 4, 72, 64, 1), (1, 4, 288, 64, 0), (1, 2, 1152, 64, 1)]:
         Cc = heads * d
         qkv = th.randn(nb * T, 3 * Cc, generator=g(40))
         dout = th.randn(nb * T, Cc, generator=g(41))
@@ -557,6 +560,29 @@ def check_attn(precision):
         dq = at.backward(qkv.to(DEV), (dout * sd).to(DEV))
         out.append(rec(f"attn bwd[p{precision}] nb{nb} h{heads} T{T} d{d} legacy{legacy}", dq, (qr.grad * sd).float()))
     return out
+
+
+def check_attn_family_guard():
+    """the backward runs the kernel family of the forward that filled the buffers or fails — here the context drops to exact fp32 between
+    the passes, which would select attn_mid_* (probabilities) for buffers that hold flash-attention row statistics.  Returns the error text."""
+    from cgd_amd import ops
+    ctx = _ctx(1)
+    nb, heads, T, d = 1, 2, 128, 64
+    qkv = th.randn(nb * T, 3 * heads * d, generator=g(40)).to(DEV)
+    dout = th.randn(nb * T, heads * d, generator=g(41)).to(DEV)
+    at = ops.Attention(ctx, nb, heads, T, d, 1, DEV)
+    at.forward(qkv)
+    ctx.check(ctx.lib.cgd_set_precision(ctx.h, 0))
+    try:
+        at.backward(qkv, dout)
+    except RuntimeError as e:
+        msg = str(e)
+    else:
+        msg = ""
+    ctx.check(ctx.lib.cgd_set_precision(ctx.h, 1))
+    ok = at.backward(qkv, dout)  # same family again: runs
+    th.cuda.synchronize()
+    return msg, bool(th.isfinite(ok).all())
 
 
 def check_cutouts_loss():

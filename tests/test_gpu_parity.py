@@ -143,6 +143,11 @@ def test_attention(precision):
     _assert_all(pc.check_attn(precision))
 
 
+def test_attention_backward_refuses_another_kernel_family_than_the_forward():
+    msg, ok = pc.check_attn_family_guard()
+    assert "kernel family" in msg and ok, msg
+
+
 @pytest.mark.parametrize("mode", ["0", "1", "2"])
 def test_attention_other_kernel_selections_in_bf16x3_context(mode, monkeypatch):
     """CGD_ATTN_FLASH=0 keeps attn_mid_*<true> / attn_s64_*<true> (P / dS written to global memory, rounds 2-4) selectable; 1 = flash kernels for
