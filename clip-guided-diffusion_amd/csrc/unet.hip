@@ -107,6 +107,9 @@ struct UNet : NetBase {
   int B = 0, H = 0, W = 0;
   bool have_fwd = false;
   DevBuf temb, e1, e1s, e2, e2s, emb_all, h0, headn, head_s, dheadn, dhead;
+  DevBuf emb_slot1;             // second FiLM-projection buffer: embed() for step n + 1 may run (on another stream) while step n's forward reads slot n & 1
+  const float* emb_cur = nullptr;  // the slot the running forward reads
+  int emb_B[2] = {0, 0};        // batch each slot was computed for (0 = never)
   std::vector<DevBuf> cats;
   std::vector<TV> hs;
   std::vector<std::pair<int, int>> hs_hw;
@@ -117,7 +120,8 @@ struct UNet : NetBase {
 
   int build();
   int finalize(hipStream_t s);
-  int forward(const float* x, const float* t, const int64_t* y, float* out, int B, int H, int W, hipStream_t s);
+  int embed(const float* t, const int64_t* y, int Bn, int slot, hipStream_t s, bool ahead = false);
+  int forward(const float* x, const float* t, const int64_t* y, float* out, int B, int H, int W, hipStream_t s, int slot = -1);
   int dgrad(const float* gout, float* gx, hipStream_t s);
 };
 
@@ -206,12 +210,12 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   c2.stats = 1;  // (both halves of a skip concat carry their own records: the GroupNorm of the concat merges the two sources)
   const bool fuse2 = cgd_conv_uses_hconv(ctx, c2);
   if (fuse2) {
-    CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, nullptr, 0, B, Ho * Wo, cout, g2, b2, u.emb_all.p + emb_off, (int)u.emb_total, 1, 1e-5f,
+    CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, nullptr, 0, B, Ho * Wo, cout, g2, b2, u.emb_cur + emb_off, (int)u.emb_total, 1, 1e-5f,
                               s2.p, s));
     c2.gn_ab = cgd_gn_ab(s2.p, B, Ho * Wo, cout);
   } else {
     CGD_TRY(u.ensure(h3, npo * cout));
-    CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, h3.p, cout, B, Ho * Wo, cout, g2, b2, u.emb_all.p + emb_off, (int)u.emb_total, 1, 1e-5f,
+    CGD_TRY(cgd_launch_gn_fwd(ctx, h2.p, cout, h3.p, cout, B, Ho * Wo, cout, g2, b2, u.emb_cur + emb_off, (int)u.emb_total, 1, 1e-5f,
                               s2.p, s));
     c2.A = h3.p;
   }
@@ -576,38 +580,61 @@ int UNet::finalize(hipStream_t s) {
   return 0;
 }
 
-int UNet::forward(const float* x, const float* t, const int64_t* y, float* out, int Bn, int Hh, int Ww, hipStream_t s) {
+// The embedding head — timestep embedding -> time_embed MLP (+ class embedding) -> SiLU -> ALL FiLM projections of the ResBlocks as one GEMV —
+// depends on (t, y) only, not on x: eight small dependent launches (~0.15 ms with their dispatch latencies) at the head of every step.  Split off
+// (round 6) so that the sampler can run it for step n + 1 on a side stream while step n computes: `slot` (0 / 1) selects one of two
+// FiLM buffers; forward(..., slot) then reads that buffer instead of recomputing.  Calls of embed() must be stream-ordered among themselves (they
+// share the MLP temporaries); the caller orders embed(slot) before forward(slot) and forward(slot) before the next embed(slot) with events.
+// `ahead` (the C-ABI entry, whose caller may be running another pass of this context on another stream): the three GEMMs never split K, so they
+// never touch the context's shared split-K workspace (with M <= 4 rows they are GEMVs that never split anyway).
+int UNet::embed(const float* t, const int64_t* y, int Bn, int slot, hipStream_t s, bool ahead) {
+  if (!finalized) CGD_FAIL(ctx, "unet: finalize() has not been called after the last set_param");
+  if (slot < 0 || slot > 1) CGD_FAIL(ctx, "unet: embedding slot must be 0 or 1");
+  if (cfg.num_classes > 0 && !y) CGD_FAIL(ctx, "unet: class-conditional model needs y");
+  const int mc = cfg.model_channels;
+  DevBuf& dst = slot ? emb_slot1 : emb_all;
+  CGD_TRY(ensure(temb, (size_t)Bn * mc));
+  CGD_TRY(ensure(e1, (size_t)Bn * ted));
+  CGD_TRY(ensure(e1s, (size_t)Bn * ted));
+  CGD_TRY(ensure(e2, (size_t)Bn * ted));
+  CGD_TRY(ensure(e2s, (size_t)Bn * ted));
+  CGD_TRY(ensure(dst, (size_t)Bn * emb_total));
+  CGD_TRY(cgd_launch_timestep_embedding(ctx, t, freqs, temb.p, Bn, mc, s));
+  GemmParams g1;
+  g1.A = temb.p; g1.lda = mc; g1.B = P("time_embed.0.weight"); g1.ldb = mc; g1.C = e1.p; g1.ldc = ted; g1.bias = P("time_embed.0.bias");
+  g1.M = Bn; g1.N = ted; g1.K = mc; g1.no_split = ahead;
+  CGD_TRY(cgd_launch_gemm(ctx, g1, s));
+  CGD_TRY(cgd_launch_act_fwd(ctx, e1.p, e1s.p, (long)Bn * ted, 1, s));
+  GemmParams g2;
+  g2.A = e1s.p; g2.lda = ted; g2.B = P("time_embed.2.weight"); g2.ldb = ted; g2.C = e2.p; g2.ldc = ted; g2.bias = P("time_embed.2.bias");
+  g2.M = Bn; g2.N = ted; g2.K = ted; g2.no_split = ahead;
+  CGD_TRY(cgd_launch_gemm(ctx, g2, s));
+  if (cfg.num_classes > 0) CGD_TRY(cgd_launch_embedding_add(ctx, P("label_emb.weight"), y, e2.p, Bn, ted, s));
+  CGD_TRY(cgd_launch_act_fwd(ctx, e2.p, e2s.p, (long)Bn * ted, 1, s));
+  GemmParams g3;
+  g3.A = e2s.p; g3.lda = ted; g3.B = emb_w_all; g3.ldb = ted; g3.C = dst.p; g3.ldc = (int)emb_total; g3.bias = emb_b_all;
+  g3.M = Bn; g3.N = (int)emb_total; g3.K = ted; g3.no_split = ahead;
+  CGD_TRY(cgd_launch_gemm(ctx, g3, s));
+  emb_B[slot] = Bn;
+  return 0;
+}
+
+// slot < 0: the embedding head runs here, on `s`, into slot 0 (the plain model(x, t, y) call); slot 0 / 1: a preceding embed(t, y, B, slot) did it
+int UNet::forward(const float* x, const float* t, const int64_t* y, float* out, int Bn, int Hh, int Ww, hipStream_t s, int slot) {
   if (!finalized) CGD_FAIL(ctx, "unet: finalize() has not been called after the last set_param");
   const int levels = cfg.n_mult - 1;
   if ((Hh % (1 << levels)) || (Ww % (1 << levels))) CGD_FAIL(ctx, "unet: H and W must be divisible by 2^(levels-1)");
-  if (cfg.num_classes > 0 && !y) CGD_FAIL(ctx, "unet: class-conditional model needs y");
+  if (slot > 1) CGD_FAIL(ctx, "unet: embedding slot must be 0 or 1");
+  if (slot < 0) {
+    CGD_TRY(embed(t, y, Bn, 0, s));
+    slot = 0;
+  } else if (emb_B[slot] != Bn) {
+    CGD_FAIL(ctx, "unet: forward(slot) needs a preceding embed() of the same batch size into that slot");
+  }
+  emb_cur = slot ? emb_slot1.p : emb_all.p;
   B = Bn; H = Hh; W = Ww;
   have_fwd = false;
   ++ctx->stats_serial;  // conv-epilogue statistics of earlier passes are dead from here on (ChanStatsEntry)
-  const int mc = cfg.model_channels;
-  // ---- embeddings (independent of x: no backward) ----
-  CGD_TRY(ensure(temb, (size_t)B * mc));
-  CGD_TRY(ensure(e1, (size_t)B * ted));
-  CGD_TRY(ensure(e1s, (size_t)B * ted));
-  CGD_TRY(ensure(e2, (size_t)B * ted));
-  CGD_TRY(ensure(e2s, (size_t)B * ted));
-  CGD_TRY(ensure(emb_all, (size_t)B * emb_total));
-  CGD_TRY(cgd_launch_timestep_embedding(ctx, t, freqs, temb.p, B, mc, s));
-  GemmParams g1;
-  g1.A = temb.p; g1.lda = mc; g1.B = P("time_embed.0.weight"); g1.ldb = mc; g1.C = e1.p; g1.ldc = ted; g1.bias = P("time_embed.0.bias");
-  g1.M = B; g1.N = ted; g1.K = mc;
-  CGD_TRY(cgd_launch_gemm(ctx, g1, s));
-  CGD_TRY(cgd_launch_act_fwd(ctx, e1.p, e1s.p, (long)B * ted, 1, s));
-  GemmParams g2;
-  g2.A = e1s.p; g2.lda = ted; g2.B = P("time_embed.2.weight"); g2.ldb = ted; g2.C = e2.p; g2.ldc = ted; g2.bias = P("time_embed.2.bias");
-  g2.M = B; g2.N = ted; g2.K = ted;
-  CGD_TRY(cgd_launch_gemm(ctx, g2, s));
-  if (cfg.num_classes > 0) CGD_TRY(cgd_launch_embedding_add(ctx, P("label_emb.weight"), y, e2.p, B, ted, s));
-  CGD_TRY(cgd_launch_act_fwd(ctx, e2.p, e2s.p, (long)B * ted, 1, s));
-  GemmParams g3;
-  g3.A = e2s.p; g3.lda = ted; g3.B = emb_w_all; g3.ldb = ted; g3.C = emb_all.p; g3.ldc = (int)emb_total; g3.bias = emb_b_all;
-  g3.M = B; g3.N = (int)emb_total; g3.K = ted;
-  CGD_TRY(cgd_launch_gemm(ctx, g3, s));
   // ---- skip-concat buffers: output block k reads cat([h, hs[n-1-k]]) = cats[k] ([pixels][c1 + skip channels]).  The producers
   //      of the two halves (the previous output-side module / the input-side block or the stem) write straight into their
   //      channel slice, so no concat copy exists.
@@ -768,6 +795,23 @@ int cgd_unet_forward(cgd_unet* u, const float* x, const float* t, const int64_t*
     return rc;
   }
   return cgd_flush_pending(u->net.ctx, (hipStream_t)stream);  // nothing deferred may outlive the call
+}
+int cgd_unet_embed(cgd_unet* u, const float* t, const int64_t* y, int B, int slot, void* stream) {
+  if (!u) return -3;
+  DeviceScope dev_scope(u->net.ctx);
+  // (nothing is deferred here: GEMVs and element-wise kernels; a pending reduction of the MAIN stream's pass is not this call's to flush —
+  // cgd_launch_gemm flushes unconditionally, so the sampler only calls this between whole passes of the main stream)
+  return u->net.embed(t, y, B, slot, (hipStream_t)stream, true);
+}
+int cgd_unet_forward_slot(cgd_unet* u, const float* x, int slot, float* out, int B, int H, int W, void* stream) {
+  if (!u) return -3;
+  if (slot < 0 || slot > 1) return -3;
+  DeviceScope dev_scope(u->net.ctx);
+  if (const int rc = u->net.forward(x, nullptr, nullptr, out, B, H, W, (hipStream_t)stream, slot)) {
+    u->net.ctx->pending.valid = false;
+    return rc;
+  }
+  return cgd_flush_pending(u->net.ctx, (hipStream_t)stream);
 }
 int cgd_unet_dgrad(cgd_unet* u, const float* g_out, float* g_x, void* stream) {
   if (!u) return -3;

@@ -87,6 +87,12 @@ __device__ unsigned long long* g_wstamps;  // [workgroup][wavefront][32]: 0 entr
 // weight-fragment loads (and LDS reads) reach the CU's single vector-memory path at the same moment and each wavefront waits for the other three
 // (~60 cycles per global_load_dwordx4 with the MFMA issue of that in-order wavefront stopped).  CGD_WCONV_SKEW = n: wavefront w sleeps n * 64 * w
 // cycles after every barrier, which keeps the four schedules apart for the whole chunk.
+// fp32-product instantiations: 1 = interleave the step's loads / staging VALU behind the MFMAs by hand (with a 4-step weight ring, which frees the
+// registers that schedule needs), 0 = the compiler's own order on the 8-step ring.  Same-box A/B (profiles/r6_ab_f32_schedule.txt): 41.01 / 41.06 ms per
+// step for 0 against 41.08 / 41.17 for 1 — the 64-cycle MFMAs hide the step's loads either way; default 0, the variant stays behind the macro
+#ifndef CGD_WCONV_F32_SCHED
+#define CGD_WCONV_F32_SCHED 0
+#endif
 #ifndef CGD_WCONV_SKEW
 #define CGD_WCONV_SKEW 0
 #endif
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
   W_STAMP(0);
 
   static_assert(OCC == 1 || (NB == 2 && NC == 1), "two workgroups per CU: 8-row tile, one channel block");
-  constexpr int RING = OCC == 2 ? 4 : WRING, DIST = RING - 1;  // weight-fragment ring (steps)
+  // weight-fragment ring (steps); the hand-interleaved fp32 schedule (CGD_WCONV_F32_SCHED) needs the registers a 4-step ring frees
+  constexpr int RING = (OCC == 2 || (F32 && CGD_WCONV_F32_SCHED)) ? 4 : WRING, DIST = RING - 1;
   constexpr int TN = 128 * NC;  // output channels per workgroup
   const int ntn = (p.N + TN - 1) / TN;
   int bid = blockIdx.x;
@@ -367,6 +374,20 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
           if (loads && (NM == 12 ? (r & 1) && r < 8 : r < 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 4 patch loads
           __builtin_amdgcn_sched_group_barrier(0x002, (GN ? 6 : 3) * (NM == 12 ? 1 : 2), 0);      // VALU
           if (puts && (NM == 12 ? (r % 3) == 2 : r >= 2)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (<= 4 per step)
+        }
+      }
+      if constexpr (F32 && CGD_WCONV_F32_SCHED) {
+        // fp32 products: 8 NB NC MFMAs of 64 cycles per step; the step's loads and the staging VALU (GroupNorm + SiLU: two transcendentals per
+        // element) are spread behind them instead of being left in one block, which the compiler's own order does
+        const bool loads = w_load_task<NB, OCC>(q) >= 0;
+        const bool puts = w_proc_task<NB, OCC>(q, 0) >= 0 || w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 2) >= 0;
+        constexpr int NM = 8 * NB * NC;
+#pragma unroll
+        for (int r = 0; r < NM; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   // MFMA
+          if (loads && r < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                               // the 4 patch loads first
+          __builtin_amdgcn_sched_group_barrier(0x002, GN ? 5 : 2, 0);                                          // VALU
+          if (puts && (r & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                         // DS write
         }
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -69,6 +69,8 @@ _SIGS = {
     "cgd_unet_set_param": (i32, [vp, C.c_char_p, vp, i64]),
     "cgd_unet_finalize": (i32, [vp]),
     "cgd_unet_forward": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "cgd_unet_embed": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cgd_unet_forward_slot": (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
     "cgd_unet_dgrad": (i32, [vp, vp, vp, vp]),
     "cgd_vit_create": (i32, [vp, C.POINTER(ViTConfig), C.POINTER(vp)]),
     "cgd_vit_destroy": (None, [vp]),

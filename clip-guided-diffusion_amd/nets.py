@@ -119,6 +119,27 @@ class UNet(_Net):
         self._keep = (x, t, y)  # inputs must outlive the enqueued work
         return out
 
+    def embed(self, timesteps, y, slot):
+        """The (t, y)-only head of model(x, t, y) — time / class embedding and all FiLM projections — into buffer `slot` (0 / 1), on the current
+        stream.  `forward_slot` then runs the rest; the sampler uses the pair to take the head off the step's critical path."""
+        t = timesteps.to(dtype=th.float32).contiguous()
+        if y is not None:
+            y = y.to(dtype=th.int64).contiguous()
+        self.ctx.check(self.ctx.lib.cgd_unet_embed(self.h, t.data_ptr(), L.ptr(y), int(t.shape[0]), int(slot), self.ctx.stream()))
+        if not hasattr(self, "_keep_emb"):
+            self._keep_emb = {}
+        self._keep_emb[int(slot)] = (t, y)  # inputs must outlive the enqueued work
+
+    def forward_slot(self, x, slot, out=None):
+        """model(x, t, y) with the embedding head already computed by embed(t, y, slot)."""
+        B, _, H, W = x.shape
+        x = x.contiguous().float()
+        if out is None:
+            out = th.empty((B, self.out_channels, H, W), device=x.device, dtype=th.float32)
+        self.ctx.check(self.ctx.lib.cgd_unet_forward_slot(self.h, x.data_ptr(), int(slot), out.data_ptr(), B, H, W, self.ctx.stream()))
+        self._keep = (x,)
+        return out
+
     def __call__(self, x, timesteps, y=None, out=None):
         """model(x, timesteps, y) as the sampler and user cond_fns call it: an autograd node when `x` requires grad."""
         if x.requires_grad and th.is_grad_enabled():

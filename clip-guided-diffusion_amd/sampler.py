@@ -7,11 +7,71 @@ Per step: UNet forward (C ABI) -> p_mean_variance tail + blend (HIP) -> noise dr
 With a `ClipGuidance` cond_fn everything stays native; any other Python callable gets the reference semantics
 through autograd Functions whose forward/backward call the same C ABI (`UNetFunction`).
 """
+import os
+
 import torch as th
 
 from . import lib as L
 from .guidance import ClipGuidance
 from .nets import UNetFunction  # noqa: F401  (re-exported: the autograd node of model(x, ts, y))
+
+
+class EmbedAhead:
+    """Runs the (t, y)-only head of model(x, t, y) — timestep / class embedding, the FiLM projections of every ResBlock: eight small dependent
+    launches, ~0.15 ms with their dispatch latencies — for step n + 1 on a side stream while step n computes.  Two FiLM
+    buffers (slot = n & 1); events order embed(slot) -> forward(slot) -> the next embed(slot).  Only for the native paths (no cond_fn, or
+    ClipGuidance), batches of <= 4 rows (the head's GEMMs are GEMVs then and touch no shared split-K workspace); CGD_EMBED_AHEAD=0 switches it
+    off (A/B).  Random draws keep the reference's order: they are issued by the host in program order whatever stream executes them."""
+
+    @staticmethod
+    def create(sampler, model, cond_fn, img, indices):
+        if os.environ.get("CGD_EMBED_AHEAD", "1") == "0" or not hasattr(model, "embed") or img.shape[0] > 4 or len(indices) < 2:
+            return None
+        if cond_fn is not None and not isinstance(cond_fn, ClipGuidance):
+            return None
+        return EmbedAhead(sampler, img.device, img.shape[0], indices)
+
+    def __init__(self, sampler, dev, B, indices):
+        self.dev, self.indices = dev, indices
+        self.side = th.cuda.Stream(device=dev)
+        self.ev_emb = [th.cuda.Event(), th.cuda.Event()]
+        self.ev_fwd = [th.cuda.Event(), th.cuda.Event()]
+        self.fwd_seen = [False, False]
+        self.n = 0  # the step whose forward comes next
+        main = th.cuda.current_stream(dev)
+        # model timesteps of the whole schedule (one row per step, B columns), built on the main stream: the side stream waits for it once
+        self.tt = th.tensor([float(sampler.tables.model_timestep(k)) for k in range(sampler.num_timesteps)], dtype=th.float32,
+                            device=dev).view(-1, 1).repeat(1, B).contiguous()
+        ready = th.cuda.Event()
+        ready.record(main)
+        self.side.wait_event(ready)
+        self._keep = []
+
+    def side_stream(self):
+        return th.cuda.stream(self.side)
+
+    def launch(self, model, n, y):
+        """embedding head of step n into slot n & 1 on the side stream"""
+        slot = n & 1
+        with th.cuda.stream(self.side):
+            if self.fwd_seen[slot]:
+                self.side.wait_event(self.ev_fwd[slot])  # the forward that read this slot last (step n - 2) is done
+            if y is not None:
+                y = y.to(self.dev)
+                y.record_stream(self.side) if y.is_cuda else None
+            model.embed(self.tt[self.indices[n]], y, slot)
+            self.ev_emb[slot].record(self.side)
+        self._keep = [y]
+
+    def forward(self, model, x, out):
+        slot = self.n & 1
+        main = th.cuda.current_stream(self.dev)
+        main.wait_event(self.ev_emb[slot])
+        o = model.forward_slot(x, slot, out=out)
+        self.ev_fwd[slot].record(main)
+        self.fwd_seen[slot] = True
+        self.n += 1
+        return o
 
 
 class GuidedSampler:
@@ -43,7 +103,7 @@ class GuidedSampler:
         return th.randn((gb,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)[idx].contiguous()
 
     # ---- one step -------------------------------------------------------------------------------------
-    def _step(self, model, x, i, cond_fn, model_kwargs, noise, mode, bufs):
+    def _step(self, model, x, i, cond_fn, model_kwargs, noise, mode, bufs, ahead=None):
         ctx, lib = self.ctx, self.ctx.lib
         B, _, H, W = x.shape
         dev = x.device
@@ -68,7 +128,11 @@ class GuidedSampler:
         x0, mean, logvar, xin = (buf(n, (B, 3, H, W)) for n in ("x0", "mean", "logvar", "xin"))
         sample, x0_out = th.empty_like(x), th.empty_like(x)
         if cond_fn is None or native:
-            out6 = model.forward(x, ts, y, out=buf("out6", (B, 6, H, W)))
+            if ahead is not None:
+                # the embedding head of this step ran ahead on the side stream (EmbedAhead): wait for it, run the rest of the model
+                out6 = ahead.forward(model, x, buf("out6", (B, 6, H, W)))
+            else:
+                out6 = model.forward(x, ts, y, out=buf("out6", (B, 6, H, W)))
             ctx.check(lib.cgd_pmv_blend(ctx.h, x.data_ptr(), out6.data_ptr(), x0.data_ptr(), mean.data_ptr(), logvar.data_ptr(),
                                         xin.data_ptr(), B, H, W, coef, s))
             if noise is None:
@@ -132,17 +196,35 @@ class GuidedSampler:
             it = tqdm(indices)
         bufs = {}
         img = img.contiguous()
+
+        def draw_y():
+            """this step's class labels under `randomize_class` — same draws, in the same order of the generator, as the reference loop"""
+            if tape is not None:
+                return tape["y"][draw_y.n].to(device)
+            if self.shard is not None:
+                return th.randint(0, model.num_classes, (self.shard[1],), device=device)[self.shard[0]]
+            return th.randint(0, model.num_classes, model_kwargs["y"].shape, device=device)
+
+        draw_y.n = 0
+        rand_y = bool(randomize_class and "y" in model_kwargs)
+        ahead = EmbedAhead.create(self, model, cond_fn, img, indices)
         for n, i in enumerate(it):
-            if randomize_class and "y" in model_kwargs:
-                if tape is not None:
-                    model_kwargs["y"] = tape["y"][n].to(device)
-                elif self.shard is not None:
-                    model_kwargs["y"] = th.randint(0, model.num_classes, (self.shard[1],), device=device)[self.shard[0]]
-                else:
-                    model_kwargs["y"] = th.randint(0, model.num_classes, model_kwargs["y"].shape, device=device)
+            if rand_y and (ahead is None or n == 0):
+                draw_y.n = n
+                model_kwargs["y"] = draw_y()
+            if ahead is not None and n == 0:
+                ahead.launch(model, 0, model_kwargs.get("y"))
             step_noise = tape["noise"][n].to(device).float().contiguous() if tape is not None else None
             with th.no_grad():
-                out = self._step(model, img, i, cond_fn, model_kwargs, step_noise, mode, bufs)
+                out = self._step(model, img, i, cond_fn, model_kwargs, step_noise, mode, bufs, ahead)
+            if ahead is not None and n + 1 < len(indices):
+                # step n is enqueued: now (host order = the reference's order of random draws: after this step's noise) draw the next step's
+                # labels and run its embedding head on the side stream, where it overlaps this step's kernels
+                with ahead.side_stream():
+                    if rand_y:
+                        draw_y.n = n + 1
+                        model_kwargs["y"] = draw_y()
+                    ahead.launch(model, n + 1, model_kwargs.get("y"))
             yield out
             img = out["sample"]
 

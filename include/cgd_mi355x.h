@@ -89,6 +89,13 @@ int cgd_unet_finalize(cgd_unet* u); /* pack fwd + dgrad (rotated/transposed) wei
  * -> out (B,6,H,W) NCHW.  Keeps the activations the backward pass needs. */
 int cgd_unet_forward(cgd_unet* u, const float* x, const float* timesteps, const int64_t* y, float* out, int B, int H, int W,
                      void* stream);
+/* Round 6: the embedding head of model(x, t, y) — timestep embedding, time_embed MLP, class embedding, ALL FiLM projections — depends on (t, y)
+ * only.  cgd_unet_embed computes it into one of two buffers (slot 0 / 1) on `stream`; cgd_unet_forward_slot is cgd_unet_forward reading that
+ * buffer.  The sampler runs embed for step n + 1 on a side stream while step n computes (eight small dependent launches off the critical path).
+ * The caller orders embed(slot) -> forward_slot(slot) -> next embed(slot) with events; embed calls are stream-ordered among themselves; call it
+ * between whole passes (not between a forward and its dgrad is fine; never from another host thread). */
+int cgd_unet_embed(cgd_unet* u, const float* timesteps, const int64_t* y, int B, int slot, void* stream);
+int cgd_unet_forward_slot(cgd_unet* u, const float* x, int slot, float* out, int B, int H, int W, void* stream);
 /* d(sum(out * g_out))/dx of the LAST forward: replaces the UNet leg of th.autograd.grad(loss, x), cgd.py:228 */
 int cgd_unet_dgrad(cgd_unet* u, const float* g_out, float* g_x, void* stream);
 

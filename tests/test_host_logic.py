@@ -377,7 +377,7 @@ def test_device_sampler_loop_prologue_matches_the_oracle(monkeypatch, skip, with
     init = th.rand(shape, generator=th.Generator().manual_seed(1)) * 2 - 1 if with_init else None
     seen_dev, seen_ora = [], []
 
-    def dev_step(model_, x, i, cond_fn, model_kwargs, noise, mode, bufs):
+    def dev_step(model_, x, i, cond_fn, model_kwargs, noise, mode, bufs, ahead=None):
         seen_dev.append((i, x.clone(), model_kwargs["y"].clone()))
         return {"sample": x * 0.5 + i, "pred_xstart": x}
 
