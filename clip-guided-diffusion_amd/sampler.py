@@ -20,12 +20,16 @@ class EmbedAhead:
     """Runs the (t, y)-only head of model(x, t, y) — timestep / class embedding, the FiLM projections of every ResBlock: eight small dependent
     launches, ~0.15 ms with their dispatch latencies — for step n + 1 on a side stream while step n computes.  Two FiLM
     buffers (slot = n & 1); events order embed(slot) -> forward(slot) -> the next embed(slot).  Only for the native paths (no cond_fn, or
-    ClipGuidance), batches of <= 4 rows (the head's GEMMs are GEMVs then and touch no shared split-K workspace); CGD_EMBED_AHEAD=0 switches it
-    off (A/B).  Random draws keep the reference's order: they are issued by the host in program order whatever stream executes them."""
+    ClipGuidance), batches of <= 4 rows (the head's GEMMs are GEMVs then and touch no shared split-K workspace).  Random draws keep the
+    reference's order: they are issued by the host in program order whatever stream executes them.
+    MEASURED NEGATIVE, therefore opt-in (CGD_EMBED_AHEAD=1; 2 = the same choreography with the "side" stream being the main stream, the control
+    of the A/B): profiles/r6_ab_embed_ahead.txt — 18.65 -> 19.29 ms per step.  A second active HIP stream costs every launch of the step (~0.7 us
+    x 874) far more than the eight small launches it takes off the critical path."""
 
     @staticmethod
     def create(sampler, model, cond_fn, img, indices):
-        if os.environ.get("CGD_EMBED_AHEAD", "1") == "0" or not hasattr(model, "embed") or img.shape[0] > 4 or len(indices) < 2:
+        mode = os.environ.get("CGD_EMBED_AHEAD", "0")
+        if mode not in ("1", "2") or not hasattr(model, "embed") or img.shape[0] > 4 or len(indices) < 2:
             return None
         if cond_fn is not None and not isinstance(cond_fn, ClipGuidance):
             return None
@@ -33,7 +37,7 @@ class EmbedAhead:
 
     def __init__(self, sampler, dev, B, indices):
         self.dev, self.indices = dev, indices
-        self.side = th.cuda.Stream(device=dev)
+        self.side = th.cuda.current_stream(dev) if os.environ.get("CGD_EMBED_AHEAD") == "2" else th.cuda.Stream(device=dev)
         self.ev_emb = [th.cuda.Event(), th.cuda.Event()]
         self.ev_fwd = [th.cuda.Event(), th.cuda.Event()]
         self.fwd_seen = [False, False]
@@ -217,6 +221,8 @@ class GuidedSampler:
             step_noise = tape["noise"][n].to(device).float().contiguous() if tape is not None else None
             with th.no_grad():
                 out = self._step(model, img, i, cond_fn, model_kwargs, step_noise, mode, bufs, ahead)
+            if ahead is not None and tape is not None and rand_y and n + 1 >= len(tape["y"]):
+                ahead = None  # a replay tape shorter than the schedule (tests that run a few steps): the remaining steps run in line
             if ahead is not None and n + 1 < len(indices):
                 # step n is enqueued: now (host order = the reference's order of random draws: after this step's noise) draw the next step's
                 # labels and run its embedding head on the side stream, where it overlaps this step's kernels

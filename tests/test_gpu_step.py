@@ -33,6 +33,15 @@ def test_p_sample_trajectory_bf16x3():
     _assert_all(sc.check_step("mini", 1, steps=4))
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_p_sample_trajectory_with_the_embedding_head_one_step_ahead(mode, monkeypatch):
+    """Round 6 (opt-in, CGD_EMBED_AHEAD): the (t, y)-only head of the UNet for step n + 1 runs on a side stream (mode 1; mode 2 = the same event
+    choreography on the main stream) into the other of two FiLM buffers — cgd_unet_embed / cgd_unet_forward_slot: the trajectory must still match
+    the oracle record for record (randomised class labels come from the replay tape, four steps)."""
+    monkeypatch.setenv("CGD_EMBED_AHEAD", mode)
+    _assert_all(sc.check_step("mini", 1, steps=4))
+
+
 def test_ddim_trajectory():
     # also separates the yielded pred_xstart (unconditioned, [3P] ddim_sample_with_grad) from the x0' that builds the sample
     _assert_all(sc.check_step("mini", 1, ddim=True, steps=4))
