@@ -349,6 +349,8 @@ def main():
     # CGD_BENCH_DEVICE / CGD_BENCH_BACKEND: test knobs only (exercise the N > 1 flow on a 1-GPU box: every rank on one device, gloo)
     local = int(os.environ.get("CGD_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     th.cuda.set_device(local)
+    if os.environ.get("CGD_BENCH_STREAM") == "1":  # A/B: the whole job on a created (non-null) HIP stream instead of the default stream
+        th.cuda.set_stream(th.cuda.Stream(device=local))
     dev = f"cuda:{local}"
     # CGD_FORCE_COLLECTIVES=1 (test knob): a ONE-rank job still initialises the process group and runs every collective of the N > 1
     # flow (weight broadcast, barriers, all_gather, all_reduce MAX) — RCCL on a 1-GPU box (tests/test_gpu_step.py)
