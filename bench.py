@@ -448,6 +448,15 @@ def main():
 
         def conv_leg(name, ms, flop, n, products, algo_bytes, pmc_name):
             ach = flop / (ms * 1e-3) / 1e12
+            if args.precision == "f32" and products < 1.0:
+                # exact-fp32 Winograd: the ALGORITHMIC rate (direct-convolution FLOP / time) can exceed the fp32-MFMA peak because F(2,3) executes
+                # 2/3 of the products; the roofline fraction of this line is therefore the EXECUTED product rate against the peak, the algorithmic
+                # rate rides along
+                leg = conv_leg(name, ms, flop * products, n, 1.0, algo_bytes, pmc_name)
+                leg["achieved_algorithmic"] = round(ach, 2)
+                leg["mfma_products_per_flop"] = products
+                leg["note"] = "achieved / frac count the executed fp32 products (Winograd F(2,3): 2/3 of the direct convolution's)"
+                return leg
             return {"kernel": name, "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4),
                     "traffic": pmc_traffic(pmc_name) if args.config == 2 else None,
                     "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass of this command; a constant in this line)",
