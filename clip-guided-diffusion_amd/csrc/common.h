@@ -111,6 +111,8 @@ struct cgd_ctx {
                         // over the wide tensor); 2: the 6-channel one (head dgrad) too; 0: the round-1 MFMA route (im2col + GEMM) for both
                         // (A/B knob CGD_THIN)
   int kconv_tw8 = 1;    // (round 5) kconv_kernel on 8 x 8-pixel tiles (two workgroups per CU) wherever W is a multiple of 8; 0: the 8 x 16 tile
+  int kconv_th16 = 0;   // (round 6) kconv_kernel on 16 x 16-pixel tiles for maps of at least this many pixels per image (H, W multiples of 16): 256 =
+                        // the 16 x 16 and 32 x 32 levels, 1024 = 32 x 32 only, 0 = off (7th field of CGD_KCONV)
   int kconv_ring = 2;   // weight-fragment register sets of kconv_kernel on 8 x 8 tiles: 2 = one chunk ahead, 3 = two chunks ahead (6th field of CGD_KCONV)
   int kconv_slots = 0;  // split-K target of kconv in workgroups (0 = one per CU, the rounds 3-4 policy).  CGD_KCONV="<mode>,<max pixels>,<min chunks>,
                         // <8x8 tiles>,<slots>,<ring>": kconv_tw8 is the 4th field, kconv_slots the 5th, kconv_ring the 6th
@@ -340,6 +342,7 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 bool cgd_kconv_supported(const cgd_ctx* ctx, const GemmParams& p);
 long cgd_kconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_kconv_tw(const cgd_ctx* ctx, const GemmParams& p);
+int cgd_kconv_th(const cgd_ctx* ctx, const GemmParams& p);
 int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& p, hipStream_t s);
 
 // ---- weight GEMM with pre-packed B fragments (hgemm.hip) ------------------------------------------------

@@ -42,15 +42,20 @@ constexpr int KNQ = 5;                 // k-step slots per wavefront and chunk (
 // one full tile instead of a half-empty one; and a map has twice the pixel tiles, so half the split-K slices fill the chip (32 x 32 maps: none).
 // Patch-row pitch: 768 / 448 bf16 elements keep the A-fragment ds_read_b128 conflict-free for 2 x 16 / 4 x 8 pixels per 32 lanes (brute-force
 // check over the instruction's four 16-lane groups).
-template <int TW>
+// TH = 16 (round 6, TW = 16 only): the 16 x 16-pixel tile — 8 pixel blocks per wavefront, 128 accumulators, one workgroup per CU.  The 8 x 8 tile
+// moves 36 KB of weight fragments + 13 KB of patch per 32-channel chunk for 27 MFMAs per wavefront: with every CU pulling, the L2s deliver ~70 GB/s per
+// CU (profiles/r6_lgemm_microbench.txt), i.e. 0.7 us per chunk against 0.41 us of MFMA issue — the 16 x 16 and 32 x 32 levels are bound by operand
+// delivery.  A 16 x 16 tile uses every weight fragment for 8 pixel blocks instead of 2 (2.5 x the MFMAs per delivered byte) and gets its workgroup count
+// back from split-K (4 slices at 32 x 32, 8 at 16 x 16: 4 chunks per slice, summed by the consuming GroupNorm like today's 2).
+template <int TW, int TH = KTH>
 struct KGeo {
   static constexpr int PW = TW + 2;                 // patch width
   static constexpr int HRS = TW == 16 ? 768 : 448;  // patch-row pitch
-  static constexpr int NP = (KTH + 2) * PW;         // patch rows: 180 / 100
-  static constexpr int PLANE = (KTH + 2) * HRS;
-  static constexpr int NPASS = (NP + 31) / 32;      // staging passes of 32 patch rows: 6 / 4
-  static constexpr int NPB = TW * KTH / 32;         // 32-pixel blocks per wavefront: 4 / 2
-  static constexpr int RP = NPB * 4;                // accumulator registers per final part (4 parts, one per wavefront): 16 / 8
+  static constexpr int NP = (TH + 2) * PW;          // patch rows: 180 / 100 / 324
+  static constexpr int PLANE = (TH + 2) * HRS;
+  static constexpr int NPASS = (NP + 31) / 32;      // staging passes of 32 patch rows: 6 / 4 / 11
+  static constexpr int NPB = TW * TH / 32;          // 32-pixel blocks per wavefront: 4 / 2 / 8
+  static constexpr int RP = NPB * 4;                // accumulator registers per final part (4 parts, one per wavefront): 16 / 8 / 32
 };
 
 struct KConvParams {
@@ -73,12 +78,13 @@ __device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) 
 
 // WR = weight-fragment register sets: 2 = the next chunk's fragments are fetched while a chunk is multiplied (rounds 3-4), 3 = TWO chunks ahead
 // NT = weight-fragment loads with the non-temporal policy (single-tile maps: every fragment is read by exactly one workgroup)
-template <int MODE, bool GN, int TW, int WR = 2, bool NT = false>
+template <int MODE, bool GN, int TW, int WR = 2, bool NT = false, int TH = KTH>
 __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                     const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
                                                     const float* __restrict__ gng, const KConvParams p) {
   constexpr int NPL = MODE == 1 ? 2 : 1;
-  typedef KGeo<TW> G;
+  typedef KGeo<TW, TH> G;
+  static_assert(TH == KTH || (TH == 16 && TW == 16 && WR == 2), "kconv: the 16-row tile is 16 pixels wide");
   constexpr int KPW = G::PW, KHRS = G::HRS, KNP = G::NP, KPLANE = G::PLANE, KNPASS = G::NPASS, NPB = G::NPB, RP = G::RP;
   // one array for everything: the patch double buffer, reused for the final cross-wavefront reduction (4 parts x 3 slabs of RP x 64 floats:
   // 48 / 24 KiB)
@@ -98,9 +104,9 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
   // weight-block major within an XCD's run: the pixel tiles that share a 32-channel weight block are neighbours on one XCD
   const int ntm = gridDim.x / nbN;
   const int mt = bid % ntm, nb = bid / ntm;
-  const int tpr = (p.W + TW - 1) / TW, tpi = (p.H / KTH) * tpr;
+  const int tpr = (p.W + TW - 1) / TW, tpi = (p.H / TH) * tpr;
   const int img = mt / tpi, trem = mt - img * tpi;
-  const int y0 = (trem / tpr) * KTH, x0 = (trem % tpr) * TW;
+  const int y0 = (trem / tpr) * TH, x0 = (trem % tpr) * TW;
   const int HW = p.H * p.W;
   const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.W >> 1) : p.W;
   const float* __restrict__ Aimg = Ag + (long)img * Hs * Ws * p.lda;
@@ -246,7 +252,11 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
       if (k + 1 < KNQ) K_A_LOAD(af[(k + 1) & 1], CUR, k + 1);                                       \
       K_B_LOAD(bq[((BS) + WR - 1) % WR][k], nbp, k);                                                \
       if (k < 4 || five) K_MFMA(af[k & 1], bq[BS][k]);                                              \
-      if (k < KNPASS / 2) K_PATCH_STORE((S) ^ 1, NXT, 2 * k, 2 * k + 2);                            \
+      if constexpr (TH == KTH) {                                                                    \
+        if (k < KNPASS / 2) K_PATCH_STORE((S) ^ 1, NXT, 2 * k, 2 * k + 2);                          \
+      } else { /* 11 passes over the 5 k-step slots: 3, 3, 3, 2 */                                  \
+        if (3 * k < KNPASS) K_PATCH_STORE((S) ^ 1, NXT, 3 * k, (3 * k + 3 < KNPASS ? 3 * k + 3 : KNPASS)); \
+      }                                                                                             \
       _Pragma("unroll") for (int r = 0; r < 3 * NPB; ++r) {                                         \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
         if (r % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
       const int slot = wave - (wave > pt ? 1 : 0);
       float* dst = red + ((pt * 3 + slot) * RP) * 64 + lane;
 #pragma unroll
-      for (int r = 0; r < RP; ++r) dst[r * 64] = acc[(pt * RP) / 16][(pt * RP) % 16 + r];
+      for (int r = 0; r < RP; ++r) dst[r * 64] = acc[(pt * RP + r) / 16][(pt * RP + r) % 16];
     }
   }
   __syncthreads();
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
   for (int pt = 0; pt < 4; ++pt)
     if (pt == wave) {  // wave-uniform select of this wavefront's own part
 #pragma unroll
-      for (int r = 0; r < RP; ++r) o[r] = acc[(pt * RP) / 16][(pt * RP) % 16 + r];
+      for (int r = 0; r < RP; ++r) o[r] = acc[(pt * RP + r) / 16][(pt * RP + r) % 16];
     }
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
@@ -308,40 +318,44 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     for (int r = 0; r < RP; ++r) o[r] += src[r * 64];
   }
 
-  // ---- epilogue for part `wave` (D = W x X^T: column = pixel l31 of its pixel block, accumulator quad g = channels 8g + 4hh .. + 3)
-  const int blk = (wave * RP) / 16, g0 = ((wave * RP) % 16) / 4;  // pixel block and first channel quad of the part
-  const int pix = blk * 32 + l31, ty = pix / TW, tx = pix % TW;
-  if (x0 + tx >= p.W) return;
-  const long mrow = (long)img * HW + (long)(y0 + ty) * p.W + x0 + tx;
+  // ---- epilogue for part `wave` (D = W x X^T: column = pixel l31 of its pixel block, accumulator quad g = channels 8g + 4hh .. + 3).  A part is RP
+  //      consecutive accumulator registers: half a pixel block (RP = 8), one (16) or two (32, the 16-row tile); quad qd of the part is register
+  //      wave * RP + 4 qd of the lane = (pixel block, channel quad) below
   const int cb0 = nb * 32;
-  if (p.splitk > 1) {
-    float* __restrict__ ws = wsg + (long)blockIdx.z * p.M * p.N;
+  float* __restrict__ ws = p.splitk > 1 ? wsg + (long)blockIdx.z * p.M * p.N : nullptr;
 #pragma unroll
-    for (int g = 0; g < RP / 4; ++g)
-      *(kf32x4*)&ws[mrow * p.N + cb0 + 8 * (g0 + g) + 4 * hh] = kf32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-    return;
-  }
-  kf32x4 rv[RP / 4];
-  if (Rg) {
-#pragma unroll
-    for (int g = 0; g < RP / 4; ++g) rv[g] = *(const kf32x4*)&Rg[mrow * p.ldr + cb0 + 8 * (g0 + g) + 4 * hh];
-  }
-#pragma unroll
-  for (int g = 0; g < RP / 4; ++g) {
-    const int col = cb0 + 8 * (g0 + g) + 4 * hh;
-    kf32x4 v = kf32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]} * p.alpha;
+  for (int qd = 0; qd < RP / 4; ++qd) {
+    const int reg = wave * RP + 4 * qd, blk = reg >> 4, g = (reg & 15) >> 2;
+    const int pix = blk * 32 + l31, ty = pix / TW, tx = pix % TW;
+    if (x0 + tx >= p.W) continue;
+    const long mrow = (long)img * HW + (long)(y0 + ty) * p.W + x0 + tx;
+    const int col = cb0 + 8 * g + 4 * hh;
+    kf32x4 v = kf32x4{o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
+    if (p.splitk > 1) {
+      *(kf32x4*)&ws[mrow * p.N + col] = v;
+      continue;
+    }
+    v = v * p.alpha;
     if (biasg) v += kf32x4{biasg[col], biasg[col + 1], biasg[col + 2], biasg[col + 3]};
-    if (Rg) v += rv[g];
+    if (Rg) v += *(const kf32x4*)&Rg[mrow * p.ldr + col];
     *(kf32x4*)&Cg[mrow * p.ldc + col] = v;
   }
 }
 
 }  // namespace
 
+// tile height: 16 (with TW = 16; round 6) for the bf16x3 maps of >= kconv_th16 pixels per image whose H and W are multiples of 16 (the 16 x 16 and
+// 32 x 32 levels; 0 = never), 8 otherwise
+int cgd_kconv_th(const cgd_ctx* ctx, const GemmParams& p) {
+  return (ctx->kconv_th16 > 0 && ctx->precision == CGD_PREC_BF16X3 && !(p.H & 15) && !(p.W & 15) && p.H * p.W >= ctx->kconv_th16) ? 16 : KTH;
+}
 // tile width of a launch: 8 where the map is a whole number of 8-pixel columns and the variant is on (ctx->kconv_tw8, default), 16 otherwise
-int cgd_kconv_tw(const cgd_ctx* ctx, const GemmParams& p) { return (ctx->kconv_tw8 && !(p.W & 7)) ? 8 : 16; }
+int cgd_kconv_tw(const cgd_ctx* ctx, const GemmParams& p) {
+  if (cgd_kconv_th(ctx, p) == 16) return 16;
+  return (ctx->kconv_tw8 && !(p.W & 7)) ? 8 : 16;
+}
 long cgd_kconv_tiles_m(const cgd_ctx* ctx, const GemmParams& p) {
-  return (long)(p.M / (p.H * p.W)) * (p.H / KTH) * cdiv(p.W, cgd_kconv_tw(ctx, p));
+  return (long)(p.M / (p.H * p.W)) * (p.H / cgd_kconv_th(ctx, p)) * cdiv(p.W, cgd_kconv_tw(ctx, p));
 }
 
 // same problems as hconv2 at TH = 8 (cgd_hconv_supported); the caller (cgd_plan_gemm) restricts it to small maps
@@ -358,6 +372,11 @@ int cgd_launch_kconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.M = g.M; p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.ups = g.ups; p.splitk = g.splitk; p.alpha = g.alpha;
   dim3 grid((int)(cgd_kconv_tiles_m(ctx, g) * (g.N >> 5)), 1, g.splitk > 1 ? g.splitk : 1);
   const int tw = cgd_kconv_tw(ctx, g);
+  if (cgd_kconv_th(ctx, g) == 16) {  // the 16 x 16-pixel tile (bf16x3 only)
+    if (g.gn_ab) CGD_LAUNCH((kconv_kernel<1, true, 16, 2, false, 16>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p);
+    else CGD_LAUNCH((kconv_kernel<1, false, 16, 2, false, 16>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p);
+    return 0;
+  }
 #define KC_LAUNCH(M_, GN_, TW_, WR_) \
   CGD_LAUNCH((kconv_kernel<M_, GN_, TW_, WR_>), grid, dim3(256), 0, s, g.A, (const uint4*)g.Bpk, g.C, g.bias, g.R, g.ws, g.gn_ab, p)
 #define KC_TW(M_, GN_) \

@@ -91,6 +91,18 @@ def test_conv_weight_streaming_variant_on_the_8x16_tile(monkeypatch):
     _assert_all(pc.check_unet("mini", 1))
 
 
+def test_conv_weight_streaming_variant_on_the_16x16_tile(monkeypatch):
+    """Round 6: CGD_KCONV=1,1024,4,1,0,2,256 puts the maps whose H and W are multiples of 16 on kconv_kernel's 16 x 16-pixel tile (8 pixel blocks per
+    wavefront, every weight fragment used for 8 blocks instead of 2; the workgroup count comes back from split-K): op level (16x16 / 32x32 / 48x32 /
+    64x64 maps, batch, upsampled input, explicit and automatic split-K, forward and backward-to-input) and inside UNets (fused GroupNorm staging,
+    slices summed by the consuming norms)."""
+    monkeypatch.setenv("CGD_KCONV", "1,1024,4,1,0,2,256")
+    _assert_all(pc.check_kconv(1))
+    _assert_all(pc.check_unet("mini", 1))
+    _assert_all(pc.check_unet("mini", 1, B=2, hw=(32, 48)))
+    _assert_all(pc.check_unet("cfg64", 1))
+
+
 def test_unet_small_maps_on_the_previous_kernels(monkeypatch):
     """CGD_KCONV=0 keeps the round-2 routing (hconv2 / igemm on the <= 32x32 maps) selectable: grade it as well."""
     monkeypatch.setenv("CGD_KCONV", "0")
