@@ -56,6 +56,7 @@ int cgd_ctx_create(cgd_ctx** out, int device) {
   if (const char* e = getenv("CGD_HGEMM_TM96")) ctx->hgemm_tm96 = atoi(e);
   if (const char* e = getenv("CGD_NT")) ctx->weight_nt = atoi(e);
   if (const char* e = getenv("CGD_KGEMM")) sscanf(e, "%d,%d,%d,%d,%d", &ctx->kgemm_mode, &ctx->kgemm_max_m, &ctx->kgemm_var, &ctx->kgemm_big_m, &ctx->kgemm_big_n);
+  if (const char* e = getenv("CGD_EMBED_FUSE")) ctx->embed_fuse = atoi(e);
   if (const char* e = getenv("CGD_KCONV")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &ctx->kconv_mode, &ctx->kconv_max_m, &ctx->kconv_min_chunks, &ctx->kconv_tw8, &ctx->kconv_slots, &ctx->kconv_ring, &ctx->kconv_th16);
   if (const char* e = getenv("CGD_HCONV_SPLIT")) sscanf(e, "%d,%d", &ctx->hconv_slots, &ctx->hconv_min_chunks);
   if (ctx->kconv_min_chunks < 1) ctx->kconv_min_chunks = 1;  // divisors of the split-K policy

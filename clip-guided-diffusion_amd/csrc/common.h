@@ -105,6 +105,8 @@ struct cgd_ctx {
                        // parity-tested (tile code 512), but no faster than igemm 64x64 + split-K on the step (22.07 vs 22.07-22.11 ms,
                        // same-box A/B round 2), so off by default
   int hconv_mode = 1, hconv_min_m = 256;                     // halo conv kernel: 0 off, 1 auto for M >= hconv_min_m (ops_r1i)
+  int embed_fuse = 1;   // (round 6) the UNet's embedding head as 3 GEMV launches that form their A rows on the fly instead of 8 launches (batches of <= 4;
+                        // A/B knob CGD_EMBED_FUSE)
   int gemv_mode = 1;    // 1: GEMMs with M <= 4 rows (the UNet's time / class embedding linears, 424 MB of FiLM projection weights per step) run
                         // on the weight-streaming GEMV kernel of gemm.hip (tile code 517); 0: the MFMA GEMM + split-K reduce (A/B knob CGD_GEMV)
   int thin_direct = 1;  // 1: the 3-channel INPUT-side conv (UNet stem forward) runs on the direct fp32 kernel of conv_thin.hip (one write pass
@@ -294,6 +296,14 @@ struct GemmParams {
   int gnb_ldx = 0, gnb_act = 0;
   int stats = 0;       // conv on wconv_kernel only: 1 = the epilogue also takes per-(half tile, channel) statistics of the output for the GroupNorm
                        // that reads it next (ChanStatsEntry); ignored by the other kernels (their consumers sweep the tensor as before)
+  // GEMV kernel only (M <= 4 rows; round 6): how the A rows are formed while they are loaded into LDS — what the UNet's embedding head used to run
+  // as separate one-workgroup launches in front of each of its three GEMVs.  0: A as is; 1: SiLU(A); 2: SiLU(A + a_table[a_idx[m]]) (the class
+  // embedding row added first); 3: the sinusoidal timestep embedding [cos(t[m] f) | sin(t[m] f)], f = a_freqs[K / 2] (A is not read)
+  int a_mode = 0;
+  const float* a_t = nullptr;
+  const float* a_freqs = nullptr;
+  const float* a_table = nullptr;
+  const int64_t* a_idx = nullptr;
   int defer = 0;       // 1: if the launch splits K, leave the slices in the workspace (ctx->pending): the caller guarantees that the
                        // next kernel reading C is one that consumes a SplitSrc (cgd_take_pending); anything else flushes first
 };
@@ -363,6 +373,8 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s);
 bool cgd_conv_uses_hconv(cgd_ctx* ctx, GemmParams p);
 // would cgd_launch_gemm run this GEMM on hgemm2 in one slice (the only path that fuses an activation into its epilogue)?
 bool cgd_gemm_fuses_act(cgd_ctx* ctx, GemmParams p);
+// would cgd_launch_gemm run this GEMM on the GEMV kernel (the only one that forms its A rows on the fly: GemmParams::a_mode)?
+bool cgd_gemm_is_gemv(cgd_ctx* ctx, GemmParams p);
 
 // thin direct convs for the 3-channel ends of the UNet
 int cgd_launch_conv_in(cgd_ctx* ctx, const float* x_nchw, const float* w /*[Cout][3][3][Cin] (co,ky,kx,ci)*/, const float* bias,

@@ -330,12 +330,39 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 // outputs x K = 1024 = 424 MB of fp32 weights for 0.2 GFLOP — a pure HBM stream.  On the MFMA GEMM it took 122 us (3.5 TB/s) plus a
 // split-K reduce; here a wavefront owns rows of B: 1 KiB coalesced loads (16 B per lane), four rows in flight (16 loads per lane),
 // exact fp32 FMAs against the A rows held in LDS, a 6-step butterfly per row.  No split-K, no workspace.
+// (round 6) the A rows can be FORMED while they are loaded (GemmParams::a_mode): the UNet's embedding head is timestep embedding -> GEMV -> SiLU ->
+// GEMV -> + class embedding -> SiLU -> GEMV; the five one-workgroup kernels between the GEMVs were five dependent launches (5-8 us of dispatch latency
+// each) for 1-4 K values apiece.  Every workgroup recomputes its own copy (<= 4096 values): same arithmetic as act_fwd_kernel /
+// timestep_embedding_kernel / embedding_add_kernel (elem.hip), so the results are bit-identical to the separate launches.
+struct GemvA {
+  int mode;
+  const float* t;
+  const float* freqs;
+  const float* table;
+  const int64_t* idx;
+};
 template <int MR>
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                    float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ R,
-                                                   int ldr, int N, int K, float alpha, int nt) {
+                                                   int ldr, int N, int K, float alpha, int nt, const GemvA am) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [MR][K]
-  for (int i = threadIdx.x; i < MR * K; i += 256) xs[i] = A[(long)(i / K) * lda + (i % K)];
+  if (am.mode == 0) {
+    for (int i = threadIdx.x; i < MR * K; i += 256) xs[i] = A[(long)(i / K) * lda + (i % K)];
+  } else if (am.mode == 3) {
+    const int half = K / 2;
+    for (int i = threadIdx.x; i < MR * K; i += 256) {
+      const int m = i / K, k = i % K;
+      const float a = am.t[m] * am.freqs[k < half ? k : k - half];
+      xs[i] = k < half ? cosf(a) : sinf(a);
+    }
+  } else {
+    for (int i = threadIdx.x; i < MR * K; i += 256) {
+      const int m = i / K, k = i % K;
+      float u = A[(long)m * lda + k];
+      if (am.mode == 2) u += am.table[am.idx[m] * (long)K + k];
+      xs[i] = u / (1.f + __expf(-u));  // SiLU, elem.hip act_f
+    }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -635,6 +662,14 @@ bool cgd_conv_uses_hconv(cgd_ctx* ctx, GemmParams p) {
   return ok;
 }
 
+bool cgd_gemm_is_gemv(cgd_ctx* ctx, GemmParams p) {
+  int tile = 0, kernel = 0;
+  const std::string keep = ctx->err;
+  const bool ok = cgd_plan_gemm(ctx, p, &tile, &kernel) == 0 && kernel == 3;
+  ctx->err = keep;
+  return ok;
+}
+
 bool cgd_gemm_fuses_act(cgd_ctx* ctx, GemmParams p) {
   int tile = 0, kernel = 0;
   const std::string keep = ctx->err;
@@ -682,6 +717,7 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   CGD_TRY(cgd_plan_gemm(ctx, p, &tile, &kernel));
   const bool use_h = kernel == 1, use_g = kernel == 2;
   if (p.gn_ab && !use_h) CGD_FAIL(ctx, "cgd_launch_gemm: only the halo conv kernel applies a GroupNorm on the fly (cgd_conv_uses_hconv)");
+  if (p.a_mode && kernel != 3) CGD_FAIL(ctx, "cgd_launch_gemm: only the GEMV kernel forms its A rows on the fly (cgd_gemm_is_gemv)");
   if (p.skip_group && !(use_g && p.splitk == 1)) CGD_FAIL(ctx, "cgd_launch_gemm: skip_group needs the weight GEMM kernel in one slice (cgd_gemm_fuses_act)");
   if ((p.act_out || p.act_in) && !(use_g && p.splitk == 1 && ctx->hgemm_var != 0))
     CGD_FAIL(ctx, "cgd_launch_gemm: only hgemm2 in one slice fuses an activation into its epilogue (cgd_gemm_fuses_act)");
@@ -691,7 +727,10 @@ int cgd_launch_gemm(cgd_ctx* ctx, GemmParams p, hipStream_t s) {
   if (kernel == 3) {
     const int blocks = (int)std::min<long>(std::max<long>(cdiv(p.N, 16), 1), 4L * ctx->num_cu);
     const size_t sh = (size_t)p.M * p.K * sizeof(float);
-#define GV_LAUNCH(MR_) CGD_LAUNCH((gemv_kernel<MR_>), dim3(blocks), dim3(256), sh, s, p.A, p.lda, p.B, p.ldb, p.C, p.ldc, p.bias, p.R, p.ldr, p.N, p.K, p.alpha, (ctx->weight_nt & 4) ? 1 : 0)
+    const GemvA am = {p.a_mode, p.a_t, p.a_freqs, p.a_table, p.a_idx};
+    if (p.a_mode == 3 && (!p.a_t || !p.a_freqs || (p.K & 1))) CGD_FAIL(ctx, "cgd_launch_gemm: a_mode 3 needs a_t, a_freqs and an even K");
+    if (p.a_mode == 2 && (!p.a_table || !p.a_idx)) CGD_FAIL(ctx, "cgd_launch_gemm: a_mode 2 needs a_table and a_idx");
+#define GV_LAUNCH(MR_) CGD_LAUNCH((gemv_kernel<MR_>), dim3(blocks), dim3(256), sh, s, p.A, p.lda, p.B, p.ldb, p.C, p.ldc, p.bias, p.R, p.ldr, p.N, p.K, p.alpha, (ctx->weight_nt & 4) ? 1 : 0, am)
     switch (p.M) {
       case 1: GV_LAUNCH(1); break;
       case 2: GV_LAUNCH(2); break;

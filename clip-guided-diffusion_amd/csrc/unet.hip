@@ -599,22 +599,33 @@ int UNet::embed(const float* t, const int64_t* y, int Bn, int slot, hipStream_t 
   CGD_TRY(ensure(e2, (size_t)Bn * ted));
   CGD_TRY(ensure(e2s, (size_t)Bn * ted));
   CGD_TRY(ensure(dst, (size_t)Bn * emb_total));
-  CGD_TRY(cgd_launch_timestep_embedding(ctx, t, freqs, temb.p, Bn, mc, s));
   GemmParams g1;
   g1.A = temb.p; g1.lda = mc; g1.B = P("time_embed.0.weight"); g1.ldb = mc; g1.C = e1.p; g1.ldc = ted; g1.bias = P("time_embed.0.bias");
   g1.M = Bn; g1.N = ted; g1.K = mc; g1.no_split = ahead;
-  CGD_TRY(cgd_launch_gemm(ctx, g1, s));
-  CGD_TRY(cgd_launch_act_fwd(ctx, e1.p, e1s.p, (long)Bn * ted, 1, s));
   GemmParams g2;
   g2.A = e1s.p; g2.lda = ted; g2.B = P("time_embed.2.weight"); g2.ldb = ted; g2.C = e2.p; g2.ldc = ted; g2.bias = P("time_embed.2.bias");
   g2.M = Bn; g2.N = ted; g2.K = ted; g2.no_split = ahead;
-  CGD_TRY(cgd_launch_gemm(ctx, g2, s));
-  if (cfg.num_classes > 0) CGD_TRY(cgd_launch_embedding_add(ctx, P("label_emb.weight"), y, e2.p, Bn, ted, s));
-  CGD_TRY(cgd_launch_act_fwd(ctx, e2.p, e2s.p, (long)Bn * ted, 1, s));
   GemmParams g3;
   g3.A = e2s.p; g3.lda = ted; g3.B = emb_w_all; g3.ldb = ted; g3.C = dst.p; g3.ldc = (int)emb_total; g3.bias = emb_b_all;
   g3.M = Bn; g3.N = (int)emb_total; g3.K = ted; g3.no_split = ahead;
-  CGD_TRY(cgd_launch_gemm(ctx, g3, s));
+  if (ctx->embed_fuse && cgd_gemm_is_gemv(ctx, g1) && cgd_gemm_is_gemv(ctx, g2) && cgd_gemm_is_gemv(ctx, g3)) {
+    // (round 6) batches of <= 4 rows: the three linears are GEMVs, and the GEMV kernel forms its A rows while it loads them — the sinusoidal
+    // embedding, SiLU(e1), SiLU(e2 + label_emb[y]): 3 launches instead of 8, bit-identical values (GemmParams::a_mode)
+    g1.a_mode = 3; g1.a_t = t; g1.a_freqs = freqs;
+    g2.A = e1.p; g2.a_mode = 1;
+    g3.A = e2.p; g3.a_mode = cfg.num_classes > 0 ? 2 : 1; g3.a_table = cfg.num_classes > 0 ? P("label_emb.weight") : nullptr; g3.a_idx = y;
+    CGD_TRY(cgd_launch_gemm(ctx, g1, s));
+    CGD_TRY(cgd_launch_gemm(ctx, g2, s));
+    CGD_TRY(cgd_launch_gemm(ctx, g3, s));
+  } else {
+    CGD_TRY(cgd_launch_timestep_embedding(ctx, t, freqs, temb.p, Bn, mc, s));
+    CGD_TRY(cgd_launch_gemm(ctx, g1, s));
+    CGD_TRY(cgd_launch_act_fwd(ctx, e1.p, e1s.p, (long)Bn * ted, 1, s));
+    CGD_TRY(cgd_launch_gemm(ctx, g2, s));
+    if (cfg.num_classes > 0) CGD_TRY(cgd_launch_embedding_add(ctx, P("label_emb.weight"), y, e2.p, Bn, ted, s));
+    CGD_TRY(cgd_launch_act_fwd(ctx, e2.p, e2s.p, (long)Bn * ted, 1, s));
+    CGD_TRY(cgd_launch_gemm(ctx, g3, s));
+  }
   emb_B[slot] = Bn;
   return 0;
 }

@@ -712,6 +712,30 @@ def check_unet(case, precision, B=1, hw=None, timestep=417.0):
     return [rec(f"{tag} forward", od, o.detach()), rec(f"{tag} dgrad", gx, xr.grad * sd)]
 
 
+def check_unet_embed_fusion():
+    """Round 6: the embedding head of the UNet as 3 GEMV launches that form their A rows on the fly (sinusoidal embedding, SiLU, class-embedding add:
+    GemmParams::a_mode) against the 8-launch chain (CGD_EMBED_FUSE=0): same arithmetic, so the outputs of a class-conditional model at batch 2 (integer and
+    fractional timesteps) must agree BIT FOR BIT."""
+    import os
+    outs = {}
+    for fuse in ("1", "0"):
+        os.environ["CGD_EMBED_FUSE"] = fuse
+        try:
+            ctx = _ctx(1)
+            _, dev = build_unet_pair(ctx, "mini")
+            kw = UNET_CASES["mini"]
+            B, H = 2, kw["image_size"]
+            x = th.randn(B, 3, H, H, generator=g(60)).to(DEV)
+            t = th.tensor([417.0, 3.5]).to(DEV)
+            y = th.randint(0, kw["num_classes"], (B,), generator=g(61)).to(DEV) if kw.get("num_classes") else None
+            outs[fuse] = dev.forward(x, t, y).clone()
+            th.cuda.synchronize()
+        finally:
+            os.environ.pop("CGD_EMBED_FUSE", None)
+    same = bool(th.equal(outs["1"], outs["0"]))
+    return same, float((outs["1"] - outs["0"]).abs().max())
+
+
 def check_unet_knob_toggle():
     """a knob change between forward() and dgrad() (cgd_set_wino(0): the dgrad convs leave wconv_kernel, so no backward-sum records
     are taken) and a SECOND dgrad() after one that did take records must both give the gradient of the default route — a GroupNorm backward

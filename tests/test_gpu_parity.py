@@ -200,6 +200,11 @@ def test_unet_exact_fp32_on_the_winograd_kernel_with_epilogue_records():
     _assert_all(pc.check_unet("mini", 0, B=2, hw=(128, 128)))
 
 
+def test_unet_embedding_head_as_three_gemvs_is_bit_identical_to_the_eight_launch_chain():
+    same, dmax = pc.check_unet_embed_fusion()
+    assert same, dmax
+
+
 def test_unet_dgrad_survives_a_knob_change_between_the_passes():
     _assert_all(pc.check_unet_knob_toggle())
 
