@@ -220,7 +220,7 @@ class GuidedSampler:
                 ahead.launch(model, 0, model_kwargs.get("y"))
             step_noise = tape["noise"][n].to(device).float().contiguous() if tape is not None else None
             with th.no_grad():
-                out = self._step(model, img, i, cond_fn, model_kwargs, step_noise, mode, bufs, ahead)
+                out = self._step(model, img, i, cond_fn, model_kwargs, step_noise, mode, bufs, *((ahead,) if ahead is not None else ()))
             if ahead is not None and tape is not None and rand_y and n + 1 >= len(tape["y"]):
                 ahead = None  # a replay tape shorter than the schedule (tests that run a few steps): the remaining steps run in line
             if ahead is not None and n + 1 < len(indices):
