@@ -44,19 +44,28 @@ constexpr int WROW = 1024;            // bf16 elements per patch row: 4 position
 constexpr int WSTEPS = 24;            // (ky, position, kstep) per 32-channel chunk
 constexpr int WRING = 8, WDIST = WRING - 1;
 
-// staging schedule (steps of a chunk): task k of the NEXT chunk is loaded at step w_load_task == k into slot k & 1 and transformed
-// in three pieces at the steps w_proc_task(q, piece) == k.  NB = 4 (16 tile rows, 12 MFMAs per step): 5 tasks, loaded every 4th
-// step, transformed 5..7 steps (1920 MFMA cycles) later.  NB = 2 (8 tile rows, 6 MFMAs per step): 3 tasks, loads at steps 0, 4 and
-// 13 (slot 0 is free after step 12), transformed from steps 10, 14 and 21.
+// staging schedule (steps of a chunk): task k of the NEXT chunk is loaded at step w_load_task == k into slot k & 1 and transformed in six pieces
+// (A = pixel 0, B = pixel 2 + position 0, C = pixel 1, D = positions 1 and 2, E = pixel 3, F = position 3) at the steps w_proc_task(q, piece) == k.
+// NB = 4 (16 tile rows, 12 MFMAs per step): 5 tasks, loaded every 4th step, transformed two pieces per step 5..7 steps (1920 MFMA cycles) later; the
+// two-workgroup variant likewise.  NB = 2 (8 tile rows, 6 or 12 MFMAs per step), round 6 (CGD_WCONV_FINE = 1): ONE piece per step — the fused
+// GroupNorm + SiLU of a pixel is 8 transcendentals per thread, about what a step's MFMAs cover — 3 tasks, loads at steps 0, 4 and 11 (slot 0 is free
+// after step 10), pieces at steps 5-10, 11-16 and 18-23.  CGD_WCONV_FINE = 0: the schedule of rounds 2-5 (two pieces per step from steps 10, 14, 21).
+#ifndef CGD_WCONV_FINE
+#define CGD_WCONV_FINE 1
+#endif
 template <int NB, int OCC = 1>
 __host__ __device__ constexpr int w_load_task(int q) {
   if (OCC == 2) return q == 0 ? 0 : q == 8 ? 1 : q == 16 ? 2 : -1;  // one staging register set: a task is transformed before the next is loaded
   if (NB == 4) return ((q & 3) == 0 && q < 20) ? (q >> 2) : -1;
-  return q == 0 ? 0 : q == 4 ? 1 : q == 13 ? 2 : -1;
+  return q == 0 ? 0 : q == 4 ? 1 : q == (CGD_WCONV_FINE ? 11 : 13) ? 2 : -1;
 }
 template <int NB, int OCC = 1>
 __host__ __device__ constexpr int w_proc_task(int q, int piece) {
-  const int s = q - piece;
+  if (NB == 2 && OCC == 1 && CGD_WCONV_FINE) {
+    const int s = q - piece;
+    return s == 5 ? 0 : s == 11 ? 1 : s == 18 ? 2 : -1;
+  }
+  const int s = q - (piece >> 1);
   if (OCC == 2) return s == 5 ? 0 : s == 13 ? 1 : s == 21 ? 2 : -1;
   if (NB == 4) return (s >= 5 && ((s - 5) & 3) == 0) ? ((s - 5) >> 2) : -1;
   return s == 10 ? 0 : s == 14 ? 1 : s == 21 ? 2 : -1;
@@ -261,23 +270,15 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
       *(wbf16x4*)&(DSTB)[WPLANE + wbase[J] + (XI) * 256] = w_bf16x4(w_residual4(t_, hi_));           \
     }                                                                                                \
   }
-  // a task is transformed in three pieces of similar VALU weight (one per step)
-#define W_TASK_P1(DSTB, ARR, J)                                                                      \
-  {                                                                                                  \
-    W_TASK_PIX(ARR, J, 0) W_TASK_PIX(ARR, J, 2)                                                      \
-    W_TASK_PUT(DSTB, J, 0, ARR[0] - ARR[2])                                                          \
-  }
-#define W_TASK_P2(DSTB, ARR, J)                                                                      \
-  {                                                                                                  \
-    W_TASK_PIX(ARR, J, 1)                                                                            \
-    W_TASK_PUT(DSTB, J, 1, ARR[1] + ARR[2])                                                          \
-    W_TASK_PUT(DSTB, J, 2, ARR[2] - ARR[1])                                                          \
-  }
-#define W_TASK_P3(DSTB, ARR, J)                                                                      \
-  {                                                                                                  \
-    W_TASK_PIX(ARR, J, 3)                                                                            \
-    W_TASK_PUT(DSTB, J, 3, ARR[1] - ARR[3])                                                          \
-  }
+  // a task is transformed in six pieces (w_proc_task)
+#define W_TASK_PA(DSTB, ARR, J) { W_TASK_PIX(ARR, J, 0) }
+#define W_TASK_PB(DSTB, ARR, J) { W_TASK_PIX(ARR, J, 2) W_TASK_PUT(DSTB, J, 0, ARR[0] - ARR[2]) }
+#define W_TASK_PC(DSTB, ARR, J) { W_TASK_PIX(ARR, J, 1) }
+#define W_TASK_PD(DSTB, ARR, J) { W_TASK_PUT(DSTB, J, 1, ARR[1] + ARR[2]) W_TASK_PUT(DSTB, J, 2, ARR[2] - ARR[1]) }
+#define W_TASK_PE(DSTB, ARR, J) { W_TASK_PIX(ARR, J, 3) }
+#define W_TASK_PF(DSTB, ARR, J) { W_TASK_PUT(DSTB, J, 3, ARR[1] - ARR[3]) }
+#define W_TASK_ALL(DSTB, ARR, J) \
+  { W_TASK_PA(DSTB, ARR, J) W_TASK_PB(DSTB, ARR, J) W_TASK_PC(DSTB, ARR, J) W_TASK_PD(DSTB, ARR, J) W_TASK_PE(DSTB, ARR, J) W_TASK_PF(DSTB, ARR, J) }
   // A fragments of step Q = (ky * 4 + xi) * 2 + ks: [block][plane]
 #define W_A_LOAD(DST, SRCB, Q)                                                                       \
   {                                                                                                  \
@@ -325,9 +326,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     for (int j = 0; j < NTASK; ++j) W_TASK_LOAD(pro[j], j, 0);
 #pragma unroll
     for (int j = 0; j < NTASK; ++j) {
-      W_TASK_P1(lds, pro[j], j);
-      W_TASK_P2(lds, pro[j], j);
-      W_TASK_P3(lds, pro[j], j);
+      W_TASK_ALL(lds, pro[j], j);
     }
   }
   __syncthreads();
@@ -358,13 +357,17 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
       W_MFMA12((q >> 1) & 3, af[q & 1], bq[q % RING]);
       if constexpr (!(CGD_WCONV_EXP & 2)) {
         const int k1 = w_proc_task<NB, OCC>(q, 0), k2 = w_proc_task<NB, OCC>(q, 1), k3 = w_proc_task<NB, OCC>(q, 2);
-        if (k1 >= 0) W_TASK_P1(nxt, pr[k1 & PM], (k1 < 0 ? 0 : k1));
-        if (k2 >= 0) W_TASK_P2(nxt, pr[k2 & PM], (k2 < 0 ? 0 : k2));
-        if (k3 >= 0) W_TASK_P3(nxt, pr[k3 & PM], (k3 < 0 ? 0 : k3));
+        const int k4 = w_proc_task<NB, OCC>(q, 3), k5 = w_proc_task<NB, OCC>(q, 4), k6 = w_proc_task<NB, OCC>(q, 5);
+        if (k1 >= 0) W_TASK_PA(nxt, pr[k1 & PM], (k1 < 0 ? 0 : k1));
+        if (k2 >= 0) W_TASK_PB(nxt, pr[k2 & PM], (k2 < 0 ? 0 : k2));
+        if (k3 >= 0) W_TASK_PC(nxt, pr[k3 & PM], (k3 < 0 ? 0 : k3));
+        if (k4 >= 0) W_TASK_PD(nxt, pr[k4 & PM], (k4 < 0 ? 0 : k4));
+        if (k5 >= 0) W_TASK_PE(nxt, pr[k5 & PM], (k5 < 0 ? 0 : k5));
+        if (k6 >= 0) W_TASK_PF(nxt, pr[k6 & PM], (k6 < 0 ? 0 : k6));
       }
       if constexpr (!(CGD_WCONV_EXP & 16) && !F32) {
         const bool loads = w_load_task<NB, OCC>(q) >= 0;
-        const bool puts = w_proc_task<NB, OCC>(q, 0) >= 0 || w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 2) >= 0;
+        const bool puts = w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 3) >= 0 || w_proc_task<NB, OCC>(q, 5) >= 0;
         constexpr int NM = 3 * NB * NC;  // MFMAs per step: 12 (16-row tile, or 8-row tile x 2 channel blocks) or 6
 #pragma unroll
         for (int r = 0; r < NM; ++r) {
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
         // fp32 products: 8 NB NC MFMAs of 64 cycles per step; the step's loads and the staging VALU (GroupNorm + SiLU: two transcendentals per
         // element) are spread behind them instead of being left in one block, which the compiler's own order does
         const bool loads = w_load_task<NB, OCC>(q) >= 0;
-        const bool puts = w_proc_task<NB, OCC>(q, 0) >= 0 || w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 2) >= 0;
+        const bool puts = w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 3) >= 0 || w_proc_task<NB, OCC>(q, 5) >= 0;
         constexpr int NM = 8 * NB * NC;
 #pragma unroll
         for (int r = 0; r < NM; ++r) {
@@ -400,9 +403,13 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
 #undef W_GN_LOAD
 #undef W_TASK_PIX
 #undef W_TASK_PUT
-#undef W_TASK_P1
-#undef W_TASK_P2
-#undef W_TASK_P3
+#undef W_TASK_PA
+#undef W_TASK_PB
+#undef W_TASK_PC
+#undef W_TASK_PD
+#undef W_TASK_PE
+#undef W_TASK_PF
+#undef W_TASK_ALL
 #undef W_A_LOAD
 #undef W_B_LOAD
 #undef W_MFMA12
@@ -624,10 +631,10 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
 
 // host-only view of the staging schedule for the CPU tests: out4 = {task loaded at step q, tasks whose piece 1 / 2 / 3 is
 // transformed at step q} (-1 = none) for nb = 4 (16-row tiles) or 2 (8-row tiles)
-extern "C" int cgd_op_wconv_schedule(int nb, int q, int* out4) {
-  if (!out4 || (nb != 4 && nb != 2) || q < 0 || q >= WSTEPS) return -3;
-  out4[0] = nb == 4 ? w_load_task<4>(q) : w_load_task<2>(q);
-  for (int piece = 0; piece < 3; ++piece) out4[1 + piece] = nb == 4 ? w_proc_task<4>(q, piece) : w_proc_task<2>(q, piece);
+extern "C" int cgd_op_wconv_schedule(int nb, int q, int* out7) {
+  if (!out7 || (nb != 4 && nb != 2) || q < 0 || q >= WSTEPS) return -3;
+  out7[0] = nb == 4 ? w_load_task<4>(q) : w_load_task<2>(q);
+  for (int piece = 0; piece < 6; ++piece) out7[1 + piece] = nb == 4 ? w_proc_task<4>(q, piece) : w_proc_task<2>(q, piece);
   return 0;
 }
 

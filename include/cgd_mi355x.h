@@ -261,9 +261,9 @@ int64_t cgd_op_gn_record_merges(cgd_ctx* ctx);
  * them with float64 group statistics) */
 int64_t cgd_op_gn_stats_offset(int B, int HW, int C);
 /* host-only (no GPU, no context): the software pipeline of wconv_kernel's patch staging inside one 24-step channel chunk, nb = 4 (16-row
- * tiles) or 2 (8-row tiles): out4 = {task whose 4 pixel loads are issued at step q, tasks whose transform piece 1 / 2 / 3 runs at step
+ * tiles) or 2 (8-row tiles): out7 = {task whose 4 pixel loads are issued at step q, tasks whose transform piece 1 ... 6 runs at step
  * q}, -1 = none; task k lives in register slot k & 1.  CPU tests check that no slot is reloaded while its task is still live. */
-int cgd_op_wconv_schedule(int nb, int q, int* out4);
+int cgd_op_wconv_schedule(int nb, int q, int* out7);
 /* box calibration (bench.py `box_calibration`): a register-resident v_mfma_f32_32x32x16_bf16 loop, one wavefront per SIMD
  * on every CU, `iters` x 12 MFMAs per wavefront: no memory traffic, so its rate is what the box's clock / power state gives the matrix pipes.
  * flop_out (optional, host): the FLOP of the launch; time it with events on `stream`. */

@@ -128,9 +128,10 @@ int main() {
     EXPECT(cgd_op_plan(0, 800, 768, 770, 0, 0, 0, 1, 1, 256, out4) == -2);   // K not a multiple of 4
     EXPECT(cgd_op_plan(1, 4096, 64, 0, 64, 64, 48, 1, 1, 256, out4) == -2);  // conv Cin not a multiple of 32
     EXPECT(cgd_op_plan(0, 800, 768, 768, 0, 0, 0, 1, 1, 256, nullptr) == -3);
+    int out7[7];  // {load task, the six transform pieces}
     for (int nb : {2, 4})
-      for (int q = 0; q < 24; ++q) EXPECT(cgd_op_wconv_schedule(nb, q, out4) == 0);
-    EXPECT(cgd_op_wconv_schedule(2, 24, out4) != 0);
+      for (int q = 0; q < 24; ++q) EXPECT(cgd_op_wconv_schedule(nb, q, out7) == 0);
+    EXPECT(cgd_op_wconv_schedule(2, 24, out7) != 0);
     EXPECT(cgd_op_wconv_schedule(4, 0, nullptr) != 0);
   }
 

@@ -41,28 +41,29 @@ def test_lds_transposed_epilogues_round_trip_and_are_bank_conflict_free():
 
 
 def test_staging_schedule_never_reloads_a_live_register_slot():
-    """Task k of the next chunk is loaded into slot k & 1 and transformed in three pieces later in the same chunk: every task is loaded
-    and transformed exactly once, in order, with >= 5 steps of load latency covered, and a slot is only reloaded after the last piece
-    of its previous task (the load is issued at the top of a step, the pieces after the step's MFMAs)."""
+    """Task k of the next chunk is loaded into slot k & 1 and transformed in six pieces later in the same chunk (one or two per step): every
+    task is loaded and transformed exactly once, in order, with >= 5 steps of load latency covered, and a slot is only reloaded after the
+    last piece of its previous task (the load is issued at the top of a step, the pieces after the step's MFMAs)."""
     handle = lib.load()
     for nb, ntask in ((4, 5), (2, 3)):
         load, pieces = {}, {}
         for q in range(24):
-            out = (C.c_int * 4)()
+            out = (C.c_int * 7)()
             assert handle.cgd_op_wconv_schedule(nb, q, out) == 0
             if out[0] >= 0:
                 assert out[0] not in load
                 load[out[0]] = q
-            for piece in range(3):
+            for piece in range(6):
                 if out[1 + piece] >= 0:
                     assert (out[1 + piece], piece) not in pieces
                     pieces[(out[1 + piece], piece)] = q
-        assert sorted(load) == list(range(ntask)) and sorted(pieces) == [(k, p) for k in range(ntask) for p in range(3)]
+        assert sorted(load) == list(range(ntask)) and sorted(pieces) == [(k, p) for k in range(ntask) for p in range(6)]
         for k in range(ntask):
-            assert load[k] + 5 <= pieces[(k, 0)] < pieces[(k, 1)] < pieces[(k, 2)] <= 23
+            steps = [pieces[(k, p)] for p in range(6)]
+            assert load[k] + 5 <= steps[0] and steps == sorted(steps) and steps[-1] <= 23
             if k >= 2:  # slot k & 1 held task k - 2
-                assert load[k] > pieces[(k - 2, 2)]
-        assert handle.cgd_op_wconv_schedule(3, 0, (C.c_int * 4)()) == -3 and handle.cgd_op_wconv_schedule(4, 24, (C.c_int * 4)()) == -3
+                assert load[k] > pieces[(k - 2, 5)]
+        assert handle.cgd_op_wconv_schedule(3, 0, (C.c_int * 7)()) == -3 and handle.cgd_op_wconv_schedule(4, 24, (C.c_int * 7)()) == -3
 
 
 def _split(x):
