@@ -136,8 +136,10 @@ struct cgd_ctx {
                        // profiles/r5_ab_attention_small_T_fused_bwd.txt); 0 = attn_mid_* / attn_s64_* of attn.hip (A/B knob CGD_ATTN_FLASH)
   int fuse_act = 1;    // 1: the ViT's QuickGELU (forward and backward) runs in the epilogue of the MLP GEMMs (A/B knob)
   int fuse_gn_skip_m = 0;  // A/B: convs of exactly this many pixels read a materialised normalised tensor instead (4th field of CGD_FUSE_GN)
-  int fuse_gn_max_m = 1 << 30, fuse_gn_min_m = 0;  // ... only for convs of at most / at least this many pixels (A/B knob,
-                                                   // CGD_FUSE_GN="1,<max pixels>,<min pixels>")
+  int fuse_gn_max_m = 1 << 30, fuse_gn_min_m = 4096;  // ... only for convs of at most / at least this many pixels (CGD_FUSE_GN="1,<max pixels>,<min
+                                                      // pixels>").  Round 6: the <= 32 x 32 maps read a materialised normalised tensor again — a kconv_kernel
+                                                      // workgroup owns ONE 32-channel output block, so a 512-1024-channel layer evaluated the SiLU of every
+                                                      // patch 16-32 times, more VALU cycles per chunk than its MFMAs (-0.05 ms, profiles/r6_ab_fuse_gn_small_maps.txt)
   int fuse_gn = 1;     // 1: ResBlock convs on the halo kernel apply their GroupNorm + FiLM + SiLU while staging (A/B knob)
   int tile_order = 0;  // XCD tile order of hgemm2 / hconv2: 0 auto (weight-panel major when the weights are the larger operand),
                        // 1 always weight-panel (N) major, 2 always row-panel (M) major (A/B knob)

@@ -76,6 +76,11 @@ __device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) 
   return kf32x4{v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]};
 }
 
+// CGD_KCONV_FINE = 1 (round 6): the conversion passes of the next patch run one per k-step slot instead of two in each of the first slots (the fused
+// GroupNorm + SiLU of a pass is 8 quarter-rate transcendentals per thread, about what the 6 MFMAs of a slot cover); 0 = the order of rounds 3-5
+#ifndef CGD_KCONV_FINE
+#define CGD_KCONV_FINE 1
+#endif
 // WR = weight-fragment register sets: 2 = the next chunk's fragments are fetched while a chunk is multiplied (rounds 3-4), 3 = TWO chunks ahead
 // NT = weight-fragment loads with the non-temporal policy (single-tile maps: every fragment is read by exactly one workgroup)
 template <int MODE, bool GN, int TW, int WR = 2, bool NT = false, int TH = KTH>
@@ -252,7 +257,9 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
       if (k + 1 < KNQ) K_A_LOAD(af[(k + 1) & 1], CUR, k + 1);                                       \
       K_B_LOAD(bq[((BS) + WR - 1) % WR][k], nbp, k);                                                \
       if (k < 4 || five) K_MFMA(af[k & 1], bq[BS][k]);                                              \
-      if constexpr (TH == KTH) {                                                                    \
+      if constexpr (CGD_KCONV_FINE && TH == KTH) { /* round 6: the passes spread evenly over the k-step slots (4 passes: 1, 1, 1, 1, 0) */ \
+        K_PATCH_STORE((S) ^ 1, NXT, (k * KNPASS + KNQ - 1) / KNQ, ((k + 1) * KNPASS + KNQ - 1) / KNQ); \
+      } else if constexpr (TH == KTH) {                                                             \
         if (k < KNPASS / 2) K_PATCH_STORE((S) ^ 1, NXT, 2 * k, 2 * k + 2);                          \
       } else { /* 11 passes over the 5 k-step slots: 3, 3, 3, 2 */                                  \
         if (3 * k < KNPASS) K_PATCH_STORE((S) ^ 1, NXT, 3 * k, (3 * k + 3 < KNPASS ? 3 * k + 3 : KNPASS)); \

@@ -53,6 +53,17 @@ constexpr int WRING = 8, WDIST = WRING - 1;
 #ifndef CGD_WCONV_FINE
 #define CGD_WCONV_FINE 1
 #endif
+// the last chunk of a workgroup runs a copy of the scheduled region without staging and without weight prefetch: 2 (default) = in every instantiation,
+// 1 = in the one-channel-block instantiations (NC = 1) only, 0 = it re-stages itself (rounds 2-5).
+// CGD_WCONV_RING2 = weight-fragment ring depth of the two-channel-block instantiations: 6 (default) frees the 32 registers the second copy of the loop
+// needs — with the 8-step ring of the other instantiations the NC = 2 kernels spill 9-20 registers, and a dispatch that needs scratch costs +3.7 us.
+// Same-box (profiles/r6_ab_wconv_peel_variants.txt): peel 0 / ring 8 18.31 ms per step, 0 / 6 18.29, 1 / 8 18.30, 2 / 8 (scratch) 18.50, 2 / 6 18.22.
+#ifndef CGD_WCONV_PEEL
+#define CGD_WCONV_PEEL 2
+#endif
+#ifndef CGD_WCONV_RING2
+#define CGD_WCONV_RING2 6
+#endif
 template <int NB, int OCC = 1>
 __host__ __device__ constexpr int w_load_task(int q) {
   if (OCC == 2) return q == 0 ? 0 : q == 8 ? 1 : q == 16 ? 2 : -1;  // one staging register set: a task is transformed before the next is loaded
@@ -175,7 +186,9 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
 
   static_assert(OCC == 1 || (NB == 2 && NC == 1), "two workgroups per CU: 8-row tile, one channel block");
   // weight-fragment ring (steps); the hand-interleaved fp32 schedule (CGD_WCONV_F32_SCHED) needs the registers a 4-step ring frees
-  constexpr int RING = (OCC == 2 || (F32 && CGD_WCONV_F32_SCHED)) ? 4 : WRING, DIST = RING - 1;
+  constexpr int RING = (OCC == 2 || (F32 && CGD_WCONV_F32_SCHED)) ? 4 : (NC == 2 ? CGD_WCONV_RING2 : WRING), DIST = RING - 1;
+  static_assert(WSTEPS % RING == 0, "the ring slot of a step must not depend on the chunk");
+  constexpr bool PEEL = CGD_WCONV_PEEL > 1 || (CGD_WCONV_PEEL == 1 && NC == 1);
   constexpr int TN = 128 * NC;  // output channels per workgroup
   const int ntn = (p.N + TN - 1) / TN;
   int bid = blockIdx.x;
@@ -332,30 +345,42 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
   __syncthreads();
   w_skew(wave);
   W_STAMP(1);
-  for (int c = 0; c < nchunk; ++c) {
+  // Two copies of the chunk body (the unrolled `ph` loop makes `stage` a compile-time constant in each): chunks 0 .. n - 2 stage their successor's
+  // patch and prefetch its first weight fragments; the LAST chunk (round 6) does neither — it used to re-stage itself into the idle buffer to keep one
+  // copy of the scheduled region, i.e. 1 / nchunk of all patch loads, GroupNorm + SiLU evaluations, transforms and LDS writes were thrown away
+  // (CGD_WCONV_PEEL = 0: that variant)
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+  const bool stage = PEEL ? ph == 0 : true;
+  const int cbeg = PEEL ? (ph == 0 ? 0 : (nchunk > 0 ? nchunk - 1 : 0)) : (ph == 0 ? 0 : nchunk);
+  const int cend = PEEL ? (ph == 0 ? nchunk - 1 : nchunk) : nchunk;
+  for (int c = cbeg; c < cend; ++c) {
     const bool more = c + 1 < nchunk;
-    const int cn = more ? c + 1 : c;  // the last chunk re-stages itself into the idle buffer: no branch in the scheduled region
+    const int cn = more ? c + 1 : c;  // (CGD_WCONV_PEEL = 0: the last chunk re-stages itself into the idle buffer: no branch in the scheduled region)
     const __bf16* cur = lds + (c & 1) * (2 * WPLANE);
     __bf16* nxt = lds + ((c & 1) ^ 1) * (2 * WPLANE);
     const uint4* __restrict__ cb = Bw0 + (long)c * (WSTEPS * 128);
     const uint4* __restrict__ nb = Bw0 + (long)cn * (WSTEPS * 128);
-    W_GN_LOAD(cn);
+    if (stage) W_GN_LOAD(cn);
     W_A_LOAD(af[0], cur, 0);
 #pragma unroll
     for (int q = 0; q < WSTEPS; ++q) {
       // ---- issue: A fragments one step ahead, B fragments WDIST steps ahead, one staging task every 4 steps
       if constexpr (!(CGD_WCONV_EXP & 8))
         if (q + 1 < WSTEPS) W_A_LOAD(af[(q + 1) & 1], cur, q + 1);
+      const bool bload = stage || q + DIST < WSTEPS;  // the last chunk has no successor whose fragments to prefetch
       if constexpr (!(CGD_WCONV_EXP & 1)) {
-        const int q2 = (q + DIST) % WSTEPS;
-        const uint4* __restrict__ base = (q + DIST < WSTEPS) ? cb : nb;
-        W_B_LOAD(bq[(q + DIST) % RING], base, q2);
+        if (bload) {
+          const int q2 = (q + DIST) % WSTEPS;
+          const uint4* __restrict__ base = (q + DIST < WSTEPS) ? cb : nb;
+          W_B_LOAD(bq[(q + DIST) % RING], base, q2);
+        }
       }
-      const int lt = w_load_task<NB, OCC>(q);  // (folded: q is a constant in the unrolled loop)
+      const int lt = stage ? w_load_task<NB, OCC>(q) : -1;  // (folded: q and stage are constants in the unrolled loops)
       if constexpr (!(CGD_WCONV_EXP & 2))
         if (lt >= 0) W_TASK_LOAD(pr[lt & PM], (lt < 0 ? 0 : lt), cn);
       W_MFMA12((q >> 1) & 3, af[q & 1], bq[q % RING]);
-      if constexpr (!(CGD_WCONV_EXP & 2)) {
+      if constexpr (!(CGD_WCONV_EXP & 2)) if (stage) {
         const int k1 = w_proc_task<NB, OCC>(q, 0), k2 = w_proc_task<NB, OCC>(q, 1), k3 = w_proc_task<NB, OCC>(q, 2);
         const int k4 = w_proc_task<NB, OCC>(q, 3), k5 = w_proc_task<NB, OCC>(q, 4), k6 = w_proc_task<NB, OCC>(q, 5);
         if (k1 >= 0) W_TASK_PA(nxt, pr[k1 & PM], (k1 < 0 ? 0 : k1));
@@ -366,24 +391,24 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
         if (k6 >= 0) W_TASK_PF(nxt, pr[k6 & PM], (k6 < 0 ? 0 : k6));
       }
       if constexpr (!(CGD_WCONV_EXP & 16) && !F32) {
-        const bool loads = w_load_task<NB, OCC>(q) >= 0;
-        const bool puts = w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 3) >= 0 || w_proc_task<NB, OCC>(q, 5) >= 0;
+        const bool loads = stage && w_load_task<NB, OCC>(q) >= 0;
+        const bool puts = stage && (w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 3) >= 0 || w_proc_task<NB, OCC>(q, 5) >= 0);
         constexpr int NM = 3 * NB * NC;  // MFMAs per step: 12 (16-row tile, or 8-row tile x 2 channel blocks) or 6
 #pragma unroll
         for (int r = 0; r < NM; ++r) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       // MFMA
           if (r < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // DS read (2 NB per step)
-          if (NC == 2 ? r >= 8 : (NB == 4 ? (r == 8 || r == 10) : (r == 4 || r == 5))) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 2 NC weight fragments
+          if (bload && (NC == 2 ? r >= 8 : (NB == 4 ? (r == 8 || r == 10) : (r == 4 || r == 5)))) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 2 NC weight fragments
           if (loads && (NM == 12 ? (r & 1) && r < 8 : r < 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 4 patch loads
-          __builtin_amdgcn_sched_group_barrier(0x002, (GN ? 6 : 3) * (NM == 12 ? 1 : 2), 0);      // VALU
+          if (stage) __builtin_amdgcn_sched_group_barrier(0x002, (GN ? 6 : 3) * (NM == 12 ? 1 : 2), 0);      // VALU
           if (puts && (NM == 12 ? (r % 3) == 2 : r >= 2)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (<= 4 per step)
         }
       }
       if constexpr (F32 && CGD_WCONV_F32_SCHED) {
         // fp32 products: 8 NB NC MFMAs of 64 cycles per step; the step's loads and the staging VALU (GroupNorm + SiLU: two transcendentals per
         // element) are spread behind them instead of being left in one block, which the compiler's own order does
-        const bool loads = w_load_task<NB, OCC>(q) >= 0;
-        const bool puts = w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 3) >= 0 || w_proc_task<NB, OCC>(q, 5) >= 0;
+        const bool loads = stage && w_load_task<NB, OCC>(q) >= 0;
+        const bool puts = stage && (w_proc_task<NB, OCC>(q, 1) >= 0 || w_proc_task<NB, OCC>(q, 3) >= 0 || w_proc_task<NB, OCC>(q, 5) >= 0);
         constexpr int NM = 8 * NB * NC;
 #pragma unroll
         for (int r = 0; r < NM; ++r) {
@@ -398,6 +423,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     if constexpr (!(CGD_WCONV_EXP & 4)) __syncthreads();  // patch c consumed by every wavefront, patch c + 1 written
     if (c + 1 < nchunk) w_skew(wave);
     W_STAMP(2 + (c < 27 ? c : 27));
+  }
   }
 #undef W_TASK_LOAD
 #undef W_GN_LOAD
@@ -416,6 +442,12 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
 
   // ---- epilogue: output transform in registers.  D = U x V^T in the 32x32 C/D layout: column (lane & 31) = pixel pair, row =
   //      channel (r & 3) + 8 (r >> 2) + 4 hh: accumulator quad g holds channels 8g + 4hh .. + 3 of the lane's pair.
+  // The epilogue's lane geometry is re-derived from a laundered thread id: the compiler would otherwise compute its addresses before the chunk loops and,
+  // in the 512-register instantiations (NC = 2), spill them across the loops.
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  {
+  const int lane = tid_e & 63, wave = tid_e >> 6, hh = lane >> 5, lr = (lane & 31) >> 3, lp = lane & 7;
 #pragma unroll
   for (int cj = 0; cj < NC; ++cj) {  // one 32-channel block of the wavefront at a time (the slab holds one)
   const int cb0 = (nb0 + cj) * 32;
@@ -582,6 +614,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     }
   }
   }  // cj
+  }
   W_STAMP(30);
 #ifdef CGD_WCONV_STAMPS
   if (lane == 0)
