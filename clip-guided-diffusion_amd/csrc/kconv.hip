@@ -81,6 +81,12 @@ __device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) 
 #ifndef CGD_KCONV_FINE
 #define CGD_KCONV_FINE 1
 #endif
+// CGD_KCONV_PEEL = 1 (round 6 experiment, default 0): the last two chunks of a slice run copies of the chunk body without the loads / conversions nobody
+// consumes (K_CHUNK) — what pays in wconv_kernel does not here: 162 -> 226 registers for the eight copies of the body and +0.03 ms per step in four
+// same-box pairs (profiles/r6_ab_kconv_peel.txt)
+#ifndef CGD_KCONV_PEEL
+#define CGD_KCONV_PEEL 0
+#endif
 // WR = weight-fragment register sets: 2 = the next chunk's fragments are fetched while a chunk is multiplied (rounds 3-4), 3 = TWO chunks ahead
 // NT = weight-fragment loads with the non-temporal policy (single-tile maps: every fragment is read by exactly one workgroup)
 template <int MODE, bool GN, int TW, int WR = 2, bool NT = false, int TH = KTH>
@@ -248,16 +254,20 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     // chunk C (ring set S, LDS buffer CUR): fetch patch C + 2 into staging set S, write patch C + 1 (staging set S ^ 1, fetched during
     // chunk C - 1; for the first chunk a harmless rewrite of what the prologue stored) into NXT, fetch the fragments of chunk C + 1
     // (BS = weight set of chunk C = (C - c0) % WR; the fragments of chunk C + WR - 1 go into set (BS + WR - 1) % WR)
-#define K_CHUNK(S, CUR, NXT, C, BS)                                                                 \
+  // LP / SP / LB (compile-time 0 / 1): fetch patch C + 2 / convert and write patch C + 1 / fetch the fragments of chunk C + WR - 1.  Round 6
+  // (CGD_KCONV_PEEL): the last chunks of a slice switch off what has no consumer — they used to run everything on clamped chunk indices, i.e. a
+  // slice of n chunks fetched (n + 1) / n of its weight fragments through the CU's vector-memory path, which is what bounds this kernel
+#define K_CHUNK(S, CUR, NXT, C, BS, LP, SP, LB)                                                     \
   {                                                                                                 \
     const uint4* __restrict__ nbp = Bw0 + (long)((C) + WR - 1 < c1 ? (C) + WR - 1 : c1 - 1) * (9 * 4 * 64); \
-    K_PATCH_LOAD(S, (C) + 2);                                                                       \
+    if constexpr (LP) K_PATCH_LOAD(S, (C) + 2);                                                     \
     K_A_LOAD(af[0], CUR, 0);                                                                        \
     _Pragma("unroll") for (int k = 0; k < KNQ; ++k) {                                               \
       if (k + 1 < KNQ) K_A_LOAD(af[(k + 1) & 1], CUR, k + 1);                                       \
-      K_B_LOAD(bq[((BS) + WR - 1) % WR][k], nbp, k);                                                \
+      if constexpr (LB) K_B_LOAD(bq[((BS) + WR - 1) % WR][k], nbp, k);                              \
       if (k < 4 || five) K_MFMA(af[k & 1], bq[BS][k]);                                              \
-      if constexpr (CGD_KCONV_FINE && TH == KTH) { /* round 6: the passes spread evenly over the k-step slots (4 passes: 1, 1, 1, 1, 0) */ \
+      if constexpr (!(SP)) {                                                                        \
+      } else if constexpr (CGD_KCONV_FINE && TH == KTH) { /* round 6: the passes spread evenly over the k-step slots (4 passes: 1, 1, 1, 1, 0) */ \
         K_PATCH_STORE((S) ^ 1, NXT, (k * KNPASS + KNQ - 1) / KNQ, ((k + 1) * KNPASS + KNQ - 1) / KNQ); \
       } else if constexpr (TH == KTH) {                                                             \
         if (k < KNPASS / 2) K_PATCH_STORE((S) ^ 1, NXT, 2 * k, 2 * k + 2);                          \
@@ -278,13 +288,31 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     // the loop body covers one common period P of the LDS buffer / staging set (2) and the weight set (WR): every index is a compile-time constant
     constexpr int P = WR == 3 ? 6 : 2;
     int c = c0;
-    for (; c + P - 1 < c1; c += P) {
+    if constexpr (WR == 2 && TW == 8 && CGD_KCONV_PEEL) {  // (the 8 x 8 tile: the other tiles have no registers for the extra copies)
+      for (; c + 3 < c1; c += 2) {  // both chunks of the pair have two successors
+        K_CHUNK(0, buf0, buf1, c, 0, 1, 1, 1);
+        K_CHUNK(1, buf1, buf0, c + 1, 1, 1, 1, 1);
+      }
+      const int left = c1 - c;  // 1, 2 or 3 chunks: ... full, penultimate (nothing to fetch two chunks ahead), last (nothing to prepare at all)
+      if (left == 3) {
+        K_CHUNK(0, buf0, buf1, c, 0, 1, 1, 1);
+        K_CHUNK(1, buf1, buf0, c + 1, 1, 0, 1, 1);
+        K_CHUNK(0, buf0, buf1, c + 2, 0, 0, 0, 0);
+      } else if (left == 2) {
+        K_CHUNK(0, buf0, buf1, c, 0, 0, 1, 1);
+        K_CHUNK(1, buf1, buf0, c + 1, 1, 0, 0, 0);
+      } else {
+        K_CHUNK(0, buf0, buf1, c, 0, 0, 0, 0);
+      }
+    } else {
+      for (; c + P - 1 < c1; c += P) {
 #pragma unroll
-      for (int u = 0; u < P; ++u) K_CHUNK(u & 1, ((u & 1) ? buf1 : buf0), ((u & 1) ? buf0 : buf1), c + u, u % WR);
+        for (int u = 0; u < P; ++u) K_CHUNK(u & 1, ((u & 1) ? buf1 : buf0), ((u & 1) ? buf0 : buf1), c + u, u % WR, 1, 1, 1);
+      }
+#pragma unroll
+      for (int u = 0; u < P - 1; ++u)
+        if (c + u < c1) K_CHUNK(u & 1, ((u & 1) ? buf1 : buf0), ((u & 1) ? buf0 : buf1), c + u, u % WR, 1, 1, 1);
     }
-#pragma unroll
-    for (int u = 0; u < P - 1; ++u)
-      if (c + u < c1) K_CHUNK(u & 1, ((u & 1) ? buf1 : buf0), ((u & 1) ? buf0 : buf1), c + u, u % WR);
 #undef K_PATCH_LOAD
 #undef K_SILU
 #undef K_PATCH_STORE
