@@ -673,7 +673,7 @@ bool cgd_gemm_is_gemv(cgd_ctx* ctx, GemmParams p) {
 bool cgd_gemm_fuses_act(cgd_ctx* ctx, GemmParams p) {
   int tile = 0, kernel = 0;
   const std::string keep = ctx->err;
-  const bool ok = !p.conv && ctx->fuse_act && ctx->hgemm_var != 0 && (long)p.M * p.lda < (1L << 31) &&
+  const bool ok = !p.conv && ctx->fuse_act && ctx->hgemm_var != 0 && (long)p.M * p.lda < (1L << 29) &&
                   cgd_plan_gemm(ctx, p, &tile, &kernel) == 0 && kernel == 2 && p.splitk == 1;
   ctx->err = keep;
   return ok;

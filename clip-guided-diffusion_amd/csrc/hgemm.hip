@@ -318,6 +318,25 @@ epilogue:
 #ifndef CGD_HGEMM_EXP
 #define CGD_HGEMM_EXP 0
 #endif
+// CGD_HGEMM_BUFLOAD = 1 (round 6): hgemm2_kernel fetches both operand streams with buffer loads (resource = the tensor, per-lane byte offset in a
+// register that never changes, the chunk / k-step offset in a scalar).  What it buys: (a) the prefetches that run past the end of a slice — the weight
+// ring is 7 k-steps ahead, the activation sets up to 3 chunks — used to re-read the slice's last fragments / last chunk on clamped indices (a 4-chunk
+// slice of a split-K ViT linear issued 7 patch loads for 4 useful ones through the L2 path that bounds this class); with a resource of ZERO records
+// they are out of range, return zeros and touch no memory — no branch in the scheduled region; (b) no 64-bit per-lane address arithmetic per load.
+#ifndef CGD_HGEMM_BUFLOAD
+#define CGD_HGEMM_BUFLOAD 1
+#endif
+typedef int hi32x4 __attribute__((ext_vector_type(4)));
+// neg = a wave-uniform integer: < 0 -> the load is wanted, >= 0 -> it is past the end of the slice (sign bit spread by a scalar shift: a bool select
+// would be lowered through v_cndmask and put the resource into vector registers, i.e. a readfirstlane loop around every load)
+__device__ __forceinline__ hi32x4 h_buf_load16(const void* base, int neg, int voffset, int soffset) {
+  // raw buffer, stride 0; gfx9 resource word 3 = 0x00020000 (DATA_FORMAT 32); num_records 0: every lane is out of range
+  int num;
+  asm("s_ashr_i32 %0, %1, 31" : "=s"(num) : "s"(neg) : "scc");  // (plain C++ is re-written into a compare + select by the optimiser)
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
+}
+
 constexpr int h2_gcd(int a, int b) { return b ? h2_gcd(b, a % b) : a; }
 constexpr int h2_lcm(int a, int b) { return a / h2_gcd(a, b) * b; }
 // RING = weight-fragment ring depth in k-steps (a multiple of 4: slots of a chunk are ring[(4 j) % RING ..]), NSET = staging register sets of
@@ -383,6 +402,11 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
   const long bstride_nb = (long)(p.K >> 5) * 4 * 64;
   // this wavefront's k-steps in its own linear order t = 4 (chunk - c0) + j: k-step (chunk * KG + kg) * 4 + j of the packed weight block
   const uint4* __restrict__ Bw0 = Bg + (long)(nb0 < nbN ? nb0 : nbN - 1) * bstride_nb + lane + (long)(c0 * KG + kg) * 4 * 128;
+  // (buffer loads) the wavefront's weight block as a scalar base: column block and K-group are the same for all its lanes
+  const int wn_s = __builtin_amdgcn_readfirstlane(wn), kg_s = __builtin_amdgcn_readfirstlane(kg);
+  const int nb0_s = (n0 >> 5) + wn_s;
+  const uint4* __restrict__ Bwb = Bg + (long)(nb0_s < nbN ? nb0_s : nbN - 1) * bstride_nb + (long)(c0 * KG + kg_s) * 4 * 128;
+  (void)Bw0; (void)Bwb;
   const int t_last = (c1 - c0) * 4 - 1;
 
   f32x16 acc[NI];
@@ -395,11 +419,21 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
     constexpr int AHEAD = NSET + 1;  // set (C - c0) % NSET holds chunk C + 1 while chunk C runs and is refilled with chunk C + AHEAD
     f32x4 prs[NSET][NPS];
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#if CGD_HGEMM_BUFLOAD
+#define H2_PATCH_LOAD(PR, CH)                                                                     \
+  {                                                                                               \
+    const int in_ = (CH) - c1; /* < 0: inside the slice */                                        \
+    const int so_ = (CH) * (GKW * 4);                                                             \
+    _Pragma("unroll") for (int j = 0; j < NPS; ++j)                                               \
+        PR[j] = __builtin_bit_cast(f32x4, h_buf_load16(Ag, in_, aoff[j] * 4, so_));               \
+  }
+#else
 #define H2_PATCH_LOAD(PR, CH)                                                                     \
   {                                                                                               \
     const float* __restrict__ Ac = Ag + (long)((CH) < c1 ? (CH) : c1 - 1) * GKW;                  \
     _Pragma("unroll") for (int j = 0; j < NPS; ++j) PR[j] = *(const f32x4*)(Ac + aoff[j]);        \
   }
+#endif
 #define H2_PATCH_STORE(PR, DSTB, J0, J1)                                                          \
   {                                                                                               \
     _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                             \
@@ -417,6 +451,15 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
       if constexpr (MODE == 1) DST[i][1] = *(const bf16x8*)&(SRCB)[PLANE + fro[i] + (Q) * 16];    \
     }                                                                                             \
   }
+#if CGD_HGEMM_BUFLOAD
+#define H2_B_LOAD(DST, T)                                                                         \
+  {                                                                                               \
+    const int in_ = (T) - t_last - 1; /* < 0: inside the slice */                                 \
+    const int so_ = (((T) >> 2) * (4 * KG) + ((T) & 3)) * (128 * 16);                             \
+    DST[0] = __builtin_bit_cast(uint4, h_buf_load16(Bwb, in_, lane * 16, so_));                   \
+    if constexpr (MODE == 1) DST[1] = __builtin_bit_cast(uint4, h_buf_load16(Bwb, in_, lane * 16 + 1024, so_)); \
+  }
+#else
 #define H2_B_LOAD(DST, T)                                                                         \
   {                                                                                               \
     const int t_ = (T) < t_last ? (T) : t_last;                                                   \
@@ -424,6 +467,7 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
     DST[0] = q_[0];                                                                               \
     if constexpr (MODE == 1) DST[1] = q_[64];                                                     \
   }
+#endif
 #define H2_MFMA(AQ, BQ)                                                                           \
   {                                                                                               \
     if constexpr (MODE == 1) {                                                                    \
@@ -972,8 +1016,8 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   const int tm = cgd_hgemm_tile_m(ctx, g);
   dim3 grid(cdiv(g.M, tm) * cdiv(g.N, GN), 1, g.splitk > 1 ? g.splitk : 1);
   const bool x3 = ctx->precision == CGD_PREC_BF16X3;
-  // hgemm2 addresses A with 32-bit element offsets
-  const bool v2 = ctx->hgemm_var != 0 && (long)g.M * g.lda < (1L << 31);
+  // hgemm2 addresses A with 32-bit BYTE offsets (buffer loads)
+  const bool v2 = ctx->hgemm_var != 0 && (long)g.M * g.lda < (1L << 29);
   if (g.skip_group && (!v2 || g.splitk > 1 || g.R || g.act_out || g.act_in))
     CGD_FAIL(ctx, "hgemm: skip_group needs hgemm2 in one slice without residual / activation operands");
 #define HG_ARGS grid, dim3(256), 0, s, g.A, (const uint4*)packed, g.C, g.bias, g.R, g.ws, p
