@@ -81,6 +81,20 @@ __device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) 
 #ifndef CGD_KCONV_FINE
 #define CGD_KCONV_FINE 1
 #endif
+// CGD_KCONV_BUFLOAD = 1 (round 6): the patch and weight-fragment prefetches are buffer loads (scalar chunk offset, per-lane offset in a register that
+// never changes); a prefetch past the end of the slice gets a resource of zero records — out of range, returns zeros, touches no memory — where the
+// global loads re-read the slice's last chunk on a clamped index.  One copy of the chunk body (what CGD_KCONV_PEEL needs eight of).
+#ifndef CGD_KCONV_BUFLOAD
+#define CGD_KCONV_BUFLOAD 1
+#endif
+typedef int ki32x4 __attribute__((ext_vector_type(4)));
+// neg: wave-uniform, < 0 = wanted (hgemm.hip h_buf_load16: the scalar shift keeps the resource in scalar registers)
+__device__ __forceinline__ ki32x4 k_buf_load16(const void* base, int neg, int voffset, int soffset) {
+  int num;
+  asm("s_ashr_i32 %0, %1, 31" : "=s"(num) : "s"(neg) : "scc");
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
+}
 // CGD_KCONV_PEEL = 1 (round 6 experiment, default 0): the last two chunks of a slice run copies of the chunk body without the loads / conversions nobody
 // consumes (K_CHUNK) — what pays in wconv_kernel does not here: 162 -> 226 registers for the eight copies of the body and +0.03 ms per step in four
 // same-box pairs (profiles/r6_ab_kconv_peel.txt)
@@ -166,6 +180,9 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     c1 = min(nchunk, c0 + per);
   }
   const uint4* __restrict__ Bw0 = Bg + (long)nb * nchunk * (9 * 4 * 64) + lane;
+  constexpr bool BUFL = CGD_KCONV_BUFLOAD && !NT;  // operand prefetches as buffer loads (see k_buf_load16)
+  const uint4* __restrict__ Bwb = Bg + (long)nb * nchunk * (9 * 4 * 64);  // the workgroup's weight block as a scalar base
+  (void)Bwb;
 
   kf32x16 acc[NPB];
 #pragma unroll
@@ -189,8 +206,13 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
       ga[S][0] = *(const kf32x4*)(gnimg + ch_ * 64);                                                \
       ga[S][1] = *(const kf32x4*)(gnimg + ch_ * 64 + 4);                                            \
     }                                                                                               \
-    _Pragma("unroll") for (int j = 0; j < KNPASS; ++j)                                              \
-        pr[S][j] = *(const kf32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4));                         \
+    if constexpr (BUFL) { /* a chunk past the end of the slice: out of range, no memory touched */  \
+      _Pragma("unroll") for (int j = 0; j < KNPASS; ++j)                                            \
+          pr[S][j] = __builtin_bit_cast(kf32x4, k_buf_load16(Aimg, (CH) - c1, (poff[j] > 0 ? poff[j] : c4 * 4) * 4, (CH) * 128)); \
+    } else {                                                                                        \
+      _Pragma("unroll") for (int j = 0; j < KNPASS; ++j)                                            \
+          pr[S][j] = *(const kf32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4));                       \
+    }                                                                                               \
   }
 #define K_SILU(X, A, B) ({ const float u_ = (X) * (A) + (B); u_ * __builtin_amdgcn_rcpf(1.f + __expf(-u_)); })
 #define K_PATCH_STORE(S, DSTB, J0, J1)                                                              \
@@ -218,6 +240,13 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     const uint4* bp_ = (BASE) + boff[K];                                                            \
     DST[0] = NT ? cgd_load_nt(bp_) : bp_[0];                                                        \
     if constexpr (MODE == 1) DST[1] = NT ? cgd_load_nt(bp_ + 64) : bp_[64];                         \
+  }
+  // (buffer loads) the fragments of chunk CH for k-step slot K: scalar offset, out of range past the end of the slice
+#define K_B_LOAD_BUF(DST, CH, K)                                                                    \
+  {                                                                                                 \
+    const int so_ = ((CH) * (9 * 4 * 64) + boff[K]) * 16;                                           \
+    DST[0] = __builtin_bit_cast(uint4, k_buf_load16(Bwb, (CH) - c1, lane * 16, so_));               \
+    if constexpr (MODE == 1) DST[1] = __builtin_bit_cast(uint4, k_buf_load16(Bwb, (CH) - c1, lane * 16 + 1024, so_)); \
   }
 #define K_MFMA(AQ, BQ)                                                                              \
   {                                                                                                 \
@@ -264,7 +293,8 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     K_A_LOAD(af[0], CUR, 0);                                                                        \
     _Pragma("unroll") for (int k = 0; k < KNQ; ++k) {                                               \
       if (k + 1 < KNQ) K_A_LOAD(af[(k + 1) & 1], CUR, k + 1);                                       \
-      if constexpr (LB) K_B_LOAD(bq[((BS) + WR - 1) % WR][k], nbp, k);                              \
+      if constexpr (LB && BUFL) { K_B_LOAD_BUF(bq[((BS) + WR - 1) % WR][k], (C) + WR - 1, k); }     \
+      else if constexpr (LB) { K_B_LOAD(bq[((BS) + WR - 1) % WR][k], nbp, k); }                     \
       if (k < 4 || five) K_MFMA(af[k & 1], bq[BS][k]);                                              \
       if constexpr (!(SP)) {                                                                        \
       } else if constexpr (CGD_KCONV_FINE && TH == KTH) { /* round 6: the passes spread evenly over the k-step slots (4 passes: 1, 1, 1, 1, 0) */ \
