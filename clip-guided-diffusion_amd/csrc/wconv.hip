@@ -64,6 +64,22 @@ constexpr int WRING = 8, WDIST = WRING - 1;
 #ifndef CGD_WCONV_RING2
 #define CGD_WCONV_RING2 6
 #endif
+// CGD_WCONV_BUFLOAD = 1 (round 6): patch pixels and weight fragments come through buffer loads.  A third of the chunk loop's vector-ALU instructions were
+// address arithmetic (64-bit per-lane adds for 96 fragment loads per chunk, the in-image test + select per patch load) and 48 more zeroed the padding
+// pixels after the load: with a buffer resource the chunk / step offset is a scalar, the per-lane offsets of a thread's 12 patch pixels are computed
+// once, and a padding pixel is an out-of-range offset — the load returns zeros and touches no memory.
+#ifndef CGD_WCONV_BUFLOAD
+#define CGD_WCONV_BUFLOAD 3  // bit 0: weight fragments, bit 1: patch pixels
+#endif
+#define WBUF_W (CGD_WCONV_BUFLOAD & 1)
+#define WBUF_P (CGD_WCONV_BUFLOAD & 2)
+typedef int wi32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wi32x4 w_buf_load16(const void* base, unsigned num_records, int voffset, int soffset) {
+  // raw buffer, stride 0; gfx9 resource word 3 = 0x00020000 (DATA_FORMAT 32); lanes with voffset >= num_records read zeros
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num_records, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
+}
+constexpr int W_OOB = (int)0x80000000;  // per-lane offset of a padding pixel: beyond the 2^31 records of the patch resource
 template <int NB, int OCC = 1>
 __host__ __device__ constexpr int w_load_task(int q) {
   if (OCC == 2) return q == 0 ? 0 : q == 8 ? 1 : q == 16 ? 2 : -1;  // one staging register set: a task is transformed before the next is loaded
@@ -223,6 +239,13 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     const int x = x0 + 2 * sp + k - 1;
     colo[k] = (unsigned)x < (unsigned)p.W ? (p.ups ? x >> 1 : x) * p.lda + c4 * 4 : -1;
   }
+#if WBUF_P
+  int poffv[NTASK][4];  // byte offset of pixel k of task j inside the image, W_OOB for a padding pixel (sign bit = "padding")
+#pragma unroll
+  for (int j = 0; j < NTASK; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) poffv[j][k] = (rowoff[j] | colo[k]) >= 0 ? (rowoff[j] + colo[k]) * 4 : W_OOB;
+#endif
   // ---- fragment reads of this lane: pair column l31 of every block = (tile row 4b + (l31 >> 3), pair l31 & 7)
   const int lr = l31 >> 3, lp = l31 & 7;
   int fro[4];
@@ -235,6 +258,13 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
   const long bstride_nb = (long)nchunk * (WSTEPS * 2 * 64);
   const uint4* __restrict__ Bw0 = Bg + (long)(nb0 < nbN ? nb0 : nbN - 1) * bstride_nb + lane;
   const long bnext = (NC > 1 && nb0 + 1 < nbN) ? bstride_nb : 0;  // offset of the second block's fragments (clamped like the first)
+#if WBUF_W
+  // the wavefront's first weight block as a scalar base, the second block's distance in bytes (a packed tensor is far below 2^31 bytes per block pair)
+  const int nb0_s = (n0 >> 5) + NC * __builtin_amdgcn_readfirstlane(wave);
+  const uint4* __restrict__ Bwb = Bg + (long)(nb0_s < nbN ? nb0_s : nbN - 1) * bstride_nb;
+  const int bnext_b = (NC > 1 && nb0_s + 1 < nbN) ? (int)(bstride_nb * 16) : 0;
+  (void)bnext; (void)bnext_b; (void)Bw0;
+#endif
 
   wf32x16 acc[4][NB][NC];  // [position][pixel block][channel block]
 #pragma unroll
@@ -252,12 +282,22 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
   const wf32x4 z4 = wf32x4{0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ gnimg = GN ? gng + ((long)img * p.Cin + c4 * 4) * 2 : nullptr;
 
+#if WBUF_P
+#define W_TASK_LOAD(ARR, J, CH)                                                                      \
+  {                                                                                                  \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                    \
+        ARR[k] = __builtin_bit_cast(wf32x4, w_buf_load16(Aimg, 0x80000000u, poffv[J][k], (CH) * 128)); \
+  }
+#define W_PIX_OK(J, K) (poffv[J][K] >= 0)
+#else
 #define W_TASK_LOAD(ARR, J, CH)                                                                      \
   {                                                                                                  \
     const float* __restrict__ Ac_ = Aimg + (CH) * 32;                                                \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                    \
         ARR[k] = *(const wf32x4*)(Ac_ + ((rowoff[J] | colo[k]) >= 0 ? rowoff[J] + colo[k] : c4 * 4)); \
   }
+#define W_PIX_OK(J, K) ((rowoff[J] | colo[K]) >= 0)
+#endif
 #define W_GN_LOAD(CH)                                                                                \
   if constexpr (GN) {                                                                                \
     ga[0] = *(const wf32x4*)(gnimg + (CH) * 64);                                                     \
@@ -270,7 +310,8 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     if constexpr (GN)                                                                                \
       v_ = wf32x4{w_silu(v_.x, ga[0].x, ga[0].y), w_silu(v_.y, ga[0].z, ga[0].w), w_silu(v_.z, ga[1].x, ga[1].y),   \
                   w_silu(v_.w, ga[1].z, ga[1].w)};                                                   \
-    ARR[K] = (rowoff[J] | colo[K]) >= 0 ? v_ : z4;                                                   \
+    /* (buffer loads: a padding pixel arrives as zeros; only the fused activation has to be undone) */ \
+    if constexpr (GN || !WBUF_P) ARR[K] = W_PIX_OK(J, K) ? v_ : z4; else ARR[K] = v_;                \
   }
 #define W_TASK_PUT(DSTB, J, XI, V)                                                                   \
   {                                                                                                  \
@@ -302,6 +343,19 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
       DST[b][1] = *(const wbf16x8*)&(SRCB)[WPLANE + o_ + b * (4 * WROW)];                            \
     }                                                                                                \
   }
+#if WBUF_W
+  // BASE = chunk index (scalar): the fragments of step Q of that chunk
+#define W_B_LOAD(DST, BASE, Q)                                                                       \
+  {                                                                                                  \
+    const int so_ = ((BASE) * (WSTEPS * 128) + (Q) * 128) * 16;                                      \
+    DST[0][0] = __builtin_bit_cast(uint4, w_buf_load16(Bwb, 0xffffffffu, lane * 16, so_));           \
+    DST[0][1] = __builtin_bit_cast(uint4, w_buf_load16(Bwb, 0xffffffffu, lane * 16 + 1024, so_));    \
+    if constexpr (NC > 1) {                                                                          \
+      DST[NC - 1][0] = __builtin_bit_cast(uint4, w_buf_load16(Bwb, 0xffffffffu, lane * 16, so_ + bnext_b));        \
+      DST[NC - 1][1] = __builtin_bit_cast(uint4, w_buf_load16(Bwb, 0xffffffffu, lane * 16 + 1024, so_ + bnext_b)); \
+    }                                                                                                \
+  }
+#else
 #define W_B_LOAD(DST, BASE, Q)                                                                       \
   {                                                                                                  \
     const uint4* bp_ = (BASE) + (Q) * 128;                                                           \
@@ -312,6 +366,12 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
       DST[NC - 1][1] = bp_[bnext + 64];                                                              \
     }                                                                                                \
   }
+#endif
+#if WBUF_W
+#define W_BBASE(CH) (CH)
+#else
+#define W_BBASE(CH) (Bw0 + (long)(CH) * (WSTEPS * 128))
+#endif
 #define W_MFMA12(XI, AQ, BQ)                                                                         \
   if constexpr (F32) {                                                                               \
     _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) _Pragma("unroll") for (int e = 0; e < 4; ++e)   \
@@ -333,7 +393,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     // prologue: stage chunk 0 completely, start the weight ring
     W_GN_LOAD(0);
 #pragma unroll
-    for (int q = 0; q < DIST; ++q) W_B_LOAD(bq[q], Bw0, q);
+    for (int q = 0; q < DIST; ++q) W_B_LOAD(bq[q], W_BBASE(0), q);
     wf32x4 pro[NTASK][4];  // all tasks in flight (the accumulators are not live yet)
 #pragma unroll
     for (int j = 0; j < NTASK; ++j) W_TASK_LOAD(pro[j], j, 0);
@@ -372,7 +432,11 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
       if constexpr (!(CGD_WCONV_EXP & 1)) {
         if (bload) {
           const int q2 = (q + DIST) % WSTEPS;
+#if WBUF_W
+          const int base = (q + DIST < WSTEPS) ? c : cn;
+#else
           const uint4* __restrict__ base = (q + DIST < WSTEPS) ? cb : nb;
+#endif
           W_B_LOAD(bq[(q + DIST) % RING], base, q2);
         }
       }
@@ -439,6 +503,8 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
 #undef W_A_LOAD
 #undef W_B_LOAD
 #undef W_MFMA12
+#undef W_BBASE
+#undef W_PIX_OK
 
   // ---- epilogue: output transform in registers.  D = U x V^T in the 32x32 C/D layout: column (lane & 31) = pixel pair, row =
   //      channel (r & 3) + 8 (r >> 2) + 4 hh: accumulator quad g holds channels 8g + 4hh .. + 3 of the lane's pair.
@@ -470,6 +536,9 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
       const int pe = (4 * b + lr) * 16 + 2 * lp;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        // (accumulator quads are copied out of the AGPRs one group at a time: left alone, the scheduler hoists every v_accvgpr_read of the block to the
+        // top of the epilogue and the 512-register instantiations park accumulators in scratch memory — a dispatch with scratch costs +3.7 us)
+        __builtin_amdgcn_sched_barrier(0);
         wf32x4 m[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) m[x] = wf32x4{acc[x][b][cj][4 * g], acc[x][b][cj][4 * g + 1], acc[x][b][cj][4 * g + 2], acc[x][b][cj][4 * g + 3]};
@@ -512,49 +581,53 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     // The second operand of a group of 4 tile rows (the residual, or the norm's input x of the backward sums) comes from global memory behind a
     // ~1.5 us latency and cannot be hoisted by the compiler above the stores of the previous group (it may alias the output): it is fetched one
     // group ahead by hand (rows of different groups never overlap, also when the residual IS the output buffer)
-    wf32x4 opn[8];
+    constexpr int EG = (NC == 2 && CGD_WCONV_BUFLOAD == 3) ? 4 : 8;  // instructions in flight (2 per tile row); the 512-register instantiations have no room for 8
+    wf32x4 opn[EG];
     const bool second = Rg != nullptr || bs_on;
     const float* o2 = Rg ? rp : bxp;
     const long o2row = Rg ? rrow : xrow;
     const int o2ld = Rg ? p.ldr : p.ldbx;
     if (second) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) opn[u] = *(const wf32x4*)&o2[(u >> 1) * o2row + 8 * (u & 1) * o2ld];
+      for (int u = 0; u < EG; ++u) opn[u] = *(const wf32x4*)&o2[(u >> 1) * o2row + 8 * (u & 1) * o2ld];
     }
 #pragma unroll
-    for (int i0 = 0; i0 < 2 * TR; i0 += 8) {  // 8 instructions = 4 tile rows in flight
-      wf32x4 v[8], op[8];
+    for (int i0 = 0; i0 < 2 * TR; i0 += EG) {  // EG instructions = EG / 2 tile rows in flight
+      // (the groups of 4 rows stay apart in the instruction stream: merged by the scheduler they need more registers than the 512-register
+      // instantiations have left next to their accumulators — the allocator then parks accumulators in scratch memory)
+      __builtin_amdgcn_sched_barrier(0);
+      wf32x4 v[EG], op[EG];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const wf32x4*)&((u & 1) ? sl1 : sl0)[(i0 + u) * 256];
+      for (int u = 0; u < EG; ++u) v[u] = *(const wf32x4*)&((u & 1) ? sl1 : sl0)[(i0 + u) * 256];
       if (second) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) op[u] = opn[u];
-        if (i0 + 8 < 2 * TR) {
+        for (int u = 0; u < EG; ++u) op[u] = opn[u];
+        if (i0 + EG < 2 * TR) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) opn[u] = *(const wf32x4*)&o2[((i0 + 8 + u) >> 1) * o2row + 8 * (u & 1) * o2ld];
+          for (int u = 0; u < EG; ++u) opn[u] = *(const wf32x4*)&o2[((i0 + EG + u) >> 1) * o2row + 8 * (u & 1) * o2ld];
         }
       }
       if (Rg) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < EG; ++u) {
           if (hb) v[u] += bv;
           v[u] += op[u];
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < EG; ++u)
           if (hb) v[u] += bv;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) *(wf32x4*)&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc] = v[u];
+      for (int u = 0; u < EG; ++u) *(wf32x4*)&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc] = v[u];
       if (bs_on) {
         // du = dz * SiLU'(x a + b); sums of du and du (x - mean) over the half tile (norm.hip gn_bwd_partial_kernel's arithmetic, v_rcp for the
         // division); x is read like a residual would be (whole lines)
-        const wf32x4(&xv)[8] = op;  // (a launch has a residual or the backward sums, never both: the launcher checks)
+        const wf32x4(&xv)[EG] = op;  // (a launch has a residual or the backward sums, never both: the launcher checks)
         if ((i0 & 15) == 0) q1 = q2 = z4;
         // (vector arithmetic: the compiler packs it into v_pk_fma / v_pk_mul / v_pk_add; the two transcendentals per element dominate)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < EG; ++u) {
           wf32x4 d = v[u];
           if (p.bact) {
             const wf32x4 uu = xv[u] * cfa + cfb;
@@ -566,7 +639,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
           q1 += d;
           q2 += d * (xv[u] - cfm);
         }
-        if ((i0 & 15) == 8) {
+        if ((i0 & 15) == 16 - EG) {
 #pragma unroll
           for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
@@ -589,12 +662,12 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
           for (int e = 0; e < 4; ++e) kk[e] = __shfl(v[0][e], quad, 64);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < EG; ++u) {
           const wf32x4 d = v[u] - kk;
           s1 += d;
           s2 += d * d;
         }
-        if ((i0 & 15) == 8) {  // last 4 rows of the half tile
+        if ((i0 & 15) == 16 - EG) {  // last 4 rows of the half tile
 #pragma unroll
           for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
