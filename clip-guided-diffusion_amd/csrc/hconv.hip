@@ -84,6 +84,22 @@ constexpr int NPASS2 = 6;   // staging passes (both tile heights)
 //     registers anyway (4 VALU + 2 transcendental ops per element, in the shadow of the MFMAs), so the normalised tensor is
 //     never written nor re-read: one read + one write of the tensor and one launch less per ResBlock conv.  Padding positions
 //     stay exact zeros (they are padding of the ACTIVATED tensor).
+// CGD_HCONV_BUFLOAD = 1 (round 6): hconv2_kernel's patch pixels and weight fragments come through buffer loads (wconv.hip / kconv.hip): scalar chunk /
+// k-step offsets instead of 64-bit per-lane address arithmetic, a padding pixel is an out-of-range offset (zeros, no select, no memory access), and the
+// prefetches of the slice's last chunk (its own patch and fragments again, on clamped indices) get a resource of zero records.
+#ifndef CGD_HCONV_BUFLOAD
+#define CGD_HCONV_BUFLOAD 1
+#endif
+typedef int hci32x4 __attribute__((ext_vector_type(4)));
+// neg: wave-uniform, < 0 = the load is wanted; `records` = size of the resource when wanted (lanes with voffset >= records read zeros)
+__device__ __forceinline__ hci32x4 hc_buf_load16(const void* base, int neg, unsigned records, int voffset, int soffset) {
+  int m;
+  asm("s_ashr_i32 %0, %1, 31" : "=s"(m) : "s"(neg) : "scc");  // (a bool select would go through v_cndmask and force a readfirstlane loop per load)
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((unsigned)m & records), 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
+}
+constexpr int HC_OOB = (int)0x80000000;
+
 template <int MODE, int TH, int NJ, bool GN>
 __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict__ Ag, const uint4* __restrict__ Bg, float* Cg,
                                                          const float* __restrict__ biasg, const float* Rg, float* __restrict__ wsg,
@@ -136,6 +152,11 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
       poff[j] = inb ? (yy * Ws + xx) * p.lda + c4 * 4 : -1;  // -1: zero padding
     }
   }
+#if CGD_HCONV_BUFLOAD
+  int poffb[NPASS2];  // the same as byte offsets for the buffer loads: padding and beyond-the-patch slots are out of range
+#pragma unroll
+  for (int j = 0; j < NPASS2; ++j) poffb[j] = poff[j] >= 0 ? poff[j] * 4 : HC_OOB;
+#endif
   // this lane's pixels (one per 32-pixel block of the wavefront's NI): patch position and output row
   int fro[NI];
   long mrow[NI];  // output row of this lane's pixel, or -1 for a tile column beyond the image (W not a multiple of 16)
@@ -160,6 +181,13 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
   const int nbc = nb0 < nbN ? nb0 : nbN - 1;  // clamped first block
   const long bj1 = (nb0 + 1 < nbN) ? bstride_nb : 0;
   const uint4* __restrict__ Bw0 = Bg + (long)nbc * bstride_nb + lane;
+#if CGD_HCONV_BUFLOAD
+  // the wavefront's first weight block as a scalar base, the second block's distance in bytes
+  const int nb0_s = (n0 >> 5) + __builtin_amdgcn_readfirstlane(wn) * NJ;
+  const uint4* __restrict__ Bwb = Bg + (long)(nb0_s < nbN ? nb0_s : nbN - 1) * bstride_nb;
+  const int bj1_b = (nb0_s + 1 < nbN) ? (int)(bstride_nb * 16) : 0;
+  (void)Bw0; (void)bj1; (void)bj1_b;
+#endif
 
   f32x16 acc[NI][NJ];
 #pragma unroll
@@ -174,16 +202,31 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ gnimg = GN ? gng + ((long)img * p.Cin + c4 * 4) * 2 : nullptr;
 
-#define PATCH_LOAD2(CH)                                                                             \
+#if CGD_HCONV_BUFLOAD
+  // CH: the chunk to fetch; WANT < 0: it exists (else: nothing is read)
+#define PATCH_LOAD2(CH, WANT)                                                                       \
   {                                                                                                 \
-    const float* __restrict__ Ac = Aimg + (CH) * 32;                                                \
     if constexpr (GN) {                                                                             \
-      ga[0] = *(const f32x4*)(gnimg + (CH) * 64);                                                   \
-      ga[1] = *(const f32x4*)(gnimg + (CH) * 64 + 4);                                               \
+      const int cg_ = (WANT) < 0 ? (CH) : (CH) - 1;                                                 \
+      ga[0] = *(const f32x4*)(gnimg + cg_ * 64);                                                    \
+      ga[1] = *(const f32x4*)(gnimg + cg_ * 64 + 4);                                                \
+    }                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NPASS2; ++j)                                              \
+        pr[j] = __builtin_bit_cast(f32x4, hc_buf_load16(Aimg, (WANT), 0x80000000u, poffb[j], (CH) * 128)); \
+  }
+#else
+#define PATCH_LOAD2(CH, WANT)                                                                       \
+  {                                                                                                 \
+    const int ch_ = (WANT) < 0 ? (CH) : (CH) - 1;                                                   \
+    const float* __restrict__ Ac = Aimg + ch_ * 32;                                                 \
+    if constexpr (GN) {                                                                             \
+      ga[0] = *(const f32x4*)(gnimg + ch_ * 64);                                                    \
+      ga[1] = *(const f32x4*)(gnimg + ch_ * 64 + 4);                                                \
     }                                                                                               \
     _Pragma("unroll") for (int j = 0; j < NPASS2; ++j)                                              \
         pr[j] = *(const f32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4)); /* zeroed at store time */  \
   }
+#endif
 #define GN_SILU(X, A, B) ({ const float u_ = (X) * (A) + (B); u_ * __builtin_amdgcn_rcpf(1.f + __expf(-u_)); })  /* v_rcp_f32: 1 ulp */
 #define PATCH_STORE2(DSTB, J0, J1)                                                                  \
   {                                                                                                 \
@@ -192,7 +235,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
       if constexpr (GN)                                                                             \
         v = f32x4{GN_SILU(v.x, ga[0].x, ga[0].y), GN_SILU(v.y, ga[0].z, ga[0].w), GN_SILU(v.z, ga[1].x, ga[1].y),  \
                   GN_SILU(v.w, ga[1].z, ga[1].w)};                                                  \
-      v = poff[j] >= 0 ? v : z4;                                                                    \
+      if constexpr (GN || !CGD_HCONV_BUFLOAD) v = poff[j] >= 0 ? v : z4; /* (buffer loads: padding arrives as zeros) */ \
       const bf16x4 hi = to_bf16x4(v);                                                               \
       *(bf16x4*)&(DSTB)[soff[j]] = hi;                                                              \
       if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + soff[j]] = to_bf16x4(residual4(v, hi));    \
@@ -208,9 +251,22 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     }                                                                                               \
   }
   // B fragments of k-step (TAP, KS) of the chunk whose block base is BASE: [channel block j][plane]
-#define B_LOAD2(DST, BASE, TAP, KS)                                                                 \
+#if CGD_HCONV_BUFLOAD
+  // BASE = chunk index; WANT < 0: the chunk exists
+#define B_LOAD2(DST, BASE, WANT, TAP, KS)                                                           \
   {                                                                                                 \
-    const uint4* bp_ = (BASE) + ((TAP) * 4 + (KS) * 2) * 64;                                        \
+    const int so_ = ((BASE) * (9 * 4 * 64) + ((TAP) * 4 + (KS) * 2) * 64) * 16;                     \
+    DST[0][0] = __builtin_bit_cast(uint4, hc_buf_load16(Bwb, (WANT), 0xffffffffu, lane * 16, so_)); \
+    if constexpr (MODE == 1) DST[0][1] = __builtin_bit_cast(uint4, hc_buf_load16(Bwb, (WANT), 0xffffffffu, lane * 16 + 1024, so_)); \
+    if constexpr (NJ == 2) {                                                                        \
+      DST[1][0] = __builtin_bit_cast(uint4, hc_buf_load16(Bwb, (WANT), 0xffffffffu, lane * 16, so_ + bj1_b)); \
+      if constexpr (MODE == 1) DST[1][1] = __builtin_bit_cast(uint4, hc_buf_load16(Bwb, (WANT), 0xffffffffu, lane * 16 + 1024, so_ + bj1_b)); \
+    }                                                                                               \
+  }
+#else
+#define B_LOAD2(DST, BASE, WANT, TAP, KS)                                                           \
+  {                                                                                                 \
+    const uint4* bp_ = Bw0 + (long)((WANT) < 0 ? (BASE) : (BASE) - 1) * (9 * 4 * 64) + ((TAP) * 4 + (KS) * 2) * 64; \
     DST[0][0] = bp_[0];                                                                             \
     if constexpr (MODE == 1) DST[0][1] = bp_[64];                                                   \
     if constexpr (NJ == 2) {                                                                        \
@@ -218,6 +274,7 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
       if constexpr (MODE == 1) DST[1][1] = bp_[bj1 + 64];                                           \
     }                                                                                               \
   }
+#endif
   // 12 MFMAs of one k-step; product-major so that the same accumulator recurs only every 4th instruction
 #define MFMA12(AQ, BQ)                                                                              \
   {                                                                                                 \
@@ -239,10 +296,9 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
   bf16x8 af[2][NI][NPL];     // [pipeline slot][pixel block][plane]
   uint4 bq[RING][NJ][NPL];   // [ring slot][channel block][plane]
   if (c0 < c1) {
-    PATCH_LOAD2(c0);
-    const uint4* __restrict__ cb = Bw0 + (long)c0 * (9 * 4 * 64);
+    PATCH_LOAD2(c0, -1);
 #pragma unroll
-    for (int q = 0; q < DIST; ++q) B_LOAD2(bq[q], cb, q >> 1, q & 1);
+    for (int q = 0; q < DIST; ++q) B_LOAD2(bq[q], c0, -1, q >> 1, q & 1);
     PATCH_STORE2(lds, 0, NPASS2);
   }
   __syncthreads();
@@ -250,10 +306,11 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
     const bool more = c + 1 < c1;
     const __bf16* cur = lds + ((c - c0) & 1) * (NPL * PLANE);
     __bf16* nxt = lds + (((c - c0) & 1) ^ 1) * (NPL * PLANE);
-    const uint4* __restrict__ cb = Bw0 + (long)c * (9 * 4 * 64);
-    const uint4* __restrict__ nb = Bw0 + (long)(c + 1 < nchunk ? c + 1 : c) * (9 * 4 * 64);  // clamped: loads stay unconditional
-    PATCH_LOAD2(more ? c + 1 : c);  // in flight during the first taps; unconditional (the last chunk re-reads its own patch): a
-                                    // branch here makes the wait counts of the first k-step conservative (fragment ring drained)
+    const int want = c + 1 - c1;    // < 0: this slice has a chunk c + 1
+    PATCH_LOAD2(c + 1, want);       // in flight during the first taps; unconditional (a branch here makes the wait counts of the first k-step
+                                    // conservative: fragment ring drained).  The last chunk's prefetches: out-of-range buffer loads (global loads:
+                                    // its own patch / fragments again)
+    (void)more;
     A_LOAD2(af[0], cur, 0, 0);
 #pragma unroll
     for (int q = 0; q < 18; ++q) {
@@ -268,8 +325,8 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
       }
       {
         const int q2 = (q + DIST) % 18;
-        const uint4* __restrict__ base = (q + DIST < 18) ? cb : nb;
-        B_LOAD2(bq[(q + DIST) % RING], base, q2 >> 1, q2 & 1);
+        if (q + DIST < 18) { B_LOAD2(bq[(q + DIST) % RING], c, -1, q2 >> 1, q2 & 1); }
+        else { B_LOAD2(bq[(q + DIST) % RING], c + 1, want, q2 >> 1, q2 & 1); }
       }
       // ---- 12 MFMAs; the conversion of the next chunk's patch rides under k-steps 6..11 (unconditional: the last chunk
       //      rewrites the idle buffer with stale data, so there is no branch inside the scheduling region)
