@@ -329,13 +329,15 @@ epilogue:
 typedef int hi32x4 __attribute__((ext_vector_type(4)));
 // neg = a wave-uniform integer: < 0 -> the load is wanted, >= 0 -> it is past the end of the slice (sign bit spread by a scalar shift: a bool select
 // would be lowered through v_cndmask and put the resource into vector registers, i.e. a readfirstlane loop around every load)
-__device__ __forceinline__ hi32x4 h_buf_load16(const void* base, int neg, int voffset, int soffset) {
+// `records`: size of the resource when the load is wanted — lanes with voffset >= records read zeros (rows beyond M carry the offset H_OOB)
+__device__ __forceinline__ hi32x4 h_buf_load16(const void* base, int neg, int voffset, int soffset, unsigned records = 0xffffffffu) {
   // raw buffer, stride 0; gfx9 resource word 3 = 0x00020000 (DATA_FORMAT 32); num_records 0: every lane is out of range
   int num;
   asm("s_ashr_i32 %0, %1, 31" : "=s"(num) : "s"(neg) : "scc");  // (plain C++ is re-written into a compare + select by the optimiser)
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((unsigned)num & records), 0x00020000);
   return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
 }
+constexpr int H_OOB = (int)0x80000000;
 
 constexpr int h2_gcd(int a, int b) { return b ? h2_gcd(b, a % b) : a; }
 constexpr int h2_lcm(int a, int b) { return a / h2_gcd(a, b) * b; }
@@ -387,6 +389,11 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
     aoff[j] = (ok ? r : p.M - 1) * p.lda + c4 * 4;
     amask |= ok ? (1u << j) : 0u;
   }
+#if CGD_HGEMM_BUFLOAD
+  int aoffb[NPS];  // byte offsets for the buffer loads; a row beyond M is out of range: zeros without a select
+#pragma unroll
+  for (int j = 0; j < NPS; ++j) aoffb[j] = (amask >> j) & 1u ? aoff[j] * 4 : H_OOB;
+#endif
   int fro[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) fro[i] = (i * 32 + l31) * GPHW + hh * 8 + kg * GK;
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
     const int in_ = (CH) - c1; /* < 0: inside the slice */                                        \
     const int so_ = (CH) * (GKW * 4);                                                             \
     _Pragma("unroll") for (int j = 0; j < NPS; ++j)                                               \
-        PR[j] = __builtin_bit_cast(f32x4, h_buf_load16(Ag, in_, aoff[j] * 4, so_));               \
+        PR[j] = __builtin_bit_cast(f32x4, h_buf_load16(Ag, in_, aoffb[j], so_, 0x80000000u));     \
   }
 #else
 #define H2_PATCH_LOAD(PR, CH)                                                                     \
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
   {                                                                                               \
     _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                             \
       const int row = r0 + 16 * j;                                                                \
-      const f32x4 v = (amask >> j) & 1u ? PR[j] : z4;                                             \
+      const f32x4 v = CGD_HGEMM_BUFLOAD ? PR[j] : ((amask >> j) & 1u ? PR[j] : z4);               \
       const bf16x4 hi = g_to_bf16x4(v);                                                           \
       *(bf16x4*)&(DSTB)[row * GPHW + c4 * 4] = hi;                                                \
       if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + row * GPHW + c4 * 4] = g_to_bf16x4(g_residual4(v, hi)); \

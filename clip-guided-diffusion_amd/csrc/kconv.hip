@@ -89,12 +89,14 @@ __device__ __forceinline__ kf32x4 k_residual4(const kf32x4 v, const kbf16x4 hi) 
 #endif
 typedef int ki32x4 __attribute__((ext_vector_type(4)));
 // neg: wave-uniform, < 0 = wanted (hgemm.hip h_buf_load16: the scalar shift keeps the resource in scalar registers)
-__device__ __forceinline__ ki32x4 k_buf_load16(const void* base, int neg, int voffset, int soffset) {
+// `records`: size of the resource when the load is wanted — lanes with voffset >= records read zeros (padding pixels carry the offset K_OOB)
+__device__ __forceinline__ ki32x4 k_buf_load16(const void* base, int neg, int voffset, int soffset, unsigned records = 0xffffffffu) {
   int num;
   asm("s_ashr_i32 %0, %1, 31" : "=s"(num) : "s"(neg) : "scc");
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)((unsigned)num & records), 0x00020000);
   return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
 }
+constexpr int K_OOB = (int)0x80000000;
 // CGD_KCONV_PEEL = 1 (round 6 experiment, default 0): the last two chunks of a slice run copies of the chunk body without the loads / conversions nobody
 // consumes (K_CHUNK) — what pays in wconv_kernel does not here: 162 -> 226 registers for the eight copies of the body and +0.03 ms per step in four
 // same-box pairs (profiles/r6_ab_kconv_peel.txt)
@@ -181,6 +183,10 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
   }
   const uint4* __restrict__ Bw0 = Bg + (long)nb * nchunk * (9 * 4 * 64) + lane;
   constexpr bool BUFL = CGD_KCONV_BUFLOAD && !NT;  // operand prefetches as buffer loads (see k_buf_load16)
+  int poffb[KNPASS];  // byte offsets of the patch slots; padding / beyond-the-patch slots are out of range (zeros without a select)
+#pragma unroll
+  for (int j = 0; j < KNPASS; ++j) poffb[j] = poff[j] >= 0 ? poff[j] * 4 : K_OOB;
+  (void)poffb;
   const uint4* __restrict__ Bwb = Bg + (long)nb * nchunk * (9 * 4 * 64);  // the workgroup's weight block as a scalar base
   (void)Bwb;
 
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
     }                                                                                               \
     if constexpr (BUFL) { /* a chunk past the end of the slice: out of range, no memory touched */  \
       _Pragma("unroll") for (int j = 0; j < KNPASS; ++j)                                            \
-          pr[S][j] = __builtin_bit_cast(kf32x4, k_buf_load16(Aimg, (CH) - c1, (poff[j] > 0 ? poff[j] : c4 * 4) * 4, (CH) * 128)); \
+          pr[S][j] = __builtin_bit_cast(kf32x4, k_buf_load16(Aimg, (CH) - c1, poffb[j], (CH) * 128, 0x80000000u)); \
     } else {                                                                                        \
       _Pragma("unroll") for (int j = 0; j < KNPASS; ++j)                                            \
           pr[S][j] = *(const kf32x4*)(Ac + (poff[j] > 0 ? poff[j] : c4 * 4));                       \
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
       if constexpr (GN)                                                                             \
         v = kf32x4{K_SILU(v.x, ga[S][0].x, ga[S][0].y), K_SILU(v.y, ga[S][0].z, ga[S][0].w), K_SILU(v.z, ga[S][1].x, ga[S][1].y), \
                    K_SILU(v.w, ga[S][1].z, ga[S][1].w)};                                            \
-      v = poff[j] >= 0 ? v : z4;                                                                    \
+      if constexpr (GN || !BUFL) v = poff[j] >= 0 ? v : z4; /* (buffer loads: padding arrives as zeros) */ \
       const kbf16x4 hi = k_bf16x4(v);                                                               \
       *(kbf16x4*)&(DSTB)[soff[j]] = hi;                                                             \
       if constexpr (MODE == 1) *(kbf16x4*)&(DSTB)[KPLANE + soff[j]] = k_bf16x4(k_residual4(v, hi)); \
