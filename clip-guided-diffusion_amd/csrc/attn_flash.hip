@@ -70,11 +70,7 @@ __device__ __forceinline__ void fa_store_nat(__bf16* hi, __bf16* lo, const fa_f3
   for (int i = 0; i < 8; ++i) {
     const fa_f32x4 v = rg[i] * scale;
     fa_bf16x4 h, l;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      h[c] = (__bf16)v[c];
-      l[c] = (__bf16)(v[c] - (float)h[c]);
-    }
+    cgd_split_quad(v, h, l);
     const int off = fa_row(lane, i) * FA_NP + 4 * dq;
     *(fa_bf16x4*)&hi[off] = h;
     *(fa_bf16x4*)&lo[off] = l;
@@ -85,12 +81,9 @@ __device__ __forceinline__ void fa_store_tr(__bf16* hi, __bf16* lo, const fa_f32
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     fa_bf16x8 h, l;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float x = rg[i][c] * scale;
-      h[i] = (__bf16)x;
-      l[i] = (__bf16)(x - (float)h[i]);
-    }
+    const float x8[8] = {rg[0][c] * scale, rg[1][c] * scale, rg[2][c] * scale, rg[3][c] * scale,
+                         rg[4][c] * scale, rg[5][c] * scale, rg[6][c] * scale, rg[7][c] * scale};
+    cgd_split_oct(x8, h, l);
     const int off = (4 * dq + c) * FA_TP + tpos;
     *(fa_bf16x8*)&hi[off] = h;
     *(fa_bf16x8*)&lo[off] = l;
@@ -112,13 +105,10 @@ __device__ __forceinline__ void fa_mma3(fa_f32x16& acc, const fa_bf16x8 xh, cons
 // accumulator registers 8 j .. 8 j + 7 -> the Y operand of k-step j (hi / lo planes)
 __device__ __forceinline__ void fa_split_acc(const float (&p)[16], fa_bf16x8 (&h)[2], fa_bf16x8 (&l)[2]) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float x = p[8 * j + e];
-      h[j][e] = (__bf16)x;
-      l[j][e] = (__bf16)(x - (float)h[j][e]);
-    }
+  for (int j = 0; j < 2; ++j) {
+    const float x8[8] = {p[8 * j], p[8 * j + 1], p[8 * j + 2], p[8 * j + 3], p[8 * j + 4], p[8 * j + 5], p[8 * j + 6], p[8 * j + 7]};
+    cgd_split_oct(x8, h[j], l[j]);
+  }
 }
 // this lane's operand row straight from global memory: row pointer `rp` (already at column 8 hh), 4 k-steps, scaled; `ok` = row exists
 __device__ __forceinline__ void fa_row_frags(fa_bf16x8 (&h)[4], fa_bf16x8 (&l)[4], const float* __restrict__ rp, bool ok, float scale) {
@@ -127,11 +117,7 @@ __device__ __forceinline__ void fa_row_frags(fa_bf16x8 (&h)[4], fa_bf16x8 (&l)[4
     fa_f32x4 a = *(const fa_f32x4*)(rp + 16 * s), b = *(const fa_f32x4*)(rp + 16 * s + 4);
     if (!ok) a = b = fa_f32x4{0.f, 0.f, 0.f, 0.f};
     const float v[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale, b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      h[s][e] = (__bf16)v[e];
-      l[s][e] = (__bf16)(v[e] - (float)h[s][e]);
-    }
+    cgd_split_oct(v, h[s], l[s]);
   }
 }
 // a wavefront parks its [64 d][32 x] accumulator pair (tiles t = 0, 1; lane = x, registers = d rows) as slab[x][d], fp32 pitch FA_OP

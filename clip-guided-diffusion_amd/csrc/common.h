@@ -250,6 +250,45 @@ __device__ __forceinline__ uint4 cgd_load_nt(const uint4* p) {
   return uint4{v.x, v.y, v.z, v.w};
 }
 
+// fp32 quad -> bf16 hi quad + bf16 lo quad (lo = bf16(v - float(hi)): the operands of the bf16x3 products), in the instruction sequence the staging loops
+// want (round 6): per PAIR one v_cvt_pk_bf16_f32 for hi, the two hi values back as floats with one shift and one mask of that packed word, one packed
+// subtract, one v_cvt_pk_bf16_f32 for lo — 10 vector-ALU instructions per quad.  Written element by element (`(__bf16)v.x`, `v.x - (float)hi[0]`) the
+// compiler converts the first pair of every quad three times (packed for the store, each element again for its residual): 13 per quad.  Same values.
+typedef float cgd_f32x2 __attribute__((ext_vector_type(2)));
+typedef float cgd_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cgd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 cgd_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned cgd_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cgd_split_pair(const cgd_f32x2 v, unsigned& hi, unsigned& lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, cgd_bf16x2));
+  const cgd_f32x2 hf = cgd_f32x2{__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, cgd_bf16x2));
+}
+__device__ __forceinline__ void cgd_split_quad(const cgd_f32x4 v, cgd_bf16x4& hi, cgd_bf16x4& lo) {
+  cgd_u32x2 h, l;
+  unsigned a, b;
+  cgd_split_pair(cgd_f32x2{v.x, v.y}, a, b);
+  h.x = a; l.x = b;
+  cgd_split_pair(cgd_f32x2{v.z, v.w}, a, b);
+  h.y = a; l.y = b;
+  hi = __builtin_bit_cast(cgd_bf16x4, h);
+  lo = __builtin_bit_cast(cgd_bf16x4, l);
+}
+
+typedef __bf16 cgd_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void cgd_split_oct(const float (&v)[8], cgd_bf16x8& hi, cgd_bf16x8& lo) {
+  cgd_u32x4 h, l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned a, b;
+    cgd_split_pair(cgd_f32x2{v[2 * p], v[2 * p + 1]}, a, b);
+    h[p] = a;
+    l[p] = b;
+  }
+  hi = __builtin_bit_cast(cgd_bf16x8, h);
+  lo = __builtin_bit_cast(cgd_bf16x8, l);
+}
+
 // ---- GEMM / implicit-GEMM conv ---------------------------------------------------------------
 // C[M][N] = alpha * sum_k A[m][k] * B[n][k] (+ bias[n]) (+ R[m][n]);  A and B are K-contiguous fp32.
 // conv=1: A is an NHWC activation [Bn*H*W][lda] (Cin used channels) and the contraction runs over

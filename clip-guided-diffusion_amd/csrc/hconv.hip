@@ -197,6 +197,9 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // cgd_split_quad (common.h) everywhere but in the largest instantiation: there the longer IR keeps the fully unrolled chunk loop from being formed
+  // before the last scalar-replacement pass and the weight ring lands in scratch memory
+  constexpr bool SPLITQ = !(GN && NJ == 2 && TH == 8);
   f32x4 pr[NPASS2];
   f32x4 ga[GN ? 2 : 1];  // {a0, b0, a1, b1}, {a2, b2, a3, b3} of this thread's 4 channels of the chunk being staged
   const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -236,9 +239,16 @@ __global__ __launch_bounds__(TH * 32) void hconv2_kernel(const float* __restrict
         v = f32x4{GN_SILU(v.x, ga[0].x, ga[0].y), GN_SILU(v.y, ga[0].z, ga[0].w), GN_SILU(v.z, ga[1].x, ga[1].y),  \
                   GN_SILU(v.w, ga[1].z, ga[1].w)};                                                  \
       if constexpr (GN || !CGD_HCONV_BUFLOAD) v = poff[j] >= 0 ? v : z4; /* (buffer loads: padding arrives as zeros) */ \
-      const bf16x4 hi = to_bf16x4(v);                                                               \
-      *(bf16x4*)&(DSTB)[soff[j]] = hi;                                                              \
-      if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + soff[j]] = to_bf16x4(residual4(v, hi));    \
+      if constexpr (MODE == 1 && SPLITQ) {                                                          \
+        bf16x4 hi, lo;                                                                              \
+        cgd_split_quad(v, hi, lo);                                                                  \
+        *(bf16x4*)&(DSTB)[soff[j]] = hi;                                                            \
+        *(bf16x4*)&(DSTB)[PLANE + soff[j]] = lo;                                                    \
+      } else {                                                                                      \
+        const bf16x4 hi = to_bf16x4(v);                                                             \
+        *(bf16x4*)&(DSTB)[soff[j]] = hi;                                                            \
+        if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + soff[j]] = to_bf16x4(residual4(v, hi));  \
+      }                                                                                             \
     }                                                                                               \
   }
   // A fragments of k-step (TAP, KS): [pixel block i][plane]

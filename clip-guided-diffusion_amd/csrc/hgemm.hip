@@ -446,9 +446,14 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
     _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                             \
       const int row = r0 + 16 * j;                                                                \
       const f32x4 v = CGD_HGEMM_BUFLOAD ? PR[j] : ((amask >> j) & 1u ? PR[j] : z4);               \
-      const bf16x4 hi = g_to_bf16x4(v);                                                           \
-      *(bf16x4*)&(DSTB)[row * GPHW + c4 * 4] = hi;                                                \
-      if constexpr (MODE == 1) *(bf16x4*)&(DSTB)[PLANE + row * GPHW + c4 * 4] = g_to_bf16x4(g_residual4(v, hi)); \
+      if constexpr (MODE == 1) {                                                                  \
+        bf16x4 hi, lo;                                                                            \
+        cgd_split_quad(v, hi, lo);                                                                \
+        *(bf16x4*)&(DSTB)[row * GPHW + c4 * 4] = hi;                                              \
+        *(bf16x4*)&(DSTB)[PLANE + row * GPHW + c4 * 4] = lo;                                      \
+      } else {                                                                                    \
+        *(bf16x4*)&(DSTB)[row * GPHW + c4 * 4] = g_to_bf16x4(v);                                  \
+      }                                                                                           \
     }                                                                                             \
   }
 #define H2_A_LOAD(DST, SRCB, Q)                                                                   \
@@ -809,11 +814,9 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const float* __restrict__ Ag
       const f32x4 a0 = aok[i] ? aq[SLOT][i][0] : f32x4{0.f, 0.f, 0.f, 0.f};                       \
       const f32x4 a1 = aok[i] ? aq[SLOT][i][1] : f32x4{0.f, 0.f, 0.f, 0.f};                       \
       bf16x8 ah, al;                                                                              \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
-        ah[e] = (__bf16)a0[e];                                                                    \
-        ah[4 + e] = (__bf16)a1[e];                                                                \
-        al[e] = (__bf16)(a0[e] - (float)ah[e]);                                                   \
-        al[4 + e] = (__bf16)(a1[e] - (float)ah[4 + e]);                                           \
+      {                                                                                           \
+        const float a8_[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};            \
+        cgd_split_oct(a8_, ah, al);                                                               \
       }                                                                                           \
       if constexpr (MODE == 1) {                                                                  \
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[SLOT][0]), al, acc[i], 0, 0, 0); \

@@ -229,9 +229,14 @@ __global__ __launch_bounds__(256, TW == 8 ? 2 : 1) void kconv_kernel(const float
         v = kf32x4{K_SILU(v.x, ga[S][0].x, ga[S][0].y), K_SILU(v.y, ga[S][0].z, ga[S][0].w), K_SILU(v.z, ga[S][1].x, ga[S][1].y), \
                    K_SILU(v.w, ga[S][1].z, ga[S][1].w)};                                            \
       if constexpr (GN || !BUFL) v = poff[j] >= 0 ? v : z4; /* (buffer loads: padding arrives as zeros) */ \
-      const kbf16x4 hi = k_bf16x4(v);                                                               \
-      *(kbf16x4*)&(DSTB)[soff[j]] = hi;                                                             \
-      if constexpr (MODE == 1) *(kbf16x4*)&(DSTB)[KPLANE + soff[j]] = k_bf16x4(k_residual4(v, hi)); \
+      if constexpr (MODE == 1) {                                                                    \
+        kbf16x4 hi, lo;                                                                             \
+        cgd_split_quad(v, hi, lo);                                                                  \
+        *(kbf16x4*)&(DSTB)[soff[j]] = hi;                                                           \
+        *(kbf16x4*)&(DSTB)[KPLANE + soff[j]] = lo;                                                  \
+      } else {                                                                                      \
+        *(kbf16x4*)&(DSTB)[soff[j]] = k_bf16x4(v);                                                  \
+      }                                                                                             \
     }                                                                                               \
   }
 #define K_A_LOAD(DST, SRCB, K)                                                                      \

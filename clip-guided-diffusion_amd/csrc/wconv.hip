@@ -319,9 +319,10 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     if constexpr (F32) {                                                                             \
       *(wf32x4*)&(DSTB)[wbase[J] + (XI) * 256] = t_;                                                 \
     } else {                                                                                         \
-      const wbf16x4 hi_ = w_bf16x4(t_);                                                              \
+      wbf16x4 hi_, lo_;                                                                              \
+      cgd_split_quad(t_, hi_, lo_);                                                                  \
       *(wbf16x4*)&(DSTB)[wbase[J] + (XI) * 256] = hi_;                                               \
-      *(wbf16x4*)&(DSTB)[WPLANE + wbase[J] + (XI) * 256] = w_bf16x4(w_residual4(t_, hi_));           \
+      *(wbf16x4*)&(DSTB)[WPLANE + wbase[J] + (XI) * 256] = lo_;                                      \
     }                                                                                                \
   }
   // a task is transformed in six pieces (w_proc_task)
