@@ -607,6 +607,9 @@ def main():
                 # one number to compare records from different boxes by: the step scaled to a box whose canonical layer takes 150 us (the three lines
                 # of round 6 — 18.05 / 18.53 / 18.72 ms on boxes with 147.3 / 152.6 / 151.8 us — become 18.38 / 18.22 / 18.50: +-0.8 % instead of +-1.8 %)
                 box["ms_per_step_scaled_to_wconv_ref_150us"] = round(res["ms_per_step"] * 150.0 / box["wconv_ref_us_random"], 3)
+                # (the reference layer runs the BUILD's own kernel: this figure compares lines of one build across boxes; across builds use
+                # mfma_tflops — e.g. the second half of round 6 made the layer itself 4 % faster: 150 -> 144 us on the same class of box)
+                box["scaled_figure_scope"] = "same build, different boxes"
             res["box_calibration"] = box
         if roof:
             res["roofline"] = roof
