@@ -32,6 +32,9 @@ int cgd_launch_ln_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dy, in
 int cgd_launch_pool2x2(cgd_ctx* ctx, const float* in, int ldi, float* out, int ldo, const float* add, int ldadd, int B, int Ho,
                        int Wo, int C, float scale, hipStream_t s);
 // out[b,y,x,:] = scale * in[b,y/2,x/2,:] (+ add)
+// two resamplings of equal shape in one launch: up = 0: 2 x 2 sums * scale, 1: nearest 2x * scale (elem.hip resample2x_pair_kernel)
+int cgd_launch_resample2x_pair(cgd_ctx* ctx, int up, const float* in0, int ldi0, float* out0, int ldo0, const float* in1, int ldi1, float* out1,
+                               int ldo1, int B, int Ho, int Wo, int C, float scale, hipStream_t s);
 int cgd_launch_upsample2x(cgd_ctx* ctx, const float* in, int ldi, float* out, int ldo, const float* add, int ldadd, int B, int Ho,
                           int Wo, int C, float scale, hipStream_t s);
 // out = a (+ b), 2-D with row strides

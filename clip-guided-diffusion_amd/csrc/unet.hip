@@ -190,8 +190,8 @@ int ResBlock::fwd(UNet& u, TV xin, int Bn, int& Hh, int& Ww, TV* o, hipStream_t 
   if (down) {
     CGD_TRY(u.ensure(h1p, npo * cin));
     CGD_TRY(u.ensure(xr, npo * cin));
-    CGD_TRY(cgd_launch_pool2x2(ctx, h1.p, cin, h1p.p, cin, nullptr, 0, B, Ho, Wo, cin, 0.25f, s));
-    CGD_TRY(cgd_launch_pool2x2(ctx, x.p, x.ld, xr.p, cin, nullptr, 0, B, Ho, Wo, cin, 0.25f, s));
+    // h branch and skip branch in one launch
+    CGD_TRY(cgd_launch_resample2x_pair(ctx, 0, h1.p, cin, h1p.p, cin, x.p, x.ld, xr.p, cin, B, Ho, Wo, cin, 0.25f, s));
     c1.A = h1p.p; c1.lda = cin;
     skip_src = xr.p;
     skip_ld = cin;
@@ -257,13 +257,9 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   // skip path into dx first (GN1's backward accumulates on top of it further down)
   const float* add = nullptr;
   int ldadd = 0;
-  if (down) {
-    // x_upd = AvgPool2d(2): adjoint = nearest upsample * 0.25
-    CGD_TRY(cgd_launch_upsample2x(ctx, dout.p, dout.ld, dx.p, cin, nullptr, 0, B, H, W, cin, 0.25f, s));  // identity skip
-    add = dx.p; ldadd = cin;
-  } else if (up) {
-    // nearest upsample adjoint = 2x2 sum
-    CGD_TRY(cgd_launch_pool2x2(ctx, dout.p, dout.ld, dx.p, cin, nullptr, 0, B, H, W, cin, 1.f, s));
+  if (down || up) {
+    // identity skip of a resampling block: x_upd = AvgPool2d(2) (adjoint = nearest upsample * 0.25) or nearest upsample (adjoint = 2 x 2 sum) of dout
+    // into dx — launched together with the same resampling of d1 behind conv1's dgrad below (round 6: one launch for the two)
     add = dx.p; ldadd = cin;
   } else if (skip_conv) {
     GemmParams sk;
@@ -287,11 +283,11 @@ int ResBlock::bwd(UNet& u, TV dout, TV* din, hipStream_t s) {
   const float* dh1 = d1.p;
   if (down) {
     CGD_TRY(u.ensure(d1f, npi * cin));
-    CGD_TRY(cgd_launch_upsample2x(ctx, d1.p, cin, d1f.p, cin, nullptr, 0, B, H, W, cin, 0.25f, s));
+    CGD_TRY(cgd_launch_resample2x_pair(ctx, 1, d1.p, cin, d1f.p, cin, dout.p, dout.ld, dx.p, cin, B, H, W, cin, 0.25f, s));
     dh1 = d1f.p;
   } else if (up) {
     CGD_TRY(u.ensure(d1f, npi * cin));
-    CGD_TRY(cgd_launch_pool2x2(ctx, d1.p, cin, d1f.p, cin, nullptr, 0, B, H, W, cin, 1.f, s));
+    CGD_TRY(cgd_launch_resample2x_pair(ctx, 0, d1.p, cin, d1f.p, cin, dout.p, dout.ld, dx.p, cin, B, H, W, cin, 1.f, s));
     dh1 = d1f.p;
   }
   // + the gradient of the skip connection that read this block's input (fused here instead of a separate add pass)
