@@ -28,6 +28,40 @@ def test_library_exports_every_declared_symbol():
     assert handle.cgd_version().startswith(b"cgd_mi355x")
 
 
+def test_no_kernel_of_the_library_uses_scratch_memory():
+    """Round 6 (profiles/r6_ab_wconv_peel_variants.txt): a dispatch of a kernel that needs scratch memory costs +3.7 us on this stack, and a spilled
+    register or an array the compiler could not keep in registers shows up nowhere else.  The AMDGPU metadata of every gfx950 code object in the
+    built library must say private_segment_fixed_size = 0 and no spilled vector registers, for every kernel (scalar registers spill into lanes of a
+    vector register, not into memory: not counted)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("no ROCm LLVM tools: the code objects cannot be read here")
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "lib.so")  # (llvm-objdump --offloading extracts next to its input)
+        shutil.copy(lib.LIB_PATH, so)
+        subprocess.run([f"{llvm}/llvm-objdump", "--offloading", so], check=True, capture_output=True, timeout=300)
+        objs = sorted(glob.glob(so + ".*gfx950"))
+        assert len(objs) >= 10, objs
+        kernels, bad = 0, []
+        for o in objs:
+            notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", o], check=True, capture_output=True, text=True, timeout=300).stdout
+            name = None
+            for line in notes.splitlines():
+                m = re.match(r"\s*\.name:\s+(\S+)", line)
+                if m:
+                    name = m.group(1)
+                    kernels += 1
+                m = re.match(r"\s*\.(private_segment_fixed_size|vgpr_spill_count):\s+(\d+)", line)
+                if m and int(m.group(2)) != 0:
+                    bad.append((name, m.group(1), int(m.group(2))))
+        assert kernels >= 150, kernels
+        assert not bad, bad
+
+
 def test_pure_helpers_without_gpu():
     handle = lib.load()
     assert handle.cgd_op_gn_scratch_floats(1, 4096, 256) > 0
