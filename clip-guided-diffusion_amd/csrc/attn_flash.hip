@@ -54,15 +54,25 @@ __device__ __forceinline__ int fa_row(int lane, int i) {
   const int qg = lane >> 4;
   return 16 * (qg >> 1) + 4 * (qg & 1) + (i & 3) + 8 * (i >> 2);
 }
+// (round 6) the staging loads are buffer loads: the resource ends behind the block's last valid row, so the rows beyond T are out of range — zeros
+// without an index select and four data selects per row — and a load costs no 64-bit per-lane address arithmetic.  `src`: wave-uniform pointer to the
+// block's row 0, nvalid >= 1 rows exist.
+typedef int fa_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ const void* fa_uniform(const void* p) {
+  const unsigned long v = (unsigned long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const void*)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fa_rows_rsrc(const float* src, long ld, int nvalid) {
+  const int nv = __builtin_amdgcn_readfirstlane(nvalid < 32 ? nvalid : 32);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(fa_uniform(src)), 0, nv * (int)ld * 4, 0x00020000);
+}
 __device__ __forceinline__ void fa_gload(fa_f32x4 (&rg)[8], const float* __restrict__ src, long ld, int nvalid, int lane) {
   const int dq = lane & 15;
+  const __amdgpu_buffer_rsrc_t rs = fa_rows_rsrc(src, ld, nvalid);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = fa_row(lane, i);
-    const bool ok = r < nvalid;
-    rg[i] = *(const fa_f32x4*)(src + (long)(ok ? r : 0) * ld + 4 * dq);
-    if (!ok) rg[i] = fa_f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int i = 0; i < 8; ++i)
+    rg[i] = __builtin_bit_cast(fa_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (fa_row(lane, i) * (int)ld + 4 * dq) * 4, 0, 0));
 }
 __device__ __forceinline__ void fa_store_nat(__bf16* hi, __bf16* lo, const fa_f32x4 (&rg)[8], float scale, int lane) {
   const int dq = lane & 15;
@@ -110,12 +120,16 @@ __device__ __forceinline__ void fa_split_acc(const float (&p)[16], fa_bf16x8 (&h
     cgd_split_oct(x8, h[j], l[j]);
   }
 }
-// this lane's operand row straight from global memory: row pointer `rp` (already at column 8 hh), 4 k-steps, scaled; `ok` = row exists
-__device__ __forceinline__ void fa_row_frags(fa_bf16x8 (&h)[4], fa_bf16x8 (&l)[4], const float* __restrict__ rp, bool ok, float scale) {
+// this lane's operand row (row l31 of the 32-row block at the wave-uniform pointer `blk`, of which nvalid >= 1 exist; columns from 8 hh) straight from
+// global memory: 4 k-steps, scaled; a row beyond the block's valid rows reads zeros (buffer resource, see fa_gload)
+__device__ __forceinline__ void fa_row_frags(fa_bf16x8 (&h)[4], fa_bf16x8 (&l)[4], const float* __restrict__ blk, long ld, int nvalid, int l31, int hh,
+                                             float scale) {
+  const __amdgpu_buffer_rsrc_t rs = fa_rows_rsrc(blk, ld, nvalid);
+  const int vo = (l31 * (int)ld + 8 * hh) * 4;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    fa_f32x4 a = *(const fa_f32x4*)(rp + 16 * s), b = *(const fa_f32x4*)(rp + 16 * s + 4);
-    if (!ok) a = b = fa_f32x4{0.f, 0.f, 0.f, 0.f};
+    const fa_f32x4 a = __builtin_bit_cast(fa_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 64 * s, 0, 0));
+    const fa_f32x4 b = __builtin_bit_cast(fa_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 64 * s + 16, 0, 0));
     const float v[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale, b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
     cgd_split_oct(v, h[s], l[s]);
   }
@@ -143,10 +157,7 @@ __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(const float* __rest
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z, q0 = qb * 32;
   const float* __restrict__ base = qkv + (long)n * T * ldq + h * step;
   fa_bf16x8 qh[4], ql[4];
-  {
-    const bool ok = q0 + l31 < T;
-    fa_row_frags(qh, ql, base + qo + (long)(ok ? q0 + l31 : 0) * ldq + 8 * hh, ok, alpha);
-  }
+  fa_row_frags(qh, ql, base + qo + (long)q0 * ldq, ldq, T - q0, l31, hh, alpha);
   __bf16* const Kh = lds + w * FA_FWD_WAVE;
   __bf16* const Kl = Kh + FA_NPLANE;
   __bf16* const Vh = Kl + FA_NPLANE;
@@ -177,12 +188,18 @@ __global__ __launch_bounds__(256) void attn_flash_fwd_kernel(const float* __rest
 #pragma unroll
     for (int s = 0; s < 4; ++s) fa_mma3(sacc, fa_frag_nat(Kh, l31, hh, s), fa_frag_nat(Kl, l31, hh, s), qh[s], ql[s]);
     float p[16], bm = -INFINITY;
+    if (b * 32 + 32 > T) {  // the ragged last block only (wave-uniform): keys beyond T leave the softmax
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      p[r] = key < T ? sacc[r] : -INFINITY;
-      bm = fmaxf(bm, p[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int key = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        p[r] = key < T ? sacc[r] : -INFINITY;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r] = sacc[r];
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bm = fmaxf(bm, p[r]);
     bm = fmaxf(bm, __shfl_xor(bm, 32, 64));  // the block holds at least one key < T: finite
     const float mn = fmaxf(m_run, bm);
     const float corr = __expf(m_run - mn);   // first block: exp(-inf) = 0
@@ -281,8 +298,8 @@ __global__ __launch_bounds__(256) void attn_flash_bwd_dq_kernel(const float* __r
   const float Dq = Dsh[l31];
   const float lq = lse[((long)n * H + h) * Tq + q0 + l31];  // +inf for rows >= T
   fa_bf16x8 qh[4], ql[4], gh[4], gl[4];
-  fa_row_frags(qh, ql, base + qo + (long)(qok ? q0 + l31 : 0) * ldq + 8 * hh, qok, alpha);
-  fa_row_frags(gh, gl, dob + (long)(qok ? q0 + l31 : 0) * lddo + 8 * hh, qok, 1.f);
+  fa_row_frags(qh, ql, base + qo + (long)q0 * ldq, ldq, T - q0, l31, hh, alpha);
+  fa_row_frags(gh, gl, dob + (long)q0 * lddo, lddo, T - q0, l31, hh, 1.f);
   __bf16* const Kh = lds + w * FA_DQ_WAVE;
   __bf16* const Kl = Kh + FA_NPLANE;
   __bf16* const Kth = Kl + FA_NPLANE;
@@ -365,12 +382,8 @@ __global__ __launch_bounds__(256) void attn_flash_bwd_dkv_kernel(const float* __
   const float* __restrict__ lrow = lse + ((long)n * H + h) * Tq;
   const float* __restrict__ drow = Dbuf + ((long)n * H + h) * Tq;
   fa_bf16x8 kh[4], kl[4], vh[4], vl[4];
-  {
-    const bool ok = k0 + l31 < T;
-    const long r = ok ? k0 + l31 : 0;
-    fa_row_frags(kh, kl, base + ko + r * ldq + 8 * hh, ok, 1.f);
-    fa_row_frags(vh, vl, base + vo + r * ldq + 8 * hh, ok, 1.f);
-  }
+  fa_row_frags(kh, kl, base + ko + (long)k0 * ldq, ldq, T - k0, l31, hh, 1.f);
+  fa_row_frags(vh, vl, base + vo + (long)k0 * ldq, ldq, T - k0, l31, hh, 1.f);
   __bf16* const Qh = lds + w * FA_DKV_WAVE;
   __bf16* const Ql = Qh + FA_NPLANE;
   __bf16* const Qth = Ql + FA_NPLANE;
