@@ -791,6 +791,7 @@ bool cgd_wconv_supported(const cgd_ctx* ctx, const GemmParams& p) {
   if (p.ups && ((p.H | p.W) & 1)) return false;
   if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
   if (p.R && ((p.ldr & 3) || ((uintptr_t)p.R & 15))) return false;
+  if ((long)p.H * p.W * p.lda * 4 >= (1L << 31)) return false;  // (buffer loads) 31-bit byte offsets inside one image; offset 2^31 marks a padding pixel
   return true;
 }
 
