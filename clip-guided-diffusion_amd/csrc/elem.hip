@@ -5,6 +5,25 @@
 
 namespace {
 
+// CGD_ELEM_NT (A/B builds; measured neutral, profiles/r6_ab_nt_more.txt: default 0): bit 0 = the stores of pool2x2 / upsample2x / the pair kernel
+// non-temporal, bit 1 = the loads of the 2 x 2 sums (every input element is read exactly once)
+#ifndef CGD_ELEM_NT
+#define CGD_ELEM_NT 0
+#endif
+typedef float el_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 el_ld4(const float* p) {
+  if constexpr (NT) {
+    const el_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const el_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *(const float4*)p;
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void el_st4(float* p, const float4 o) {
+  if constexpr (NT) __builtin_nontemporal_store(el_f32x4{o.x, o.y, o.z, o.w}, reinterpret_cast<el_f32x4*>(p)); else *(float4*)p = o;
+}
 __global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
                                                       const float* __restrict__ add, int ldadd, int B, int Ho, int Wo, int C,
                                                       float scale) {
@@ -18,15 +37,15 @@ __global__ __launch_bounds__(256) void pool2x2_kernel(const float* __restrict__ 
     const int y = (int)(t % Ho), b = (int)(t / Ho);
     const long Wi = 2L * Wo;
     const float* p00 = in + (((long)b * 2 * Ho + 2 * y) * Wi + 2 * x) * ldi + q * 4;
-    const float4 a = *(const float4*)p00, c = *(const float4*)(p00 + ldi);
-    const float4 d = *(const float4*)(p00 + Wi * ldi), e = *(const float4*)(p00 + Wi * ldi + ldi);
+    const float4 a = el_ld4<(CGD_ELEM_NT & 2) != 0>(p00), c = el_ld4<(CGD_ELEM_NT & 2) != 0>(p00 + ldi);
+    const float4 d = el_ld4<(CGD_ELEM_NT & 2) != 0>(p00 + Wi * ldi), e = el_ld4<(CGD_ELEM_NT & 2) != 0>(p00 + Wi * ldi + ldi);
     float4 o = make_float4((a.x + c.x + d.x + e.x) * scale, (a.y + c.y + d.y + e.y) * scale, (a.z + c.z + d.z + e.z) * scale,
                            (a.w + c.w + d.w + e.w) * scale);
     if (add) {
       const float4 r = *(const float4*)(add + pix * ldadd + q * 4);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
-    *(float4*)(out + pix * ldo + q * 4) = o;
+    el_st4<(CGD_ELEM_NT & 1) != 0>(out + pix * ldo + q * 4, o);
   }
 }
 
@@ -47,7 +66,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
       const float4 r = *(const float4*)(add + pix * ldadd + q * 4);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
-    *(float4*)(out + pix * ldo + q * 4) = o;
+    el_st4<(CGD_ELEM_NT & 1) != 0>(out + pix * ldo + q * 4, o);
   }
 }
 
@@ -79,12 +98,12 @@ __global__ __launch_bounds__(256) void resample2x_pair_kernel(const ResamplePair
     } else {   // 2 x 2 sum: (arithmetic of pool2x2_kernel)
       const long Wi = 2L * Wo;
       const float* p00 = in + (((long)b * 2 * Ho + 2 * y) * Wi + 2 * x) * ldi + q * 4;
-      const float4 a = *(const float4*)p00, c = *(const float4*)(p00 + ldi);
-      const float4 d = *(const float4*)(p00 + Wi * ldi), e = *(const float4*)(p00 + Wi * ldi + ldi);
+      const float4 a = el_ld4<(CGD_ELEM_NT & 2) != 0>(p00), c = el_ld4<(CGD_ELEM_NT & 2) != 0>(p00 + ldi);
+      const float4 d = el_ld4<(CGD_ELEM_NT & 2) != 0>(p00 + Wi * ldi), e = el_ld4<(CGD_ELEM_NT & 2) != 0>(p00 + Wi * ldi + ldi);
       o = make_float4((a.x + c.x + d.x + e.x) * scale, (a.y + c.y + d.y + e.y) * scale, (a.z + c.z + d.z + e.z) * scale,
                       (a.w + c.w + d.w + e.w) * scale);
     }
-    *(float4*)(out + pix * ldo + q * 4) = o;
+    el_st4<(CGD_ELEM_NT & 1) != 0>(out + pix * ldo + q * 4, o);
   }
 }
 

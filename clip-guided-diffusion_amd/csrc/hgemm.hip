@@ -70,6 +70,7 @@ struct HGemmParams {
   int lep;         // hgemm2, bf16x3: 1 = output block through LDS, whole-line stores / operand reads (ctx->hgemm_epi)
   int skip_group;  // hgemm2, one slice: drop the first row of every group of this many rows, write the rest compactly (GemmParams)
   int nt;      // kgemm_kernel: weight-fragment loads with the non-temporal policy
+  int nt_out;  // hgemm2 LDS epilogue: the output is larger than the L2 (non-temporal stores under CGD_HGEMM_NT)
   int nmajor;  // tile order within the XCD-contiguous runs: 0 = M-tile major (an XCD owns row panels and streams all weights),
                // 1 = N-tile major (an XCD owns weight column panels, read from HBM once and kept in its 4 MB L2; the small
                // activation matrix is what every XCD re-reads): chosen when the weights are the larger operand (N >= M)
@@ -325,6 +326,10 @@ epilogue:
 // they are out of range, return zeros and touch no memory — no branch in the scheduled region; (b) no 64-bit per-lane address arithmetic per load.
 #ifndef CGD_HGEMM_BUFLOAD
 #define CGD_HGEMM_BUFLOAD 1
+#endif
+// CGD_HGEMM_NT (A/B builds; measured neutral, profiles/r6_ab_nt_more.txt: default 0): outputs larger than the L2 (HGemmParams::nt_out, set by the launcher from M * N) are stored with the non-temporal policy
+#ifndef CGD_HGEMM_NT
+#define CGD_HGEMM_NT 0
 #endif
 typedef int hi32x4 __attribute__((ext_vector_type(4)));
 // neg = a wave-uniform integer: < 0 -> the load is wanted, >= 0 -> it is past the end of the slice (sign bit spread by a scalar shift: a bool select
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(256 * KG) void hgemm2_kernel(const float* __restric
           o *= d;
         }
         if (ok[u]) {
-          *(f32x4*)&Cg[row[u] * p.ldc + col] = o;
+          if (CGD_HGEMM_NT && p.nt_out) __builtin_nontemporal_store(o, (f32x4*)&Cg[row[u] * p.ldc + col]); else *(f32x4*)&Cg[row[u] * p.ldc + col] = o;
           if (p.act_out) {  // second output: the activated tensor, same arithmetic as elem.hip act_f
             f32x4 a;
 #pragma unroll
@@ -1023,6 +1028,7 @@ int cgd_launch_hgemm(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   p.act_out = g.act_out; p.act_in = g.act_in; p.ld_act = g.ld_act; p.act = g.act;
   p.skip_group = g.skip_group;
   p.lep = ctx->hgemm_epi;
+  p.nt_out = (long)g.M * g.N * 4 > (32L << 20) ? 1 : 0;  // an output beyond the 32 MB of L2
   const int tm = cgd_hgemm_tile_m(ctx, g);
   dim3 grid(cdiv(g.M, tm) * cdiv(g.N, GN), 1, g.splitk > 1 ? g.splitk : 1);
   const bool x3 = ctx->precision == CGD_PREC_BF16X3;

@@ -508,6 +508,31 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_ch_kernel(const float* __rest
   }
 }
 
+// CGD_GN_NT (round 6): bit 0 = the x / dz streams of gn_bwd_apply_kernel with the non-temporal policy (both are read here for the last time: x is the
+// forward activation, dz the upstream gradient), bit 1 = its dx store (67 MB on the 256 x 256 level: twice the L2).  Same-box: loads -0.07 ms per step,
+// store -0.035, both -0.09 (profiles/r6_ab_gn_bwd_apply_nt.txt); bit 2 = the add / add2 operands (skip-connection gradients, read here for the last
+// time as well): -0.025 (profiles/r6_ab_nt_more.txt); 0 = the default policy everywhere (rounds 1-5)
+#ifndef CGD_GN_NT
+#define CGD_GN_NT 7
+#endif
+typedef float gn_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 gn_ld4(const float* p) {
+  if constexpr (NT) {
+    const gn_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gn_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *(const float4*)p;
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void gn_st4(float* p, const float4 o) {
+  if constexpr (NT) {
+    __builtin_nontemporal_store(gn_f32x4{o.x, o.y, o.z, o.w}, reinterpret_cast<gn_f32x4*>(p));
+  } else {
+    *(float4*)p = o;
+  }
+}
 template <int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz,
                                                            int lddz, float* __restrict__ dx, int lddx, const float* __restrict__ add,
@@ -534,11 +559,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 #pragma unroll
      for (int u = 0; u < GN_UB; ++u) {
        const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
-       vv[u] = *(const float4*)(xb + (long)pc * ldx + q * 4);
-       dd[u] = *(const float4*)(db + (long)pc * lddz + q * 4);
-       if (ab) aa[u] = *(const float4*)(ab + (long)pc * ldadd + q * 4);
+       vv[u] = gn_ld4<(CGD_GN_NT & 1) != 0>(xb + (long)pc * ldx + q * 4);
+       dd[u] = gn_ld4<(CGD_GN_NT & 1) != 0>(db + (long)pc * lddz + q * 4);
+       if (ab) aa[u] = gn_ld4<(CGD_GN_NT & 4) != 0>(ab + (long)pc * ldadd + q * 4);
        if (ab2) {
-         const float4 a2 = *(const float4*)(ab2 + (long)pc * ldadd2 + q * 4);
+         const float4 a2 = gn_ld4<(CGD_GN_NT & 4) != 0>(ab2 + (long)pc * ldadd2 + q * 4);
          if (ab) { aa[u].x += a2.x; aa[u].y += a2.y; aa[u].z += a2.z; aa[u].w += a2.w; } else aa[u] = a2;
        }
      }
@@ -563,7 +588,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         const float4 a = aa[u];
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
       }
-      *(float4*)(ob + (long)p * lddx + q * 4) = o;
+      gn_st4<(CGD_GN_NT & 2) != 0>(ob + (long)p * lddx + q * 4, o);
      }
     }
   }

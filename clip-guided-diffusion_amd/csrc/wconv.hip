@@ -74,12 +74,27 @@ constexpr int WRING = 8, WDIST = WRING - 1;
 #define WBUF_W (CGD_WCONV_BUFLOAD & 1)
 #define WBUF_P (CGD_WCONV_BUFLOAD & 2)
 typedef int wi32x4 __attribute__((ext_vector_type(4)));
+template <int AUX = 0>  // cache policy bits of the instruction (2 = nt)
 __device__ __forceinline__ wi32x4 w_buf_load16(const void* base, unsigned num_records, int voffset, int soffset) {
   // raw buffer, stride 0; gfx9 resource word 3 = 0x00020000 (DATA_FORMAT 32); lanes with voffset >= num_records read zeros
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num_records, 0x00020000);
-  return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, AUX);
 }
-constexpr int W_OOB = (int)0x80000000;  // per-lane offset of a padding pixel: beyond the 2^31 records of the patch resource
+constexpr int W_OOB = (int)0x80000000;
+// CGD_WCONV_NT (round 6): bit 0 = the output tile's stores with the non-temporal policy (a 256 x 256 x 256-channel output is 67 MB: twice the L2, where
+// the next kernel cannot find it anyway), bit 1 = the epilogue's second operand (residual / the norm's input of the backward sums).  Same-box
+// (profiles/r6_ab_wconv_nt.txt): stores -0.035 ms per step, second-operand loads +0.02, both +-0: default 1.  Bit 2 = the patch loads of the chunk loop: +0.09
+#ifndef CGD_WCONV_NT
+#define CGD_WCONV_NT 1
+#endif
+template <bool NT>
+__device__ __forceinline__ wf32x4 w_ld_out(const float* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const wf32x4*>(p)); else return *(const wf32x4*)p;
+}
+template <bool NT>
+__device__ __forceinline__ void w_st_out(float* p, const wf32x4 v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<wf32x4*>(p)); else *(wf32x4*)p = v;
+}  // per-lane offset of a padding pixel: beyond the 2^31 records of the patch resource
 template <int NB, int OCC = 1>
 __host__ __device__ constexpr int w_load_task(int q) {
   if (OCC == 2) return q == 0 ? 0 : q == 8 ? 1 : q == 16 ? 2 : -1;  // one staging register set: a task is transformed before the next is loaded
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
 #define W_TASK_LOAD(ARR, J, CH)                                                                      \
   {                                                                                                  \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                    \
-        ARR[k] = __builtin_bit_cast(wf32x4, w_buf_load16(Aimg, 0x80000000u, poffv[J][k], (CH) * 128)); \
+        ARR[k] = __builtin_bit_cast(wf32x4, w_buf_load16<(CGD_WCONV_NT & 4) ? 2 : 0>(Aimg, 0x80000000u, poffv[J][k], (CH) * 128)); \
   }
 #define W_PIX_OK(J, K) (poffv[J][K] >= 0)
 #else
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     const int o2ld = Rg ? p.ldr : p.ldbx;
     if (second) {
 #pragma unroll
-      for (int u = 0; u < EG; ++u) opn[u] = *(const wf32x4*)&o2[(u >> 1) * o2row + 8 * (u & 1) * o2ld];
+      for (int u = 0; u < EG; ++u) opn[u] = w_ld_out<(CGD_WCONV_NT & 2) != 0>(&o2[(u >> 1) * o2row + 8 * (u & 1) * o2ld]);
     }
 #pragma unroll
     for (int i0 = 0; i0 < 2 * TR; i0 += EG) {  // EG instructions = EG / 2 tile rows in flight
@@ -605,7 +620,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
         for (int u = 0; u < EG; ++u) op[u] = opn[u];
         if (i0 + EG < 2 * TR) {
 #pragma unroll
-          for (int u = 0; u < EG; ++u) opn[u] = *(const wf32x4*)&o2[((i0 + EG + u) >> 1) * o2row + 8 * (u & 1) * o2ld];
+          for (int u = 0; u < EG; ++u) opn[u] = w_ld_out<(CGD_WCONV_NT & 2) != 0>(&o2[((i0 + EG + u) >> 1) * o2row + 8 * (u & 1) * o2ld]);
         }
       }
       if (Rg) {
@@ -620,7 +635,7 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
           if (hb) v[u] += bv;
       }
 #pragma unroll
-      for (int u = 0; u < EG; ++u) *(wf32x4*)&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc] = v[u];
+      for (int u = 0; u < EG; ++u) w_st_out<(CGD_WCONV_NT & 1) != 0>(&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc], v[u]);
       if (bs_on) {
         // du = dz * SiLU'(x a + b); sums of du and du (x - mean) over the half tile (norm.hip gn_bwd_partial_kernel's arithmetic, v_rcp for the
         // division); x is read like a residual would be (whole lines)
