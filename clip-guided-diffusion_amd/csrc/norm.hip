@@ -515,6 +515,9 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_ch_kernel(const float* __rest
 #ifndef CGD_GN_NT
 #define CGD_GN_NT 7
 #endif
+#ifndef CGD_GN_NT_MIN_BYTES
+#define CGD_GN_NT_MIN_BYTES 0
+#endif
 typedef float gn_f32x4 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ float4 gn_ld4(const float* p) {
@@ -533,7 +536,7 @@ __device__ __forceinline__ void gn_st4(float* p, const float4 o) {
     *(float4*)p = o;
   }
 }
-template <int ACT>
+template <int ACT, int NT = CGD_GN_NT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz,
                                                            int lddz, float* __restrict__ dx, int lddx, const float* __restrict__ add,
                                                            int ldadd, const float* __restrict__ add2, int ldadd2, int HW, int C, int chunk,
@@ -559,11 +562,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 #pragma unroll
      for (int u = 0; u < GN_UB; ++u) {
        const int p = pb + u * m.rows, pc = p < p1 ? p : pb;
-       vv[u] = gn_ld4<(CGD_GN_NT & 1) != 0>(xb + (long)pc * ldx + q * 4);
-       dd[u] = gn_ld4<(CGD_GN_NT & 1) != 0>(db + (long)pc * lddz + q * 4);
-       if (ab) aa[u] = gn_ld4<(CGD_GN_NT & 4) != 0>(ab + (long)pc * ldadd + q * 4);
+       vv[u] = gn_ld4<(NT & 1) != 0>(xb + (long)pc * ldx + q * 4);
+       dd[u] = gn_ld4<(NT & 1) != 0>(db + (long)pc * lddz + q * 4);
+       if (ab) aa[u] = gn_ld4<(NT & 4) != 0>(ab + (long)pc * ldadd + q * 4);
        if (ab2) {
-         const float4 a2 = gn_ld4<(CGD_GN_NT & 4) != 0>(ab2 + (long)pc * ldadd2 + q * 4);
+         const float4 a2 = gn_ld4<(NT & 4) != 0>(ab2 + (long)pc * ldadd2 + q * 4);
          if (ab) { aa[u].x += a2.x; aa[u].y += a2.y; aa[u].z += a2.z; aa[u].w += a2.w; } else aa[u] = a2;
        }
      }
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         const float4 a = aa[u];
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
       }
-      gn_st4<(CGD_GN_NT & 2) != 0>(ob + (long)p * lddx + q * 4, o);
+      gn_st4<(NT & 2) != 0>(ob + (long)p * lddx + q * 4, o);
      }
     }
   }
@@ -1306,12 +1309,18 @@ int cgd_launch_gn_bwd(cgd_ctx* ctx, const float* x, int ldx, const float* dz, in
     }
     CGD_LAUNCH(gn_bwd_coef_kernel, dim3(32, B), dim3(256), 0, s, part, nchunk, stats, coef, C, HW, bcoef);
   }
+  // non-temporal streams (CGD_GN_NT) from CGD_GN_NT_MIN_BYTES per tensor on (A/B builds; 0 = always)
+  const bool nt = (long)B * HW * C * 4 >= (long)CGD_GN_NT_MIN_BYTES;
   if (act) {
-    CGD_LAUNCH((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
-                       HW, C, chunk, coef, bcoef);
+    if (nt)
+      CGD_LAUNCH((gn_bwd_apply_kernel<1>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, HW, C, chunk, coef, bcoef);
+    else
+      CGD_LAUNCH((gn_bwd_apply_kernel<1, 0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, HW, C, chunk, coef, bcoef);
   } else {
-    CGD_LAUNCH((gn_bwd_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2,
-                       HW, C, chunk, coef, bcoef);
+    if (nt)
+      CGD_LAUNCH((gn_bwd_apply_kernel<0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, HW, C, chunk, coef, bcoef);
+    else
+      CGD_LAUNCH((gn_bwd_apply_kernel<0, 0>), dim3(nchunk, B), dim3(256), 0, s, x, ldx, dz, lddz, dx, lddx, add, ldadd, add2, ldadd2, HW, C, chunk, coef, bcoef);
   }
   CGD_TRY(cgd_prof_stamp(ctx, &pr, s));
   cgd_prof_push(ctx, &pr);

@@ -87,6 +87,9 @@ constexpr int W_OOB = (int)0x80000000;
 #ifndef CGD_WCONV_NT
 #define CGD_WCONV_NT 1
 #endif
+#ifndef CGD_WCONV_NT_MIN_BYTES
+#define CGD_WCONV_NT_MIN_BYTES 0
+#endif
 template <bool NT>
 __device__ __forceinline__ wf32x4 w_ld_out(const float* p) {
   if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const wf32x4*>(p)); else return *(const wf32x4*)p;
@@ -168,6 +171,7 @@ struct WConvParams {
   const float* bx;     // the norm's forward input, rows like the output
   const float* bcoef;  // {a, b, gcoef, mean} per (sample, channel)
   int ldbx, bact;
+  int nt_out;  // the output tile's stores with the non-temporal policy (CGD_WCONV_NT bit 0; the launcher: outputs of at least CGD_WCONV_NT_MIN_BYTES)
 };
 
 __device__ __forceinline__ wbf16x4 w_bf16x4(const wf32x4 v) {
@@ -634,8 +638,13 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
         for (int u = 0; u < EG; ++u)
           if (hb) v[u] += bv;
       }
+      if ((CGD_WCONV_NT & 1) && p.nt_out) {
 #pragma unroll
-      for (int u = 0; u < EG; ++u) w_st_out<(CGD_WCONV_NT & 1) != 0>(&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc], v[u]);
+        for (int u = 0; u < EG; ++u) w_st_out<true>(&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc], v[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < EG; ++u) w_st_out<false>(&cp[((i0 + u) >> 1) * crow + 8 * (u & 1) * p.ldc], v[u]);
+      }
       if (bs_on) {
         // du = dz * SiLU'(x a + b); sums of du and du (x - mean) over the half tile (norm.hip gn_bwd_partial_kernel's arithmetic, v_rcp for the
         // division); x is read like a residual would be (whole lines)
@@ -828,6 +837,7 @@ int cgd_launch_wconv(cgd_ctx* ctx, const GemmParams& g, hipStream_t s) {
   if (g.gnb_x && g.gnb_coef && merges && (ctx->gn_epi & 2) && !(g.gnb_ldx & 3) && !((uintptr_t)g.gnb_x & 15) && !g.stats && !g.R)
     p.bstat = cgd_chanstats_register(ctx, g.C, g.ldc, g.N, g.M, s, 1);
   ctx->last_wconv_bstat = p.bstat != nullptr;
+  p.nt_out = (long)g.M * g.N * 4 >= (long)CGD_WCONV_NT_MIN_BYTES ? 1 : 0;
   const int nb = cgd_wconv_nb(ctx, g), nc = cgd_wconv_nc(ctx, g);
   dim3 grid((int)cgd_wconv_tiles_m(ctx, g) * cdiv(g.N, 128 * nc));
 #define WC_LAUNCH(GN_, NB_, NC_, F32_) \
