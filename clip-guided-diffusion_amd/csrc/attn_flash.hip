@@ -294,7 +294,6 @@ __global__ __launch_bounds__(256) void attn_flash_bwd_dq_kernel(const float* __r
     }
   }
   __syncthreads();
-  const bool qok = q0 + l31 < T;
   const float Dq = Dsh[l31];
   const float lq = lse[((long)n * H + h) * Tq + q0 + l31];  // +inf for rows >= T
   fa_bf16x8 qh[4], ql[4], gh[4], gl[4];

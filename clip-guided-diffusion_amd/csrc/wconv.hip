@@ -42,7 +42,7 @@ namespace {
 
 constexpr int WROW = 1024;            // bf16 elements per patch row: 4 positions x 8 pairs x 32 channels
 constexpr int WSTEPS = 24;            // (ky, position, kstep) per 32-channel chunk
-constexpr int WRING = 8, WDIST = WRING - 1;
+constexpr int WRING = 8;               // weight-fragment ring of the one-channel-block tiles (steps)
 
 // staging schedule (steps of a chunk): task k of the NEXT chunk is loaded at step w_load_task == k into slot k & 1 and transformed in six pieces
 // (A = pixel 0, B = pixel 2 + position 0, C = pixel 1, D = positions 1 and 2, E = pixel 3, F = position 3) at the steps w_proc_task(q, piece) == k.
@@ -439,13 +439,15 @@ __global__ __launch_bounds__(256, OCC) void wconv_kernel(const float* __restrict
     const int cn = more ? c + 1 : c;  // (CGD_WCONV_PEEL = 0: the last chunk re-stages itself into the idle buffer: no branch in the scheduled region)
     const __bf16* cur = lds + (c & 1) * (2 * WPLANE);
     __bf16* nxt = lds + ((c & 1) ^ 1) * (2 * WPLANE);
+#if !WBUF_W
     const uint4* __restrict__ cb = Bw0 + (long)c * (WSTEPS * 128);
     const uint4* __restrict__ nb = Bw0 + (long)cn * (WSTEPS * 128);
+#endif
     if (stage) W_GN_LOAD(cn);
     W_A_LOAD(af[0], cur, 0);
 #pragma unroll
     for (int q = 0; q < WSTEPS; ++q) {
-      // ---- issue: A fragments one step ahead, B fragments WDIST steps ahead, one staging task every 4 steps
+      // ---- issue: A fragments one step ahead, B fragments DIST steps ahead, the staging task loads of w_load_task
       if constexpr (!(CGD_WCONV_EXP & 8))
         if (q + 1 < WSTEPS) W_A_LOAD(af[(q + 1) & 1], cur, q + 1);
       const bool bload = stage || q + DIST < WSTEPS;  // the last chunk has no successor whose fragments to prefetch
