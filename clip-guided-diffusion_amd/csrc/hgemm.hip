@@ -795,6 +795,12 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const float* __restrict__ Ag
     aok[i] = r < p.M;
     arow[i] = (long)(aok[i] ? r : p.M - 1) * p.lda + 8 * hh;
   }
+  // (buffer loads) byte offset of the lane's row, no clamp: a row beyond M lies beyond the resource of M rows
+  int aoffb[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) aoffb[i] = ((m0 + 32 * i + l31) * p.lda + 8 * hh) * 4;
+  const unsigned arec = (unsigned)p.M * (unsigned)p.lda * 4u;
+  (void)aoffb; (void)arec;
   f32x16 acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -809,15 +815,20 @@ __global__ __launch_bounds__(256) void kgemm_kernel(const float* __restrict__ Ag
     bq[SLOT][0] = p.nt ? cgd_load_nt(Bw + (long)kq_ * 128) : Bw[(long)kq_ * 128];                 \
     if constexpr (MODE == 1) bq[SLOT][1] = p.nt ? cgd_load_nt(Bw + (long)kq_ * 128 + 64) : Bw[(long)kq_ * 128 + 64]; \
     _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
-      aq[SLOT][i][0] = *(const f32x4*)(Ag + arow[i] + 16 * kq_);                                  \
-      aq[SLOT][i][1] = *(const f32x4*)(Ag + arow[i] + 16 * kq_ + 4);                              \
+      if constexpr (CGD_HGEMM_BUFLOAD) { /* rows beyond M and k-steps beyond the wavefront's last: out of range, zeros, no memory access */ \
+        aq[SLOT][i][0] = __builtin_bit_cast(f32x4, h_buf_load16(Ag, (T) - mine, aoffb[i], 64 * kq_, arec));       \
+        aq[SLOT][i][1] = __builtin_bit_cast(f32x4, h_buf_load16(Ag, (T) - mine, aoffb[i] + 16, 64 * kq_, arec));  \
+      } else {                                                                                    \
+        aq[SLOT][i][0] = *(const f32x4*)(Ag + arow[i] + 16 * kq_);                                \
+        aq[SLOT][i][1] = *(const f32x4*)(Ag + arow[i] + 16 * kq_ + 4);                            \
+      }                                                                                           \
     }                                                                                             \
   }
 #define KG_STEP(SLOT)                                                                             \
   {                                                                                               \
     _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
-      const f32x4 a0 = aok[i] ? aq[SLOT][i][0] : f32x4{0.f, 0.f, 0.f, 0.f};                       \
-      const f32x4 a1 = aok[i] ? aq[SLOT][i][1] : f32x4{0.f, 0.f, 0.f, 0.f};                       \
+      const f32x4 a0 = (CGD_HGEMM_BUFLOAD || aok[i]) ? aq[SLOT][i][0] : f32x4{0.f, 0.f, 0.f, 0.f};  \
+      const f32x4 a1 = (CGD_HGEMM_BUFLOAD || aok[i]) ? aq[SLOT][i][1] : f32x4{0.f, 0.f, 0.f, 0.f};  \
       bf16x8 ah, al;                                                                              \
       {                                                                                           \
         const float a8_[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};            \
@@ -948,7 +959,7 @@ int cgd_hgemm_chunks(const GemmParams& p) { return p.K / GK; }
 // a forced launch used to fail with "does not support this problem" when a policy knob said no)
 bool cgd_kgemm_capable(const cgd_ctx* ctx, const GemmParams& p) {
   if ((uintptr_t)p.bias & 15) return false;  // the epilogue reads the bias 16 bytes at a time
-  return p.weight && p.M > 4 && cgd_hgemm_supported(ctx, p) && !p.act_out && !p.act_in && !p.skip_group && p.splitk <= 1 && (long)p.M * p.lda < (1L << 31);
+  return p.weight && p.M > 4 && cgd_hgemm_supported(ctx, p) && !p.act_out && !p.act_in && !p.skip_group && p.splitk <= 1 && (long)p.M * p.lda < (1L << 29);
 }
 bool cgd_kgemm_supported(const cgd_ctx* ctx, const GemmParams& p) {
   const bool rows_ok = p.M <= ctx->kgemm_max_m || (p.M <= ctx->kgemm_big_m && p.N <= ctx->kgemm_big_n);
